@@ -1,0 +1,199 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own Python (through
+oracle/ref_harness.py) on recipe-filled parameters and recipe inputs.
+
+CONTAINER-ONLY (needs /root/reference).  Fixtures are data: inputs, parameters of the
+small modules, expected outputs / gradients.  Run:  python oracle/make_golden.py
+"""
+import os
+import sys
+import json
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "adnm-unet_amd"))
+
+import ref_harness as H  # noqa: E402
+from adnm_hip import recipe  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.manual_seed(0)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (npy(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def module_case(name, mod, inputs, call=None, grad_inputs=()):
+    """Fill `mod` by recipe, run fwd + bwd against a recipe cotangent, save params, inputs,
+    output, input grads and parameter grads."""
+    recipe.fill_parameters(mod)
+    ins = {k: v.clone().requires_grad_(k in grad_inputs) for k, v in inputs.items()}
+    out = call(mod, **ins) if call else mod(**ins)
+    outs = out if isinstance(out, (tuple, list)) else (out,)
+    arrays = {}
+    loss = 0
+    for i, o in enumerate(outs):
+        cot = recipe.tensor(f"{name}.cot{i}", tuple(o.shape))
+        arrays[f"out{i}"] = o
+        arrays[f"cot{i}"] = cot
+        loss = loss + (o * cot).sum()
+    loss.backward()
+    for k, v in ins.items():
+        arrays["in." + k] = v
+        if k in grad_inputs:
+            arrays["gin." + k] = v.grad
+    for k, v in mod.state_dict().items():
+        arrays["p." + k] = v
+    for k, p in mod.named_parameters():
+        if p.grad is not None:
+            arrays["g." + k] = p.grad
+    save(name, **arrays)
+
+
+def main():
+    ref = H.load_reference()
+    A, S, V, Wt, U, Ls = ref.ADNMUNet, ref.ADNssd, ref.Vssd, ref.WTConv2d, ref.model_untils, ref.loss
+    T = recipe.tensor
+
+    # G2 WTConv2d (WTConv2d.py:63-153): even and odd (padded/cropped) sizes
+    module_case("wtconv_c5_l3_16x16", Wt.WTConv2d(5, 5, 5, 1, False, wt_levels=3),
+                {"x": T("wt1.x", (2, 5, 16, 16))}, grad_inputs=("x",))
+    module_case("wtconv_c8_l2_20x28", Wt.WTConv2d(8, 8, 5, 1, True, wt_levels=2),
+                {"x": T("wt2.x", (2, 8, 20, 28))}, grad_inputs=("x",))
+    module_case("wtconv_c4_l3_11x13_k3", Wt.WTConv2d(4, 4, 3, 1, True, wt_levels=3),
+                {"x": T("wt3.x", (1, 4, 11, 13))}, grad_inputs=("x",))
+
+    # G5 K1 alone (ADNssd.py:252-299 single-group branch; Vssd.py:161-208 grouped branch)
+    m = S.Mamba2(d_model=32, headdim=4)
+    x, dt = T("k1.x", (2, 96, 8, 4)), T("k1.dt", (2, 96, 8), 0.1, positive=True)
+    Aneg = -torch.exp(T("k1.alog", (8,), 1.5))
+    Bm, Cm, D = T("k1.B", (2, 96, 16)), T("k1.C", (2, 96, 16)), 1 + 0.1 * T("k1.D", (8,))
+    y = m.non_casual_linear_attn(x, dt, Aneg, Bm, Cm, D, 8, 12)
+    save("k1_single_group", x=x, dt=dt, A=Aneg, B=Bm, C=Cm, D=D, y=y)
+    mv = V.Mamba2(d_model=32, headdim=4)
+    Bg, Cg = T("k1g.B", (2, 96, 32)), T("k1g.C", (2, 96, 32))
+    yg = mv.non_casual_linear_attn(x, dt, Aneg, Bg, Cg, D, 8, 12)
+    save("k1_grouped", x=x, dt=dt, A=Aneg, B=Bg, C=Cg, D=D, y=yg)
+
+    # G3 / G4 mixers
+    module_case("adn_mamba2_d32", S.Mamba2(d_model=32, headdim=4), {"u": T("adn.u", (2, 144, 32))},
+                call=lambda mod, u: mod(u, 12, 12), grad_inputs=("u",))
+    module_case("adn_mamba2_d64_rect", S.Mamba2(d_model=64, headdim=4), {"u": T("adn2.u", (1, 60, 64))},
+                call=lambda mod, u: mod(u, 6, 10), grad_inputs=("u",))
+    module_case("vssd_mamba2_d32", V.Mamba2(d_model=32, headdim=4), {"u": T("vssd.u", (2, 144, 32))},
+                call=lambda mod, u: mod(u, 12, 12), grad_inputs=("u",))
+
+    # G6 Block (ADNMUNet.py:51-168) through create_block (:243-292), eps 1e-6 as create_ADNMUNet
+    module_case("block_32_32", A.create_block(32, 32, headdim=4, norm_epsilon=1e-6), {"x": T("blk.x", (2, 64, 32))},
+                call=lambda mod, x: mod(x), grad_inputs=("x",))
+    module_case("block_res_feat_64_32", A.create_block(64, 32, headdim=4, norm_epsilon=1e-6),
+                {"x": T("blk2.x", (1, 64, 32)), "r": T("blk2.r", (1, 64, 32)), "f": T("blk2.f", (1, 64, 32))},
+                call=lambda mod, x, r, f: mod(x, residual=r, features=f), grad_inputs=("x", "r", "f"))
+    module_case("block_feat_32_16", A.create_block(32, 16, headdim=4, norm_epsilon=1e-6),
+                {"x": T("blk3.x", (1, 16, 32)), "f": T("blk3.f", (1, 16, 32))},
+                call=lambda mod, x, f: mod(x, features=f), grad_inputs=("x", "f"))
+
+    # G7 conv-stack / glue modules (model_untils.py)
+    module_case("attention_d32", A.Attention(32, headdim=4), {"x": T("att.x", (2, 16, 32))},
+                call=lambda mod, x: mod(x), grad_inputs=("x",))
+    module_case("patch_embed_5_16", U.PatchEmbed(img_size=16, patch_size=2, in_channels=5, embed_dim=16, kernel=5, wt_levels=3),
+                {"x": T("pe.x", (2, 256, 5), positive=True)}, call=lambda mod, x: mod(x), grad_inputs=("x",))
+    module_case("wtlayer_16_24", U.WTLayer(16, 24, kernel=5, wt_levels=2), {"x": T("wl.x", (2, 144, 16))},
+                call=lambda mod, x: mod(x), grad_inputs=("x",))
+    module_case("wtlayer_res_16_8", U.WTLayer(16, 8, kernel=5, wt_levels=1, if_res=True),
+                {"x": T("wl2.x", (1, 64, 8)), "r": T("wl2.r", (1, 64, 8)), "f": T("wl2.f", (1, 64, 8))},
+                call=lambda mod, x, r, f: mod(x, residual=r, features=f), grad_inputs=("x", "r"))
+    module_case("outproj_16_6", U.OutProj(num_frames=6, embed_dim=16, img_size=[16, 16], wt_levels=3, out_expand=2),
+                {"x": T("op.x", (2, 256, 16)), "res": T("op.r", (2, 16, 16), positive=True)},
+                call=lambda mod, x, res: mod(x, res), grad_inputs=("x",))
+    module_case("upsample_8", U.UpSample(dim=8, ratio=2), {"x": T("up.x", (2, 16, 8))},
+                call=lambda mod, x: mod(x), grad_inputs=("x",))
+    module_case("downsample_8", U.DownSample(dim=8, ratio=2), {"x": T("dn.x", (2, 64, 8))},
+                call=lambda mod, x: mod(x), grad_inputs=("x",))
+    module_case("e2d_16", U.EncoderToDecoder(embed_dim=16), {"x": T("e2d.x", (2, 64, 16)), "res": T("e2d.r", (2, 64, 16))},
+                call=lambda mod, x, res: mod(x, res), grad_inputs=("x", "res"))
+    dims = [4, 8, 8, 8, 12, 16, 20]
+    sizes = [64, 16, 16, 4, 4, 4, 4]
+
+    def bridge(mod, **kw):
+        d = {i: kw[f"t{i}"] for i in range(7)}
+        out = mod(d)
+        return tuple(out[i] for i in range(7))
+
+    module_case("bridge_small", U.Channel_Att_Bridge(c_list=dims),
+                {f"t{i}": T(f"br.t{i}", (2, sizes[i], dims[i])) for i in range(7)}, call=bridge,
+                grad_inputs=tuple(f"t{i}" for i in range(7)))
+
+    # G8 loss (loss.py:30-57): targets cross the 0.7 heavy-rain threshold; gamma 0 and 0.1
+    pred, tgt = T("loss.p", (2, 20, 1, 16, 16), positive=True), T("loss.t", (2, 20, 1, 16, 16), positive=True)
+    pr = pred.clone().requires_grad_(True)
+    l0 = Ls.enRainfallLoss(0.57, 0.25, gamma=0.0)(pr, tgt)
+    l0.backward()
+    l1 = Ls.enRainfallLoss(0.57, 0.25, gamma=0.1)(pred, tgt)
+    save("en_rainfall_loss", pred=pred, target=tgt, loss_g0=l0, grad_g0=pr.grad, loss_g01=l1)
+
+    # G9 whole model, create_ADNMUNet(5,20,6) configuration
+    manifest = None
+    for size, batch in ((64, 2), (128, 1), (256, 1)):
+        model = H.build_visionmamba(size)
+        if manifest is None:
+            # per-tensor init constant (None for randomly initialised tensors): lets the recipe rebuild
+            # the exact state_dict from this manifest alone, with no model object
+            consts = {}
+            for k, v in model.state_dict().items():
+                f = v.double().flatten()
+                consts[k] = float(f[0]) if bool((f == f[0]).all()) else None
+        recipe.fill_parameters(model)
+        if manifest is None:
+            trainable = {k: p.requires_grad for k, p in model.named_parameters()}
+            manifest = {k: {"shape": list(v.shape), "const": consts[k], "trainable": bool(trainable[k]),
+                            "sum": float(v.double().sum()), "abs": float(v.double().abs().sum())}
+                        for k, v in model.state_dict().items()}
+            with open(os.path.join(OUT, "state_dict_manifest.json"), "w") as f:
+                json.dump(manifest, f, separators=(",", ":"))
+        frames = recipe.radar_batch(batch, 25, size, name=f"radar{size}")
+        x, tgt = frames[:, :5], frames[:, 5:]
+        taps = {}
+        hooks = [model.encoder.register_forward_hook(lambda m, i, o: taps.__setitem__("encoder", o[0])),
+                 model.decoder.register_forward_hook(lambda m, i, o: taps.__setitem__("decoder", o)),
+                 model.refiner.refiner4.register_forward_hook(lambda m, i, o: taps.__setitem__("refiner4", o))]
+        out = model(x)
+        loss = Ls.enRainfallLoss(0.57, 0.25, gamma=0.0)(out, tgt)
+        loss.backward()
+        for h in hooks:
+            h.remove()
+        names = [k for k, _ in model.named_parameters()]
+        gnorm = np.array([float(p.grad.double().norm()) if p.grad is not None else -1.0 for _, p in model.named_parameters()])
+        total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
+        flat = out.flatten()
+        idx = torch.from_numpy((recipe.uniform01(f"sample{size}", 4096) * flat.numel()).astype(np.int64))
+        arrays = dict(out_idx=idx, out_samples=flat[idx], out_norm=out.double().norm(), out_mean=out.double().mean(),
+                      loss=loss, grad_total_norm=total, grad_norms=gnorm, names=np.array(names))
+        for k, v in taps.items():
+            fl = v.flatten()
+            ii = torch.from_numpy((recipe.uniform01(f"tap{k}{size}", 1024) * fl.numel()).astype(np.int64))
+            arrays[f"tap.{k}.idx"], arrays[f"tap.{k}.val"], arrays[f"tap.{k}.norm"] = ii, fl[ii], v.double().norm()
+        if size == 64:
+            arrays["out_full"] = out
+        # one AdamW step with train.py's recipe (train_untils.py:35-42, train.py:140 clip at norm_max 0.025)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2)
+        pre = torch.nn.utils.clip_grad_norm_(model.parameters(), 0.025)
+        opt.step()
+        arrays["clip_pre_norm"] = pre
+        arrays["param_sum_after_step"] = np.array([float(p.double().sum()) for _, p in model.named_parameters()])
+        save(f"visionmamba_{size}_b{batch}", **arrays)
+        del model
+
+
+if __name__ == "__main__":
+    main()

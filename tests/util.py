@@ -1,0 +1,35 @@
+import os
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_case(name):
+    """Returns (params, grads, inputs, input_grads, outs, cots) of a module_case fixture."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    t = lambda k: torch.from_numpy(z[k])
+    pick = lambda pre: {k[len(pre):]: t(k) for k in z.files if k.startswith(pre)}
+    outs = [t(f"out{i}") for i in range(16) if f"out{i}" in z.files]
+    cots = [t(f"cot{i}") for i in range(16) if f"cot{i}" in z.files]
+    return pick("p."), pick("g."), pick("in."), pick("gin."), outs, cots
+
+
+def load_npz(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fi" else z[k]) for k in z.files}
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().flatten(), b.detach().double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def assert_close(a, b, tol, what="", atol=0.0):
+    """rel-L2 check; `atol` (per-element RMS) absorbs tensors that are mathematically zero
+    (e.g. the gradient of a bias that an InstanceNorm removes) and hold only round-off."""
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    err = float((a - b).norm())
+    bound = tol * float(b.norm()) + atol * (b.numel() ** 0.5)
+    assert err <= bound, f"{what}: |err| {err:.3e} > {bound:.3e} (rel-L2 {err / (float(b.norm()) + 1e-30):.3e}, tol {tol:.1e})"
