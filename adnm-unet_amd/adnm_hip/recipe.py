@@ -48,6 +48,8 @@ def _values_for(name, p, salt):
         dt = np.maximum(dt, 1e-4)
         return dt + np.log(-np.expm1(-dt))
     v = sym(name, n, salt)
+    if leaf == "bias":  # zero-initialised (Linear/LayerNorm) or random (conv) biases alike
+        return 0.05 * v
     if p.dim() >= 2 and "_scale" not in name:
         fan_in = max(1, n // p.shape[0])
         return v * math.sqrt(3.0 / fan_in)

@@ -38,11 +38,13 @@ def test_visionmamba(size, batch):
     z = load_npz(f"visionmamba_{size}_b{batch}")
     sd = recipe.state_dict_from_manifest(m)
     names = [str(n) for n in z["names"]]
+    # fp64 oracle: leaves only the reference's own fp32 round-off in the comparison
+    sd = {k: v.double() for k, v in sd.items()}
     params = {k: sd[k].clone().requires_grad_(True) for k in names if m[k]["trainable"]}
     full = dict(sd)
     full.update(params)
     frames = recipe.radar_batch(batch, 25, size, name=f"radar{size}")
-    x, tgt = frames[:, :5], frames[:, 5:]
+    x, tgt = frames[:, :5].double(), frames[:, 5:].double()
     taps = {}
     out = O.vision_mamba(full, x, taps=taps)
     assert out.shape == (batch, 20, 1, size, size)
@@ -56,6 +58,7 @@ def test_visionmamba(size, batch):
     assert abs(float(loss) - float(z["loss"])) <= 2e-5 * abs(float(z["loss"]))
     loss.backward()
     gn = z["grad_norms"].numpy()
+    gtot = float(z["grad_total_norm"])
     sq = 0.0
     for i, k in enumerate(names):
         if not m[k]["trainable"]:
@@ -67,10 +70,12 @@ def test_visionmamba(size, batch):
         assert g is not None, f"{k} has no gradient"
         n = float(g.double().norm())
         sq += n * n
-        assert abs(n - gn[i]) <= 2e-3 * gn[i] + 1e-7, f"{k}: grad norm {n} vs {gn[i]}"
+        # scalar parameters' gradients are cancelling sums over whole feature maps: their fp32
+        # round-off in the reference scales with the total gradient norm, not with their own value
+        assert abs(n - gn[i]) <= 2e-3 * gn[i] + 2e-4 * gtot, f"{k}: grad norm {n} vs {gn[i]}"
     total = sq ** 0.5
     assert abs(total - float(z["grad_total_norm"])) <= 1e-3 * float(z["grad_total_norm"])
-    assert int((gn < 0).sum()) - sum(1 for k in names if not m[k]["trainable"]) == 307 - 0 or True
+    assert int((gn < 0).sum()) - sum(1 for k in names if not m[k]["trainable"]) == 307
 
 
 def test_skip_dead_is_identical():
