@@ -1,0 +1,422 @@
+"""Raw kernel wrappers (`k_*`, no autograd) and torch.autograd.Function wrappers over
+libadnm_hip.so.  Everything here launches on torch's current stream and allocates through
+torch's caching allocator only, so a whole training step is hipGraph-capturable.
+
+Layout convention: token tensors are (B, L, C) / (M, C) channels-last; a "row view" is a 2-D
+tensor with stride (ld, 1) — kernels take the row stride, so column slices of wide buffers are
+passed without copies."""
+import torch
+
+from . import lib
+
+_DT = {torch.float32: lib.F32, torch.bfloat16: lib.BF16}
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"adnm_hip: unsupported activation dtype {t.dtype}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rows(t):
+    """(M, C) row view -> (data_ptr, ld). Leading dims must collapse to one row stride."""
+    assert t.stride(-1) == 1 or t.shape[-1] == 1, "last dim must be contiguous"
+    if t.dim() == 2:
+        return t.data_ptr(), t.stride(0)
+    ld = t.stride(-2)
+    for i in range(t.dim() - 2):  # (B, L, C) with stride(0) == L * ld
+        assert t.stride(i) == t.stride(i + 1) * t.shape[i + 1], "leading dims are not row-collapsible"
+    return t.data_ptr(), ld
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f32(t):
+    assert t is None or (t.dtype == torch.float32 and t.is_contiguous()), "parameters must be contiguous fp32"
+    return t
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("adnm_hip kernels run on the GPU only (there is no CPU fallback); got a CPU tensor")
+
+
+# ======================================================================================= raw kernels
+def k_rownorm_fwd(x2, w, b, scale, shift, eps, mean, out=None):
+    _need_gpu(x2)
+    M, d = x2.shape
+    y = out if out is not None else torch.empty((M, d), dtype=x2.dtype, device=x2.device)
+    mu = torch.empty(M if mean else 1, dtype=torch.float32, device=x2.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x2.device)
+    px, ldx = _rows(x2)
+    py, ldy = _rows(y)
+    lib.call("adnm_rownorm_fwd", px, ldx, _p(_f32(w)), _p(_f32(b)), _p(scale), _p(shift), py, ldy, mu.data_ptr(),
+             rstd.data_ptr(), M, d, float(eps), int(mean), _dt(x2), _stream())
+    return y, mu, rstd
+
+
+def k_rownorm_bwd(dy2, x2, w, b, scale, mu, rstd, mean, want_b, want_affine, dx_out=None):
+    M, d = x2.shape
+    dev = x2.device
+    dx = dx_out if dx_out is not None else torch.empty((M, d), dtype=x2.dtype, device=dev)
+    dw = torch.empty(d, dtype=torch.float32, device=dev)
+    db = torch.empty(d, dtype=torch.float32, device=dev) if want_b else None
+    dsc = torch.empty((), dtype=torch.float32, device=dev) if want_affine else None
+    dsh = torch.empty((), dtype=torch.float32, device=dev) if want_affine else None
+    nb = lib.query("adnm_rownorm_bwd_ws_bytes", M, d)
+    ws = _ws(nb, dev)
+    pdy, lddy = _rows(dy2)
+    px, ldx = _rows(x2)
+    pdx, lddx = _rows(dx)
+    lib.call("adnm_rownorm_bwd", pdy, lddy, px, ldx, _p(w), _p(b), _p(scale), mu.data_ptr(), rstd.data_ptr(), pdx, lddx,
+             dw.data_ptr(), _p(db), _p(dsc), _p(dsh), ws.data_ptr(), nb, M, d, int(mean), _dt(x2), _stream())
+    return dx, dw, db, dsc, dsh
+
+
+def k_ssd_fwd(x, Bm, Cm, dt_raw, dt_bias, A_log, D, B, L, H, P, N, G, y=None):
+    """x (M,H*P) row view, Bm/Cm (M,G*N) row views, dt_raw (M,H) row view; M = B*L."""
+    _need_gpu(x)
+    dev = x.device
+    M = B * L
+    if y is None:
+        y = torch.empty((M, H * P), dtype=x.dtype, device=dev)
+    kv = torch.empty((B, H, N, P), dtype=torch.float32, device=dev)
+    nb = lib.query("adnm_ssd_ws_bytes", B, L, H, P, N, G)
+    ws = _ws(nb, dev)
+    px, ldx = _rows(x)
+    pb, ldb = _rows(Bm)
+    pc, ldc = _rows(Cm)
+    pt, ldt = _rows(dt_raw)
+    py, ldy = _rows(y)
+    lib.call("adnm_ssd_reduce_fwd", px, ldx, pb, ldb, pc, ldc, pt, ldt, 1, _p(_f32(dt_bias)), _p(_f32(A_log)), _p(_f32(D)), 1, py,
+             ldy, kv.data_ptr(), ws.data_ptr(), nb, B, L, H, P, N, G, _dt(x), _stream())
+    return y, kv
+
+
+def k_ssd_bwd(dy, x, Bm, Cm, dt_raw, dt_bias, A_log, D, kv, dx, dBm, dCm, ddt, B, L, H, P, N, G):
+    dev = x.device
+    dbias = torch.empty(H, dtype=torch.float32, device=dev)
+    dA = torch.empty(H, dtype=torch.float32, device=dev)
+    dD = torch.empty(H, dtype=torch.float32, device=dev)
+    nb = lib.query("adnm_ssd_ws_bytes", B, L, H, P, N, G)
+    ws = _ws(nb, dev)
+    a = []
+    for t in (dy, x, Bm, Cm, dt_raw):
+        a += list(_rows(t))
+    g = []
+    for t in (dx, dBm, dCm, ddt):
+        g += list(_rows(t))
+    lib.call("adnm_ssd_reduce_bwd", a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], 1, _p(dt_bias), _p(A_log), _p(D), 1,
+             kv.data_ptr(), g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], dbias.data_ptr(), dA.data_ptr(), dD.data_ptr(),
+             ws.data_ptr(), nb, B, L, H, P, N, G, _dt(x), _stream())
+    return dbias, dA, dD
+
+
+def k_dwconv_fwd(x, wt, bias, B, H, W, C, K, act, y=None, addend=None):
+    """x (M,C) row view (M=B*H*W); wt tap-major (K*K, C) fp32."""
+    _need_gpu(x)
+    if y is None:
+        y = torch.empty((B * H * W, C), dtype=x.dtype, device=x.device)
+    px, ldx = _rows(x)
+    py, ldy = _rows(y)
+    pa, lda = _rows(addend) if addend is not None else (None, 0)
+    lib.call("adnm_dwconv_fwd", px, ldx, _p(_f32(wt)), _p(_f32(bias)), pa, lda, py, ldy, B, H, W, C, K, K, act, _dt(x), _stream())
+    return y
+
+
+def k_dwconv_bwd(dy, x, wt, bias, B, H, W, C, K, act, dx=None, want_bias=False):
+    dev = x.device
+    if dx is None:
+        dx = torch.empty((B * H * W, C), dtype=x.dtype, device=dev)
+    dwt = torch.empty((K * K, C), dtype=torch.float32, device=dev)
+    db = torch.empty(C, dtype=torch.float32, device=dev) if want_bias else None
+    dpre = torch.empty((B * H * W, C), dtype=x.dtype, device=dev) if act != lib.ACT_NONE else None
+    nb = lib.query("adnm_dwconv_bwd_ws_bytes", B, H, W, C, K, K)
+    ws = _ws(nb, dev)
+    pdy, lddy = _rows(dy)
+    px, ldx = _rows(x)
+    pdx, lddx = _rows(dx)
+    lib.call("adnm_dwconv_bwd", pdy, lddy, px, ldx, _p(wt), _p(bias), _p(dpre), pdx, lddx, dwt.data_ptr(), _p(db), ws.data_ptr(),
+             nb, B, H, W, C, K, K, act, _dt(x), _stream())
+    return dx, dwt, db
+
+
+def k_haar_dwt(x, B, H, W, C, cx=1):
+    """x: (B*H*W, C*cx) row view holding channel c at column c*cx -> (B*h2*w2, 4C)."""
+    _need_gpu(x)
+    h2, w2 = (H + 1) // 2, (W + 1) // 2
+    y = torch.empty((B * h2 * w2, 4 * C), dtype=x.dtype, device=x.device)
+    px, ldx = _rows(x)
+    lib.call("adnm_haar_dwt", px, ldx, cx, y.data_ptr(), B, H, W, C, _dt(x), _stream())
+    return y
+
+
+def k_haar_idwt(s, ll_add, B, H, W, C):
+    """s: (B*h2*w2, 4C) contiguous (+ ll_add (B*h2*w2, C)) -> (B*H*W, C)."""
+    _need_gpu(s)
+    assert s.is_contiguous() and (ll_add is None or ll_add.is_contiguous())
+    y = torch.empty((B * H * W, C), dtype=s.dtype, device=s.device)
+    lib.call("adnm_haar_idwt", s.data_ptr(), _p(ll_add), y.data_ptr(), B, H, W, C, _dt(s), _stream())
+    return y
+
+
+def k_instnorm_fwd(x, scale, shift, B, HW, C, eps, act):
+    _need_gpu(x)
+    assert x.is_contiguous()
+    dev = x.device
+    y = torch.empty_like(x)
+    mu = torch.empty((B, C), dtype=torch.float32, device=dev)
+    rstd = torch.empty((B, C), dtype=torch.float32, device=dev)
+    nb = lib.query("adnm_instnorm_ws_bytes", B, HW, C)
+    ws = _ws(nb, dev)
+    lib.call("adnm_instnorm_fwd", x.data_ptr(), _p(scale), _p(shift), y.data_ptr(), mu.data_ptr(), rstd.data_ptr(), ws.data_ptr(), nb,
+             B, HW, C, float(eps), act, _dt(x), _stream())
+    return y, mu, rstd
+
+
+def k_instnorm_bwd(dy, x, scale, shift, mu, rstd, B, HW, C, act, want_affine=True):
+    dev = x.device
+    assert dy.is_contiguous() and x.is_contiguous()
+    dx = torch.empty_like(x)
+    dsc = torch.empty((), dtype=torch.float32, device=dev) if want_affine else None
+    dsh = torch.empty((), dtype=torch.float32, device=dev) if want_affine else None
+    nb = lib.query("adnm_instnorm_ws_bytes", B, HW, C)
+    ws = _ws(nb, dev)
+    lib.call("adnm_instnorm_bwd", dy.data_ptr(), x.data_ptr(), _p(scale), _p(shift), mu.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+             _p(dsc), _p(dsh), ws.data_ptr(), nb, B, HW, C, act, _dt(x), _stream())
+    return dx, dsc, dsh
+
+
+def k_gate_fwd(h, F):
+    _need_gpu(h)
+    M = h.shape[0]
+    y = torch.empty((M, F), dtype=h.dtype, device=h.device)
+    ph, ldh = _rows(h)
+    lib.call("adnm_gate_fwd", ph, ldh, y.data_ptr(), F, M, F, _dt(h), _stream())
+    return y
+
+
+def k_gate_bwd(dy, h, F):
+    M = h.shape[0]
+    dh = torch.empty((M, 2 * F), dtype=h.dtype, device=h.device)
+    pdy, lddy = _rows(dy)
+    ph, ldh = _rows(h)
+    lib.call("adnm_gate_bwd", pdy, lddy, ph, ldh, dh.data_ptr(), 2 * F, M, F, _dt(h), _stream())
+    return dh
+
+
+def tap_major(w):
+    """nn.Conv2d depthwise weight (C,1,KH,KW) -> tap-major (KH*KW, C) fp32 (differentiable)."""
+    c = w.shape[0]
+    return w.reshape(c, -1).t().contiguous().float()
+
+
+# ======================================================================================= autograd
+class RowNormFn(torch.autograd.Function):
+    """y = scale * ((x-mu)*rstd*w + b) + shift over the last dim (RMSNorm when mean=False)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, scale, shift, eps, mean):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        y, mu, rstd = k_rownorm_fwd(x2, w, b, scale, shift, eps, mean)
+        ctx.save_for_backward(x2, w, b, scale, mu, rstd)
+        ctx.mean, ctx.shp, ctx.has_shift = mean, shp, shift is not None
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, b, scale, mu, rstd = ctx.saved_tensors
+        dy2 = dy.reshape(-1, ctx.shp[-1])
+        if dy2.stride(-1) != 1:
+            dy2 = dy2.contiguous()
+        dx, dw, db, dsc, dsh = k_rownorm_bwd(dy2, x2, w, b, scale, mu, rstd, ctx.mean, b is not None,
+                                            scale is not None or ctx.has_shift)
+        return (dx.view(ctx.shp), dw, db, dsc if scale is not None else None, dsh if ctx.has_shift else None, None, None)
+
+
+def rownorm(x, w, b=None, scale=None, shift=None, eps=1e-5, mean=True):
+    return RowNormFn.apply(x, w, b, scale, shift, eps, mean)
+
+
+class SSDReduceFn(torch.autograd.Function):
+    """Stand-alone K1 (used by tests and by callers that hold x/B/C/dt as separate tensors)."""
+
+    @staticmethod
+    def forward(ctx, x, Bm, Cm, dt_raw, dt_bias, A_log, D, G):
+        B, L, H, P = x.shape
+        N = Bm.shape[-1] // G
+        M = B * L
+        xs, bs, cs, ts = x.reshape(M, H * P), Bm.reshape(M, -1), Cm.reshape(M, -1), dt_raw.reshape(M, H)
+        xs, bs, cs, ts = [t if t.stride(-1) == 1 else t.contiguous() for t in (xs, bs, cs, ts)]
+        y, kv = k_ssd_fwd(xs, bs, cs, ts, dt_bias, A_log, D, B, L, H, P, N, G)
+        ctx.save_for_backward(xs, bs, cs, ts, dt_bias, A_log, D, kv)
+        ctx.dims = (B, L, H, P, N, G)
+        return y.view(B, L, H, P)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, bs, cs, ts, dt_bias, A_log, D, kv = ctx.saved_tensors
+        B, L, H, P, N, G = ctx.dims
+        M = B * L
+        dy2 = dy.reshape(M, H * P)
+        dy2 = dy2 if dy2.stride(-1) == 1 else dy2.contiguous()
+        dx, dB, dC, ddt = (torch.empty_like(t, memory_format=torch.contiguous_format) for t in (xs, bs, cs, ts))
+        dbias, dA, dD = k_ssd_bwd(dy2, xs, bs, cs, ts, dt_bias, A_log, D, kv, dx, dB, dC, ddt, B, L, H, P, N, G)
+        return dx.view(B, L, H, P), dB.view(B, L, -1), dC.view(B, L, -1), ddt.view(B, L, H), dbias, dA, dD, None
+
+
+def ssd_reduce(x, Bm, Cm, dt_raw, dt_bias, A_log, D, groups=1):
+    return SSDReduceFn.apply(x, Bm, Cm, dt_raw, dt_bias, A_log, D, groups)
+
+
+class DWConvFn(torch.autograd.Function):
+    """Depthwise KxK 'same' conv (+bias, +activation) on (B, H*W, C) tokens; w is nn.Conv2d's (C,1,K,K)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, H, W, act):
+        B, L, C = x.shape
+        K = w.shape[-1]
+        x2 = x.reshape(B * L, C)
+        x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
+        wt = tap_major(w)
+        y = k_dwconv_fwd(x2, wt, bias, B, H, W, C, K, act)
+        ctx.save_for_backward(x2, wt, bias)
+        ctx.dims = (B, H, W, C, K, act, w.shape)
+        return y.view(B, L, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wt, bias = ctx.saved_tensors
+        B, H, W, C, K, act, wshape = ctx.dims
+        dy2 = dy.reshape(B * H * W, C)
+        dy2 = dy2 if dy2.stride(-1) == 1 else dy2.contiguous()
+        dx, dwt, db = k_dwconv_bwd(dy2, x2, wt, bias, B, H, W, C, K, act, want_bias=bias is not None)
+        return dx.view(B, H * W, C), dwt.t().reshape(wshape), db, None, None, None
+
+
+def dwconv(x, w, bias, H, W, act=lib.ACT_NONE):
+    return DWConvFn.apply(x, w, bias, H, W, act)
+
+
+class InstNormFn(torch.autograd.Function):
+    """act(scale * InstanceNorm2d(x) + shift) on (B, H*W, C) tokens."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, eps, act):
+        B, L, C = x.shape
+        x = x.contiguous()
+        y, mu, rstd = k_instnorm_fwd(x, scale, shift, B, L, C, eps, act)
+        ctx.save_for_backward(x, scale, shift, mu, rstd)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, shift, mu, rstd = ctx.saved_tensors
+        B, L, C = x.shape
+        dx, dsc, dsh = k_instnorm_bwd(dy.contiguous(), x, scale, shift, mu, rstd, B, L, C, ctx.act)
+        return dx, dsc if scale is not None else None, dsh if shift is not None else None, None, None
+
+
+def instnorm(x, scale=None, shift=None, eps=1e-5, act=lib.ACT_NONE):
+    return InstNormFn.apply(x, scale, shift, eps, act)
+
+
+class GateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h):
+        F = h.shape[-1] // 2
+        h2 = h.reshape(-1, 2 * F)
+        h2 = h2 if h2.stride(-1) == 1 else h2.contiguous()
+        ctx.save_for_backward(h2)
+        ctx.shp = h.shape
+        return k_gate_fwd(h2, F).view(*h.shape[:-1], F)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h2,) = ctx.saved_tensors
+        F = h2.shape[-1] // 2
+        dy2 = dy.reshape(-1, F)
+        dy2 = dy2 if dy2.stride(-1) == 1 else dy2.contiguous()
+        return k_gate_bwd(dy2, h2, F).view(ctx.shp)
+
+
+def gate(h):
+    return GateFn.apply(h)
+
+
+class WTConvFn(torch.autograd.Function):
+    """WTConv2d.forward (WTConv2d.py:100-153) on (B, H*W, C) tokens: Haar pyramid, depthwise KxK on every
+    level's 4C sub-bands (per-channel wavelet_scale folded into the taps by the caller), inverse pyramid,
+    plus the base depthwise conv (base_scale folded) — all by HIP kernels, manual backward.
+    Arguments: x, base taps (K*K,C), base bias (C)|None, *level taps (K*K,4C)."""
+
+    @staticmethod
+    def forward(ctx, x, H, W, K, base_wt, base_bias, *level_wt):
+        B, L, C = x.shape
+        x2 = x.reshape(B * L, C)
+        x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
+        levels = len(level_wt)
+        shapes, subs, tags = [], [], []
+        cur, cx, h, w = x2, 1, H, W
+        for i in range(levels):
+            shapes.append((h, w))
+            sub = k_haar_dwt(cur, B, h, w, C, cx)  # (B*h2*w2, 4C); its LL band (column c*4) feeds the next level
+            h, w = (h + 1) // 2, (w + 1) // 2
+            subs.append(sub)
+            tags.append(k_dwconv_fwd(sub, level_wt[i], None, B, h, w, 4 * C, K, lib.ACT_NONE))
+            cur, cx = sub, 4
+        nxt = None
+        for i in range(levels - 1, -1, -1):
+            hh, ww = shapes[i]
+            nxt = k_haar_idwt(tags[i], nxt, B, hh, ww, C)
+        y = k_dwconv_fwd(x2, base_wt, base_bias, B, H, W, C, K, lib.ACT_NONE, addend=nxt)
+        ctx.save_for_backward(x2, base_wt, base_bias, *level_wt, *subs)
+        ctx.dims = (B, H, W, C, K, levels, shapes)
+        return y.view(B, L, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C, K, levels, shapes = ctx.dims
+        saved = ctx.saved_tensors
+        x2, base_wt, base_bias = saved[0], saved[1], saved[2]
+        level_wt, subs = saved[3:3 + levels], saved[3 + levels:]
+        dy2 = dy.reshape(B * H * W, C)
+        dy2 = dy2 if dy2.stride(-1) == 1 else dy2.contiguous()
+        dxb, dbase, dbb = k_dwconv_bwd(dy2, x2, base_wt, base_bias, B, H, W, C, K, lib.ACT_NONE, want_bias=base_bias is not None)
+        # the reconstruction's backward walks down: d(merged_i) = DWT(d r_{i-1}); its LL band is d r_i
+        dtags = []
+        cur, cx = dy2, 1
+        for i in range(levels):
+            hh, ww = shapes[i]
+            dm = k_haar_dwt(cur, B, hh, ww, C, cx)
+            dtags.append(dm)
+            cur, cx = dm, 4
+        # the analysis side's backward walks up: d(ll_{i-1}) = IDWT(d sub_i + [d ll_i on the LL band])
+        dll = None
+        dlw = [None] * levels
+        for i in range(levels - 1, -1, -1):
+            hh, ww = shapes[i]
+            h2, w2 = (hh + 1) // 2, (ww + 1) // 2
+            dsub, dlw[i], _ = k_dwconv_bwd(dtags[i], subs[i], level_wt[i], None, B, h2, w2, 4 * C, K, lib.ACT_NONE)
+            dll = k_haar_idwt(dsub, dll, B, hh, ww, C)
+        dx = dxb + dll
+        return (dx.view(B, H * W, C), None, None, None, dbase, dbb, *dlw)
+
+
+def wtconv(x, H, W, K, base_wt, base_bias, level_wts):
+    return WTConvFn.apply(x, H, W, K, base_wt, base_bias, *level_wts)

@@ -1,0 +1,112 @@
+// Shared device/host helpers for libadnm_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/adnm_hip.h"
+
+#define ADNM_WAVE 64
+
+void adnm_set_error(const char* fmt, ...);
+
+#define ADNM_REQUIRE(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      adnm_set_error(__VA_ARGS__);         \
+      return ADNM_EINVAL;                  \
+    }                                      \
+  } while (0)
+
+#define ADNM_CHECK_LAUNCH(name)                                              \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      adnm_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return ADNM_ELAUNCH;                                                   \
+    }                                                                        \
+  } while (0)
+
+static inline int64_t adnm_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t adnm_align(int64_t a, int64_t b) { return adnm_cdiv(a, b) * b; }
+
+// ---- storage types -------------------------------------------------------------------------
+struct bf16x4 {
+  uint16_t v[4];
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  __hip_bfloat16 b = __float2bfloat16(f);  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return *reinterpret_cast<uint16_t*>(&b);
+}
+
+template <typename T>
+struct Io;
+template <>
+struct Io<float> {
+  static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <>
+struct Io<uint16_t> {  // bf16 storage
+  static __device__ __forceinline__ float4 ld4(const uint16_t* p) {
+    uint2 r = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                       __uint_as_float(r.y & 0xffff0000u));
+  }
+  static __device__ __forceinline__ void st4(uint16_t* p, float4 v) {
+    uint2 r;
+    r.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    r.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = r;
+  }
+  static __device__ __forceinline__ float ld(const uint16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// ---- math ----------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float silu_gradf_(float x) {
+  float s = sigmoidf_(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float geluf_(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_gradf_(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : log1pf(__expf(x)); }  // torch threshold 20
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float x) {
+  if (ACT == ADNM_ACT_SILU) return siluf_(x);
+  if (ACT == ADNM_ACT_GELU) return geluf_(x);
+  return x;
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad(float x) {
+  if (ACT == ADNM_ACT_SILU) return silu_gradf_(x);
+  if (ACT == ADNM_ACT_GELU) return gelu_gradf_(x);
+  return 1.0f;
+}
+
+// ---- reductions ----------------------------------------------------------------------------
+// sum across the lanes whose index differs only in bits [lo_bit, 6): i.e. lanes l, l^lo, l^2lo, ...
+__device__ __forceinline__ float wave_sum_from(float v, int lo) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1)
+    if (o >= lo) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_from(v, 1); }
+// sum across groups of `width` adjacent lanes (width power of two <= 64)
+__device__ __forceinline__ float group_sum(float v, int width) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1)
+    if (o < width) v += __shfl_xor(v, o, 64);
+  return v;
+}

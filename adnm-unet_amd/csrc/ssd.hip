@@ -1,0 +1,515 @@
+// K1 — the SSD "linear-attention duality" reduction that every Mamba2 mixer of ADNM-UNet executes
+// (non_casual_linear_attn: ADNssd.py:252-299 single-group branch :278-284, Vssd.py:161-208 grouped :194-206),
+// with softplus(dt + dt_bias) (ADNssd.py:318) fused in:
+//
+//   w[b,l,h]    = softplus(dt_raw + dt_bias[h]) * exp(A_log[h])
+//   KV[b,h,n,p] = sum_l Bm[b,l,g,n] * x[b,l,h,p] * w[b,l,h]               (pass 1: global reduction over L)
+//   y[b,l,h,p]  = sum_n Cm[b,l,g,n] * KV[b,h,n,p] + D[h] * x[b,l,h,p]      (pass 2: streaming)      g = h % G
+//
+// There is no recurrence on this branch, so there is nothing to scan: it is a two-pass, HBM-bound reduction
+// (~2.3 FMA per byte).  Mapping: one lane per (token, head); the HB = min(64, pow2(H)) lanes of a token are
+// adjacent, so a token row is read as one contiguous 16*HB-byte segment and the shared Bm/Cm row is a
+// same-address broadcast.  Each lane keeps the N x P state of ITS head in registers (64 VGPRs at N=16, P=4)
+// for all the tokens it visits; no LDS in the inner loops.  Cross-lane sums (over the tokens of a wave in
+// pass 1, over the heads of a token for dBm/dCm in backward) are xor-shuffles; cross-block sums go through
+// fp32 partials in the caller's workspace and a small deterministic second kernel — never atomics, so the
+// result is bitwise reproducible run to run.
+#include "adnm_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+
+__host__ __device__ inline int heads_per_block(int64_t H) {
+  int l = 1;
+  while (l < 64 && l < H) l <<= 1;
+  return l;
+}
+
+struct Geo {
+  int hb;         // lanes (heads) per token inside a block
+  int slots;      // tokens in flight per block step
+  int nhb;        // head blocks (grid.y)
+  int tok1;       // tokens per block, reduction passes
+  int nchunk;     // blocks along L, reduction passes
+  int tok2;       // tokens per block, streaming passes
+  int nblk2;      // blocks along L, streaming passes
+};
+
+inline Geo make_geo(int64_t L, int64_t H) {
+  Geo g;
+  g.hb = heads_per_block(H);
+  g.slots = kBlock / g.hb;
+  g.nhb = (int)adnm_cdiv(H, g.hb);
+  g.tok1 = g.slots * 16;
+  g.nchunk = (int)adnm_cdiv(L, g.tok1);
+  g.tok2 = g.slots * 8;
+  g.nblk2 = (int)adnm_cdiv(L, g.tok2);
+  return g;
+}
+
+template <typename T, int P>
+__device__ __forceinline__ void load_vec(const T* p, float (&v)[P]) {
+#pragma unroll
+  for (int i = 0; i < P; i += 4) {
+    float4 t = Io<T>::ld4(p + i);
+    v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+  }
+}
+template <typename T, int P>
+__device__ __forceinline__ void store_vec(T* p, const float (&v)[P]) {
+#pragma unroll
+  for (int i = 0; i < P; i += 4) Io<T>::st4(p + i, make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Reduction pass: part[b, chunk, h, n, p] = sum_{l in chunk} K[b,l,g,n] * V[b,l,h,p] * (WEIGHTED ? w : 1)
+// used for KV (K=Bm, V=x, weighted) and for dKV in backward (K=Cm, V=dy, unweighted).
+template <typename T, int P, int N, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock) void ssd_outer_reduce_kernel(
+    const T* __restrict__ V, int64_t ldv, const T* __restrict__ K, int64_t ldk, const T* __restrict__ dt_raw,
+    int64_t lddt, int64_t dt_hs, const float* __restrict__ dt_bias, const float* __restrict__ A_log, int64_t p_hs,
+    float* __restrict__ part, int64_t L, int H, int G, int hb, int tok_per_block, int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [hb][N*P]
+  const int hl = threadIdx.x & (hb - 1);
+  const int slot = threadIdx.x / hb;
+  const int slots = kBlock / hb;
+  const int h = blockIdx.y * hb + hl;
+  const bool hv = h < H;
+  const int b = blockIdx.z;
+  const int64_t l0 = (int64_t)blockIdx.x * tok_per_block;
+  const int64_t l1 = (l0 + tok_per_block < L) ? l0 + tok_per_block : L;
+  float acc[N][P];
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[n][p] = 0.f;
+  float a = 0.f, bias = 0.f;
+  if (WEIGHTED && hv) {
+    a = __expf(A_log[h * p_hs]);
+    bias = dt_bias[h * p_hs];
+  }
+  const int g = hv ? (h % G) : 0;
+  if (hv) {
+    for (int64_t l = l0 + slot; l < l1; l += slots) {
+      const int64_t row = (int64_t)b * L + l;
+      float v[P], k[N];
+      load_vec<T, P>(V + row * ldv + (int64_t)h * P, v);
+      load_vec<T, N>(K + row * ldk + g * N, k);
+      if (WEIGHTED) {
+        const float w = softplusf_(Io<T>::ld(dt_raw + row * lddt + h * dt_hs) + bias) * a;
+#pragma unroll
+        for (int p = 0; p < P; ++p) v[p] *= w;
+      }
+#pragma unroll
+      for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[n][p] = fmaf(k[n], v[p], acc[n][p]);
+    }
+  }
+  // fold the token slots that share a wave, then the waves of the block through LDS
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[n][p] = wave_sum_from(acc[n][p], hb);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int wv = 1; wv < kWaves; ++wv) {
+    if (wave == wv && lane < hb) {
+#pragma unroll
+      for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int p = 0; p < P; p += 4)
+          *reinterpret_cast<float4*>(smem + ((n * P + p) / 4 * hb + lane) * 4) =
+              make_float4(acc[n][p], acc[n][p + 1], acc[n][p + 2], acc[n][p + 3]);
+    }
+    __syncthreads();
+    if (wave == 0 && lane < hb) {
+#pragma unroll
+      for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int p = 0; p < P; p += 4) {
+          float4 t = *reinterpret_cast<const float4*>(smem + ((n * P + p) / 4 * hb + lane) * 4);
+          acc[n][p] += t.x; acc[n][p + 1] += t.y; acc[n][p + 2] += t.z; acc[n][p + 3] += t.w;
+        }
+    }
+    __syncthreads();
+  }
+  if (wave == 0 && lane < hb && hv) {
+    float* dst = part + (((int64_t)b * nchunk + blockIdx.x) * H + h) * (N * P);
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int p = 0; p < P; p += 4)
+        *reinterpret_cast<float4*>(dst + n * P + p) = make_float4(acc[n][p], acc[n][p + 1], acc[n][p + 2], acc[n][p + 3]);
+  }
+}
+
+// out[b, e] = sum_k part[b, k, e],  e in [0, E)
+__global__ __launch_bounds__(256) void ssd_fold_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                       int nk, int64_t E) {
+  __shared__ float sm[4][64];
+  const int b = blockIdx.y;
+  const int e_local = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + e_local;
+  float t = 0.f;
+  if (e < E)
+    for (int k = ks; k < nk; k += 4) t += part[((int64_t)b * nk + k) * E + e];
+  sm[ks][e_local] = t;
+  __syncthreads();
+  if (ks == 0 && e < E) out[(int64_t)b * E + e] = (sm[0][e_local] + sm[1][e_local]) + (sm[2][e_local] + sm[3][e_local]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streaming pass: y = Cm . KV + D x
+template <typename T, int P, int N>
+__global__ __launch_bounds__(kBlock) void ssd_apply_kernel(const T* __restrict__ x, int64_t ldx,
+                                                           const T* __restrict__ Cm, int64_t ldc,
+                                                           const float* __restrict__ D, int64_t p_hs,
+                                                           const float* __restrict__ kv, T* __restrict__ y,
+                                                           int64_t ldy, int64_t L, int H, int G, int hb,
+                                                           int tok_per_block) {
+  const int hl = threadIdx.x & (hb - 1);
+  const int slot = threadIdx.x / hb;
+  const int slots = kBlock / hb;
+  const int h = blockIdx.y * hb + hl;
+  if (h >= H) return;
+  const int b = blockIdx.z;
+  const int64_t l0 = (int64_t)blockIdx.x * tok_per_block;
+  const int64_t l1 = (l0 + tok_per_block < L) ? l0 + tok_per_block : L;
+  float s[N][P];
+  const float* src = kv + ((int64_t)b * H + h) * (N * P);
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int p = 0; p < P; p += 4) {
+      float4 t = *reinterpret_cast<const float4*>(src + n * P + p);
+      s[n][p] = t.x; s[n][p + 1] = t.y; s[n][p + 2] = t.z; s[n][p + 3] = t.w;
+    }
+  const float Dh = D[h * p_hs];
+  const int g = h % G;
+  for (int64_t l = l0 + slot; l < l1; l += slots) {
+    const int64_t row = (int64_t)b * L + l;
+    float v[P], c[N], o[P];
+    load_vec<T, P>(x + row * ldx + (int64_t)h * P, v);
+    load_vec<T, N>(Cm + row * ldc + g * N, c);
+#pragma unroll
+    for (int p = 0; p < P; ++p) o[p] = Dh * v[p];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int p = 0; p < P; ++p) o[p] = fmaf(c[n], s[n][p], o[p]);
+    store_vec<T, P>(y + row * ldy + (int64_t)h * P, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward streaming pass.  Per (token, head):
+//   t[p]   = sum_n Bm[n] dKV[n][p]          dx[p] = D dy[p] + w t[p]
+//   dw     = sum_p t[p] x[p]                ddt_raw = dw * a * sigmoid(dt_raw + bias)
+//   dCm[n] = sum_{h in g} sum_p dy[p] KV[n][p]        dBm[n] = sum_{h in g} w sum_p dKV[n][p] x[p]
+//   dD += sum_p dy x ;  ddt_bias += ddt_raw ;  dA_log += dw * w
+// hpart: per (b, l-block, wave) partial of [dD | ddt_bias | dA_log] per head; bcpart: per head-block partial of
+// [dBm | dCm] rows when H spans several head blocks (otherwise written straight to dBm/dCm).
+template <typename T, int P, int N>
+__global__ __launch_bounds__(kBlock) void ssd_bwd_kernel(
+    const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x, int64_t ldx, const T* __restrict__ Bm, int64_t ldb,
+    const T* __restrict__ Cm, int64_t ldc, const T* __restrict__ dt_raw, int64_t lddt, int64_t dt_hs,
+    const float* __restrict__ dt_bias, const float* __restrict__ A_log, const float* __restrict__ D, int64_t p_hs,
+    const float* __restrict__ kv, const float* __restrict__ dkv, T* __restrict__ dx, int64_t lddx, T* __restrict__ dBm,
+    int64_t lddb, T* __restrict__ dCm, int64_t lddc, T* __restrict__ ddt_raw, int64_t ldddt,
+    float* __restrict__ hpart, float* __restrict__ bcpart, int64_t L, int H, int G, int hb, int tok_per_block,
+    int nblk, int nhb) {
+  const int hl = threadIdx.x & (hb - 1);
+  const int slot = threadIdx.x / hb;
+  const int slots = kBlock / hb;
+  const int h = blockIdx.y * hb + hl;
+  const bool hv = h < H;
+  const int hh = hv ? h : 0;
+  const int b = blockIdx.z;
+  const int64_t l0 = (int64_t)blockIdx.x * tok_per_block;
+  const int64_t l1 = (l0 + tok_per_block < L) ? l0 + tok_per_block : L;
+  float s[N][P], ds[N][P];
+  {
+    const float* s0 = kv + ((int64_t)b * H + hh) * (N * P);
+    const float* s1 = dkv + ((int64_t)b * H + hh) * (N * P);
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int p = 0; p < P; p += 4) {
+        float4 t = *reinterpret_cast<const float4*>(s0 + n * P + p);
+        float4 u = *reinterpret_cast<const float4*>(s1 + n * P + p);
+        if (!hv) t = u = make_float4(0.f, 0.f, 0.f, 0.f);
+        s[n][p] = t.x; s[n][p + 1] = t.y; s[n][p + 2] = t.z; s[n][p + 3] = t.w;
+        ds[n][p] = u.x; ds[n][p + 1] = u.y; ds[n][p + 2] = u.z; ds[n][p + 3] = u.w;
+      }
+  }
+  const float Dh = D[hh * p_hs];
+  const float a = __expf(A_log[hh * p_hs]);
+  const float bias = dt_bias[hh * p_hs];
+  const int g = hh % G;
+  float accD = 0.f, accB = 0.f, accA = 0.f;
+  // all lanes of a token take part in the head reduction, so the loop bound is per-slot (uniform per token)
+  for (int64_t l = l0 + slot; l < l1; l += slots) {
+    const int64_t row = (int64_t)b * L + l;
+    float dBv[N], dCv[N];
+    if (hv) {
+      float v[P], gy[P], kb[N], t[P], o[P];
+      load_vec<T, P>(x + row * ldx + (int64_t)h * P, v);
+      load_vec<T, P>(dy + row * lddy + (int64_t)h * P, gy);
+      load_vec<T, N>(Bm + row * ldb + g * N, kb);
+      const float z = Io<T>::ld(dt_raw + row * lddt + h * dt_hs) + bias;
+      const float dt = softplusf_(z);
+      const float w = dt * a;
+      float dd = 0.f, dw = 0.f;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        t[p] = 0.f;
+        dd = fmaf(gy[p], v[p], dd);
+      }
+      accD += dd;
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        float cb = 0.f, cc = 0.f;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          t[p] = fmaf(kb[n], ds[n][p], t[p]);
+          cb = fmaf(ds[n][p], v[p], cb);
+          cc = fmaf(gy[p], s[n][p], cc);
+        }
+        dBv[n] = cb * w;
+        dCv[n] = cc;
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        o[p] = fmaf(w, t[p], Dh * gy[p]);
+        dw = fmaf(t[p], v[p], dw);
+      }
+      store_vec<T, P>(dx + row * lddx + (int64_t)h * P, o);
+      const float dz = dw * a * sigmoidf_(z);
+      Io<T>::st(ddt_raw + row * ldddt + h * dt_hs, dz);
+      accB += dz;
+      accA = fmaf(dw, w, accA);
+    } else {
+#pragma unroll
+      for (int n = 0; n < N; ++n) dBv[n] = dCv[n] = 0.f;
+    }
+    // sum over the heads of this token that share the K/Q group: lanes whose hl differs in bits >= log2(G)
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        if (o < hb && o >= G) {
+          dBv[n] += __shfl_xor(dBv[n], o, 64);
+          dCv[n] += __shfl_xor(dCv[n], o, 64);
+        }
+      }
+    }
+    if (hl < G) {
+      if (nhb == 1) {
+        store_vec<T, N>(dBm + row * lddb + hl * N, dBv);
+        store_vec<T, N>(dCm + row * lddc + hl * N, dCv);
+      } else {
+        float* dst = bcpart + (((int64_t)blockIdx.y * gridDim.z + b) * L + l) * (2 * G * N);
+#pragma unroll
+        for (int n = 0; n < N; n += 4) {
+          *reinterpret_cast<float4*>(dst + hl * N + n) = make_float4(dBv[n], dBv[n + 1], dBv[n + 2], dBv[n + 3]);
+          *reinterpret_cast<float4*>(dst + G * N + hl * N + n) = make_float4(dCv[n], dCv[n + 1], dCv[n + 2], dCv[n + 3]);
+        }
+      }
+    }
+  }
+  accD = wave_sum_from(accD, hb);
+  accB = wave_sum_from(accB, hb);
+  accA = wave_sum_from(accA, hb);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane < hb && hv) {
+    float* dst = hpart + ((((int64_t)b * nblk + blockIdx.x) * kWaves + wave) * 3) * H + h;
+    dst[0] = accD;
+    dst[H] = accB;
+    dst[2 * H] = accA;
+  }
+}
+
+// sums the per-head-block [dBm | dCm] partials (only when H spans several head blocks)
+template <typename T>
+__global__ void ssd_bc_fold_kernel(const float* __restrict__ bcpart, int nhb, int64_t rows, int GN, T* __restrict__ dBm,
+                                   int64_t lddb, T* __restrict__ dCm, int64_t lddc) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * 2 * GN) return;
+  const int64_t row = i / (2 * GN);
+  const int c = (int)(i % (2 * GN));
+  float t = 0.f;
+  for (int k = 0; k < nhb; ++k) t += bcpart[((int64_t)k * rows + row) * (2 * GN) + c];
+  if (c < GN) Io<T>::st(dBm + row * lddb + c, t);
+  else Io<T>::st(dCm + row * lddc + (c - GN), t);
+}
+
+// out[j*H + h] = sum_k hpart[k, j, h]  (j: dD, ddt_bias, dA_log), k over B * nblk * waves
+__global__ void ssd_head_fold_kernel(const float* __restrict__ hpart, int nk, int H, float* __restrict__ dD,
+                                     float* __restrict__ ddt_bias, float* __restrict__ dA_log) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * H) return;
+  float t = 0.f;
+  for (int k = 0; k < nk; ++k) t += hpart[(int64_t)k * 3 * H + i];
+  const int j = i / H, h = i % H;
+  (j == 0 ? dD : j == 1 ? ddt_bias : dA_log)[h] = t;
+}
+
+struct Ws {
+  float *part, *dkv, *hpart, *bcpart;
+  int64_t bytes;
+};
+
+Ws carve(void* ws, int64_t B, int64_t L, int64_t H, int64_t P, int64_t N, int64_t G) {
+  const Geo g = make_geo(L, H);
+  Ws w;
+  int64_t off = 0;
+  auto take = [&](int64_t nfloat) {
+    float* p = ws ? (float*)((char*)ws + off) : nullptr;
+    off += adnm_align(nfloat * 4, 256);
+    return p;
+  };
+  w.part = take(B * g.nchunk * H * N * P);
+  w.dkv = take(B * H * N * P);
+  w.hpart = take(B * g.nblk2 * kWaves * 3 * H);
+  w.bcpart = take(g.nhb > 1 ? (int64_t)g.nhb * B * L * 2 * G * N : 0);
+  w.bytes = off;
+  return w;
+}
+
+int check_common(const char* who, int64_t B, int64_t L, int64_t H, int64_t P, int64_t N, int64_t G, int dtype) {
+  ADNM_REQUIRE(B > 0 && L > 0 && H > 0, "%s: empty shape B=%lld L=%lld H=%lld", who, (long long)B, (long long)L, (long long)H);
+  ADNM_REQUIRE((P == 4 && (N == 8 || N == 16)) || (P == 8 && N == 8),
+               "%s: (headdim P=%lld, states-per-group N=%lld) not in {(4,8),(4,16),(8,8)}", who, (long long)P, (long long)N);
+  ADNM_REQUIRE(G == 1 || G == 2 || G == 4, "%s: groups G=%lld not in {1,2,4}", who, (long long)G);
+  ADNM_REQUIRE(B <= 65535 && adnm_cdiv(H, 64) <= 65535, "%s: grid too large", who);
+  ADNM_REQUIRE(dtype == ADNM_F32 || dtype == ADNM_BF16, "%s: bad dtype %d", who, dtype);
+  return ADNM_OK;
+}
+
+// supported (headdim, state) pairs: N*P <= 64 keeps the per-lane state in registers
+#define DISPATCH_PN(FN, ...)                                \
+  do {                                                      \
+    if (P == 4 && N == 8) FN<T, 4, 8>(__VA_ARGS__);         \
+    else if (P == 4 && N == 16) FN<T, 4, 16>(__VA_ARGS__);  \
+    else FN<T, 8, 8>(__VA_ARGS__);                          \
+  } while (0)
+
+template <typename T, int P, int N>
+void run_outer(bool weighted, const void* V, int64_t ldv, const void* K, int64_t ldk, const void* dt_raw, int64_t lddt,
+               int64_t dt_hs, const float* dt_bias, const float* A_log, int64_t p_hs, float* part, float* out, int64_t B,
+               int64_t L, int64_t H, int64_t G, hipStream_t st) {
+  const Geo g = make_geo(L, H);
+  const dim3 grid(g.nchunk, g.nhb, (unsigned)B);
+  const size_t smem = (size_t)g.hb * N * P * sizeof(float);
+  if (weighted)
+    ssd_outer_reduce_kernel<T, P, N, true><<<grid, kBlock, smem, st>>>((const T*)V, ldv, (const T*)K, ldk, (const T*)dt_raw, lddt,
+                                                                       dt_hs, dt_bias, A_log, p_hs, part, L, (int)H, (int)G,
+                                                                       g.hb, g.tok1, g.nchunk);
+  else
+    ssd_outer_reduce_kernel<T, P, N, false><<<grid, kBlock, smem, st>>>((const T*)V, ldv, (const T*)K, ldk, nullptr, 0, 0, nullptr,
+                                                                        nullptr, 0, part, L, (int)H, (int)G, g.hb, g.tok1,
+                                                                        g.nchunk);
+  const int64_t E = H * N * P;
+  ssd_fold_kernel<<<dim3((unsigned)adnm_cdiv(E, 64), (unsigned)B), 256, 0, st>>>(part, out, g.nchunk, E);
+}
+
+template <typename T, int P, int N>
+void run_apply(const void* x, int64_t ldx, const void* Cm, int64_t ldc, const float* D, int64_t p_hs, const float* kv, void* y,
+               int64_t ldy, int64_t B, int64_t L, int64_t H, int64_t G, hipStream_t st) {
+  const Geo g = make_geo(L, H);
+  ssd_apply_kernel<T, P, N><<<dim3(g.nblk2, g.nhb, (unsigned)B), kBlock, 0, st>>>((const T*)x, ldx, (const T*)Cm, ldc, D, p_hs, kv,
+                                                                                  (T*)y, ldy, L, (int)H, (int)G, g.hb, g.tok2);
+}
+
+template <typename T, int P, int N>
+void run_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* Bm, int64_t ldb, const void* Cm, int64_t ldc,
+             const void* dt_raw, int64_t lddt, int64_t dt_hs, const float* dt_bias, const float* A_log, const float* D,
+             int64_t p_hs, const float* kv, const float* dkv, void* dx, int64_t lddx, void* dBm, int64_t lddb, void* dCm,
+             int64_t lddc, void* ddt_raw, int64_t ldddt, float* hpart, float* bcpart, float* ddt_bias, float* dA_log, float* dD,
+             int64_t B, int64_t L, int64_t H, int64_t G, hipStream_t st) {
+  const Geo g = make_geo(L, H);
+  ssd_bwd_kernel<T, P, N><<<dim3(g.nblk2, g.nhb, (unsigned)B), kBlock, 0, st>>>(
+      (const T*)dy, lddy, (const T*)x, ldx, (const T*)Bm, ldb, (const T*)Cm, ldc, (const T*)dt_raw, lddt, dt_hs, dt_bias, A_log, D,
+      p_hs, kv, dkv, (T*)dx, lddx, (T*)dBm, lddb, (T*)dCm, lddc, (T*)ddt_raw, ldddt, hpart, bcpart, L, (int)H, (int)G, g.hb,
+      g.tok2, g.nblk2, g.nhb);
+  if (g.nhb > 1) {
+    const int64_t tot = B * L * 2 * G * N;
+    ssd_bc_fold_kernel<T><<<(unsigned)adnm_cdiv(tot, 256), 256, 0, st>>>(bcpart, g.nhb, B * L, (int)(G * N), (T*)dBm, lddb, (T*)dCm,
+                                                                         lddc);
+  }
+  ssd_head_fold_kernel<<<(unsigned)adnm_cdiv(3 * H, 256), 256, 0, st>>>(hpart, (int)(B * g.nblk2 * kWaves), (int)H, dD, ddt_bias,
+                                                                        dA_log);
+}
+
+}  // namespace
+
+extern "C" int64_t adnm_ssd_ws_bytes(int64_t B, int64_t L, int64_t H, int64_t P, int64_t N, int64_t G) {
+  if (B <= 0 || L <= 0 || H <= 0) return 0;
+  return carve(nullptr, B, L, H, P, N, G).bytes;
+}
+
+extern "C" int adnm_ssd_reduce_fwd(const void* x, int64_t ldx, const void* Bm, int64_t ldb, const void* Cm, int64_t ldc,
+                                   const void* dt_raw, int64_t lddt, int64_t dt_hstride, const float* dt_bias,
+                                   const float* A_log, const float* D, int64_t p_hstride, void* y, int64_t ldy, float* kv,
+                                   void* ws, int64_t ws_bytes, int64_t B, int64_t L, int64_t H, int64_t P, int64_t N,
+                                   int64_t G, int dtype, adnm_stream_t stream) {
+  if (int rc = check_common("ssd_reduce_fwd", B, L, H, P, N, G, dtype)) return rc;
+  ADNM_REQUIRE(x && Bm && Cm && dt_raw && dt_bias && A_log && D && y && kv, "ssd_reduce_fwd: null pointer");
+  ADNM_REQUIRE(ldx >= H * P && ldy >= H * P && ldb >= G * N && ldc >= G * N && lddt >= (H - 1) * dt_hstride + 1,
+               "ssd_reduce_fwd: row strides smaller than the rows they address");
+  ADNM_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0, "ssd_reduce_fwd: row strides must be multiples of 4");
+  const Ws w = carve(ws, B, L, H, P, N, G);
+  if (!ws || ws_bytes < w.bytes) {
+    adnm_set_error("ssd_reduce_fwd: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)w.bytes);
+    return ADNM_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == ADNM_F32) {
+    using T = float;
+    DISPATCH_PN(run_outer, true, x, ldx, Bm, ldb, dt_raw, lddt, dt_hstride, dt_bias, A_log, p_hstride, w.part, kv, B, L, H, G, st);
+    DISPATCH_PN(run_apply, x, ldx, Cm, ldc, D, p_hstride, kv, y, ldy, B, L, H, G, st);
+  } else {
+    using T = uint16_t;
+    DISPATCH_PN(run_outer, true, x, ldx, Bm, ldb, dt_raw, lddt, dt_hstride, dt_bias, A_log, p_hstride, w.part, kv, B, L, H, G, st);
+    DISPATCH_PN(run_apply, x, ldx, Cm, ldc, D, p_hstride, kv, y, ldy, B, L, H, G, st);
+  }
+  ADNM_CHECK_LAUNCH("ssd_reduce_fwd");
+  return ADNM_OK;
+}
+
+extern "C" int adnm_ssd_reduce_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* Bm, int64_t ldb,
+                                   const void* Cm, int64_t ldc, const void* dt_raw, int64_t lddt, int64_t dt_hstride,
+                                   const float* dt_bias, const float* A_log, const float* D, int64_t p_hstride,
+                                   const float* kv, void* dx, int64_t lddx, void* dBm, int64_t lddb, void* dCm, int64_t lddc,
+                                   void* ddt_raw, int64_t ldddt, float* ddt_bias, float* dA_log, float* dD, void* ws,
+                                   int64_t ws_bytes, int64_t B, int64_t L, int64_t H, int64_t P, int64_t N, int64_t G,
+                                   int dtype, adnm_stream_t stream) {
+  if (int rc = check_common("ssd_reduce_bwd", B, L, H, P, N, G, dtype)) return rc;
+  ADNM_REQUIRE(dy && x && Bm && Cm && dt_raw && dt_bias && A_log && D && kv && dx && dBm && dCm && ddt_raw && ddt_bias && dA_log && dD,
+               "ssd_reduce_bwd: null pointer");
+  ADNM_REQUIRE(ldx >= H * P && lddy >= H * P && lddx >= H * P && ldb >= G * N && ldc >= G * N && lddb >= G * N && lddc >= G * N,
+               "ssd_reduce_bwd: row strides smaller than the rows they address");
+  ADNM_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && lddb % 4 == 0 && lddc % 4 == 0,
+               "ssd_reduce_bwd: row strides must be multiples of 4");
+  const Ws w = carve(ws, B, L, H, P, N, G);
+  if (!ws || ws_bytes < w.bytes) {
+    adnm_set_error("ssd_reduce_bwd: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)w.bytes);
+    return ADNM_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == ADNM_F32) {
+    using T = float;
+    DISPATCH_PN(run_outer, false, dy, lddy, Cm, ldc, nullptr, 0, 0, nullptr, nullptr, 0, w.part, w.dkv, B, L, H, G, st);
+    DISPATCH_PN(run_bwd, dy, lddy, x, ldx, Bm, ldb, Cm, ldc, dt_raw, lddt, dt_hstride, dt_bias, A_log, D, p_hstride, kv, w.dkv, dx,
+                lddx, dBm, lddb, dCm, lddc, ddt_raw, ldddt, w.hpart, w.bcpart, ddt_bias, dA_log, dD, B, L, H, G, st);
+  } else {
+    using T = uint16_t;
+    DISPATCH_PN(run_outer, false, dy, lddy, Cm, ldc, nullptr, 0, 0, nullptr, nullptr, 0, w.part, w.dkv, B, L, H, G, st);
+    DISPATCH_PN(run_bwd, dy, lddy, x, ldx, Bm, ldb, Cm, ldc, dt_raw, lddt, dt_hstride, dt_bias, A_log, D, p_hstride, kv, w.dkv, dx,
+                lddx, dBm, lddb, dCm, lddc, ddt_raw, ldddt, w.hpart, w.bcpart, ddt_bias, dA_log, dD, B, L, H, G, st);
+  }
+  ADNM_CHECK_LAUNCH("ssd_reduce_bwd");
+  return ADNM_OK;
+}

@@ -1,0 +1,141 @@
+/*
+ * adnm_hip.h — C-ABI of libadnm_hip.so, the MI355X (gfx950) kernels behind the ADNM-UNet
+ * training hot path.
+ *
+ * The reference (kanyu369/ADNM-UNet) has no FFI of its own: its hot ops are torch / mamba_ssm
+ * calls inside nn.Module.forward().  Each entry point below names the reference call site it
+ * replaces (file:line under the reference tree).  The Python modules in
+ * adnm-unet_amd/models/ keep the reference's nn.Module surface and call these through
+ * ctypes (adnm-unet_amd/adnm_hip/lib.py); INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (torch allocator); no entry point
+ *    allocates, frees, synchronises or touches the host copy of anything;
+ *  - kernels are enqueued on `stream` (torch.cuda.current_stream().cuda_stream) and are
+ *    hipGraph-capturable; workspace is passed in, its size comes from the *_ws_bytes helper;
+ *  - token tensors are channels-last ("BLD" = (B, H*W, C) = NHWC), the layout the reference
+ *    keeps between stages (ADNMUNet.py:119, model_untils.py:21-27);
+ *  - `dtype` selects the storage type of activations: ADNM_F32 (0) or ADNM_BF16 (1);
+ *    parameters, statistics, reductions and workspaces are always fp32;
+ *  - return value 0 = launched; negative = rejected (nothing launched), text via
+ *    adnm_last_error() (thread-local).  No global mutable state: re-entrant per thread/stream.
+ */
+#ifndef ADNM_HIP_H
+#define ADNM_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* adnm_stream_t; /* hipStream_t */
+
+enum { ADNM_F32 = 0, ADNM_BF16 = 1 };
+enum { ADNM_ACT_NONE = 0, ADNM_ACT_SILU = 1, ADNM_ACT_GELU = 2 };
+enum { ADNM_OK = 0, ADNM_EINVAL = -1, ADNM_ELAUNCH = -2, ADNM_EWORKSPACE = -3 };
+
+const char* adnm_last_error(void);
+int adnm_abi_version(void);
+
+/* ---------------------------------------------------------------- row norms (K2, K7)
+ * y = scale * ( xhat * w + b ) + shift,  xhat = (x - mu) * rstd
+ *   RMSNorm   (mamba_ssm RMSNorm bound at ADNMUNet.py:278, used ADNMUNet.py:149,155): subtract_mean=0, b=NULL
+ *   LayerNorm (ADNssd.py:456, Vssd.py:280):                                           subtract_mean=1
+ *   BiasFree_LayerNorm (model_untils.py:43-48):                                       subtract_mean=1, b=NULL
+ * scale/shift are the scalar learnable affine of Block.forward (ADNMUNet.py:149,155) as
+ * 1-element device tensors, or NULL (= 1 / 0).  x:(M,d) with row stride ldx, y row stride ldy
+ * (elements).  mu,rstd: (M) fp32 statistics saved for backward (mu unused for RMS). d % 4 == 0. */
+int adnm_rownorm_fwd(const void* x, int64_t ldx, const float* w, const float* b, const float* scale,
+                     const float* shift, void* y, int64_t ldy, float* mu, float* rstd, int64_t M, int64_t d,
+                     float eps, int subtract_mean, int dtype, adnm_stream_t stream);
+/* dx:(M,d) stride lddx; dw,db:(d); dscale,dshift:(1) — any of db/dscale/dshift may be NULL.
+ * ws: fp32 workspace of adnm_rownorm_bwd_ws_bytes(M,d) bytes. Parameter grads are OVERWRITTEN. */
+int64_t adnm_rownorm_bwd_ws_bytes(int64_t M, int64_t d);
+int adnm_rownorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* w, const float* b,
+                     const float* scale, const float* mu, const float* rstd, void* dx, int64_t lddx, float* dw,
+                     float* db, float* dscale, float* dshift, void* ws, int64_t ws_bytes, int64_t M, int64_t d,
+                     int subtract_mean, int dtype, adnm_stream_t stream);
+
+/* ---------------------------------------------------------------- SSD reduction form (K1)
+ * non_casual_linear_attn (ADNssd.py:252-299, Vssd.py:161-208):
+ *   dt = softplus(dt_raw + dt_bias)                      (ADNssd.py:318 fused here)
+ *   KV[b,h,n,p] = sum_l Bm[b,l,g(h),n] * x[b,l,h,p] * dt[b,l,h] * exp(A_log[h])
+ *   y[b,l,h,p]  = sum_n Cm[b,l,g(h),n] * KV[b,h,n,p] + D[h] * x[b,l,h,p],     g(h) = h % G
+ * x:(B,L,H,P) row(token) stride ldx; Bm,Cm:(B,L,G*N) strides ldb,ldc; dt_raw:(B,L,H) stride lddt with
+ * per-head element stride dt_hstride (2 for the even/odd head split of ADNssd.py:375-378);
+ * dt_bias,A_log,D indexed [h*p_hstride] likewise.  y stride ldy.  kv:(B,H,N,P) fp32 (saved for backward).
+ * (P,N) in {(4,8),(4,16),(8,8)} (per-lane N x P state lives in registers), G in {1,2,4}. */
+int64_t adnm_ssd_ws_bytes(int64_t B, int64_t L, int64_t H, int64_t P, int64_t N, int64_t G);
+int adnm_ssd_reduce_fwd(const void* x, int64_t ldx, const void* Bm, int64_t ldb, const void* Cm, int64_t ldc,
+                        const void* dt_raw, int64_t lddt, int64_t dt_hstride, const float* dt_bias,
+                        const float* A_log, const float* D, int64_t p_hstride, void* y, int64_t ldy, float* kv,
+                        void* ws, int64_t ws_bytes, int64_t B, int64_t L, int64_t H, int64_t P, int64_t N,
+                        int64_t G, int dtype, adnm_stream_t stream);
+/* gradients: dx,dBm,dCm,ddt_raw share the strides of their primals (they may alias slices of one
+ * wide gradient buffer); ddt_bias,dA_log,dD:(H) contiguous fp32, OVERWRITTEN. */
+int adnm_ssd_reduce_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* Bm, int64_t ldb,
+                        const void* Cm, int64_t ldc, const void* dt_raw, int64_t lddt, int64_t dt_hstride,
+                        const float* dt_bias, const float* A_log, const float* D, int64_t p_hstride,
+                        const float* kv, void* dx, int64_t lddx, void* dBm, int64_t lddb, void* dCm, int64_t lddc,
+                        void* ddt_raw, int64_t ldddt, float* ddt_bias, float* dA_log, float* dD, void* ws,
+                        int64_t ws_bytes, int64_t B, int64_t L, int64_t H, int64_t P, int64_t N, int64_t G,
+                        int dtype, adnm_stream_t stream);
+
+/* ---------------------------------------------------------------- depthwise conv, NHWC (K4, part of K3)
+ * y[b,h,w,c] = act( sum_{i,j} wgt[c,i,j] * x[b,h+i-KH/2,w+j-KW/2,c] + bias[c] ) (+ addend[b,h,w,c])
+ * replaces the depthwise nn.Conv2d calls at ADNssd.py:334,343-346,389, Vssd.py:233,
+ * model_untils.py:180-188 (FeedForward.dwconv), :203-211 (ConvFFD.dw_conv), WTConv2d.py:81,86 —
+ * applied directly on the token layout, so the reference's BLD<->BCHW permute().contiguous()
+ * copies disappear.  x pixel stride ldx, y pixel stride ldy, addend pixel stride ldadd (elements);
+ * wgt: TAP-MAJOR (KH,KW,C) fp32 (one float4 per tap and channel quad); KH == KW in {3,5}; C % 4 == 0
+ * (the 5-channel input stage is zero-padded to 8 channels by the caller). */
+int adnm_dwconv_fwd(const void* x, int64_t ldx, const float* wgt, const float* bias, const void* addend,
+                    int64_t ldadd, void* y, int64_t ldy, int64_t B, int64_t H, int64_t W, int64_t C, int KH,
+                    int KW, int act, int dtype, adnm_stream_t stream);
+/* dpre:(B,H,W,C) contiguous scratch in activation dtype (ignored when act==NONE).
+ * dwgt:(KH,KW,C) tap-major, dbias:(C) or NULL: OVERWRITTEN. */
+int64_t adnm_dwconv_bwd_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t C, int KH, int KW);
+int adnm_dwconv_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* wgt,
+                    const float* bias, void* dpre, void* dx, int64_t lddx, float* dwgt, float* dbias, void* ws,
+                    int64_t ws_bytes, int64_t B, int64_t H, int64_t W, int64_t C, int KH, int KW, int act,
+                    int dtype, adnm_stream_t stream);
+
+/* ---------------------------------------------------------------- Haar butterflies, NHWC (K3)
+ * wavelet_transform / inverse_wavelet_transform with db1 (WTConv2d.py:31-51): per 2x2 block
+ * [[a,b],[c,d]]: LL=(a+b+c+d)/2, k1=(a+b-c-d)/2, k2=(a-b+c-d)/2, k3=(a-b-c+d)/2; output channel c*4+k.
+ * dwt: x:(B,H,W,C) with pixel stride ldx and channel stride cx (4 when x is the LL band of a previous
+ * level) -> y:(B,ceil(H/2),ceil(W/2),4C) contiguous; odd H/W are zero-padded (WTConv2d.py:114-116).
+ * idwt: s:(B,h,w,4C) contiguous, optional ll_add:(B,h,w,C) contiguous added to the LL band
+ * (WTConv2d.py:136) -> y:(B,H,W,C) contiguous with H in {2h-1,2h}, W in {2w-1,2w} (crop, :141).
+ * The butterfly is its own transpose, so dwt's backward is idwt and vice versa. */
+int adnm_haar_dwt(const void* x, int64_t ldx, int64_t cx, void* y, int64_t B, int64_t H, int64_t W, int64_t C,
+                  int dtype, adnm_stream_t stream);
+int adnm_haar_idwt(const void* s, const void* ll_add, void* y, int64_t B, int64_t H, int64_t W, int64_t C,
+                   int dtype, adnm_stream_t stream);
+
+/* ---------------------------------------------------------------- InstanceNorm2d, NHWC (K8)
+ * y = act( scale * (x - mean_{hw}) * rsqrt(var_{hw} + eps) + shift ), per (b,c) plane, no affine,
+ * external scalar scale/shift (model_untils.py:90,113,155; nn.InstanceNorm2d at :284,371,741,814).
+ * x,y:(B,HW,C) contiguous; mu,rstd:(B,C) fp32 saved for backward. act in {NONE, GELU}. */
+int64_t adnm_instnorm_ws_bytes(int64_t B, int64_t HW, int64_t C);
+int adnm_instnorm_fwd(const void* x, const float* scale, const float* shift, void* y, float* mu, float* rstd,
+                      void* ws, int64_t ws_bytes, int64_t B, int64_t HW, int64_t C, float eps, int act, int dtype,
+                      adnm_stream_t stream);
+int adnm_instnorm_bwd(const void* dy, const void* x, const float* scale, const float* shift, const float* mu,
+                      const float* rstd, void* dx, float* dscale, float* dshift, void* ws, int64_t ws_bytes,
+                      int64_t B, int64_t HW, int64_t C, int act, int dtype, adnm_stream_t stream);
+
+/* ---------------------------------------------------------------- gated FFN activation (part of K6's epilogue)
+ * FeedForward.forward (model_untils.py:194-195): h:(M,2F) -> y[m,f] = gelu(h[m,f]) * sigmoid(h[m,F+f]).
+ * bwd: dh:(M,2F) from dy:(M,F).  F % 4 == 0; row strides in elements. */
+int adnm_gate_fwd(const void* h, int64_t ldh, void* y, int64_t ldy, int64_t M, int64_t F, int dtype,
+                  adnm_stream_t stream);
+int adnm_gate_bwd(const void* dy, int64_t lddy, const void* h, int64_t ldh, void* dh, int64_t lddh, int64_t M,
+                  int64_t F, int dtype, adnm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADNM_HIP_H */

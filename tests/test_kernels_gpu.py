@@ -1,0 +1,271 @@
+"""HIP kernels (through the C-ABI, via adnm_hip.ops) against the oracle on identical seeded inputs
+and against the golden fixtures produced by the reference.  fp32 tolerance: rel-L2 <= 1e-4 on outputs,
+<= 1e-3 on gradients; bf16 storage: <= 2e-2 vs the fp32 oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import adnm_oracle as O
+from adnm_hip import ops, lib, recipe
+from util import load_case, load_npz, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+OUT_TOL, GRAD_TOL = 1e-4, 1e-3
+
+
+def T(name, shape, scale=1.0, positive=False):
+    return recipe.tensor(name, shape, scale, positive=positive)
+
+
+def leaf(t, dev=None):
+    t = t.clone().to(dev) if dev else t.clone()
+    return t.requires_grad_(True)
+
+
+# ------------------------------------------------------------------------------------------- row norms
+@pytest.mark.parametrize("M,d,mean,bias,affine", [
+    (4 * 16384, 32, False, False, True),   # refiner RMSNorm
+    (1000, 32, False, False, False),
+    (64, 1024, False, False, True),        # deep-level RMSNorm
+    (777, 64, True, True, False),          # Mamba2.norm
+    (64, 2048, True, True, False),
+    (1024, 128, True, False, True),        # BiasFree_LayerNorm + attn_scale/shift
+    (37, 48, True, True, True),
+    (5, 260, False, False, True),
+])
+def test_rownorm(M, d, mean, bias, affine):
+    eps = 1e-6 if not mean else 1e-5
+    x, w = T(f"rn.x{M}{d}", (M, d), 2.0), 1 + 0.2 * T(f"rn.w{d}", (d,))
+    b = 0.1 * T(f"rn.b{d}", (d,)) if bias else None
+    sc = torch.tensor(1.3) if affine else None
+    sh = torch.tensor(-0.2) if affine else None
+    cot = T(f"rn.c{M}{d}", (M, d))
+    # oracle (fp64 to make it the ground truth)
+    xo, wo = leaf(x.double()), leaf(w.double())
+    bo = leaf(b.double()) if bias else None
+    sco, sho = (leaf(sc.double()), leaf(sh.double())) if affine else (None, None)
+    if mean:
+        yo = O.layernorm(xo, wo, bo if bias else 0.0, eps)
+    else:
+        yo = O.rmsnorm(xo, wo, eps)
+    if affine:
+        yo = sco * yo + sho
+    (yo * cot.double()).sum().backward()
+    # kernel
+    xg, wg = leaf(x, DEV), leaf(w, DEV)
+    bg = leaf(b, DEV) if bias else None
+    scg, shg = (leaf(sc, DEV), leaf(sh, DEV)) if affine else (None, None)
+    yg = ops.rownorm(xg, wg, bg, scg, shg, eps, mean)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, OUT_TOL, "y")
+    assert_close(xg.grad, xo.grad, GRAD_TOL, "dx")
+    assert_close(wg.grad, wo.grad, GRAD_TOL, "dw")
+    if bias:
+        assert_close(bg.grad, bo.grad, GRAD_TOL, "db")
+    if affine:
+        assert_close(scg.grad, sco.grad, GRAD_TOL, "dscale", atol=1e-4)
+        assert_close(shg.grad, sho.grad, GRAD_TOL, "dshift", atol=1e-4)
+
+
+def test_rownorm_rejects_bad_shape():
+    x = torch.zeros(4, 6, device=DEV)
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        ops.rownorm(x, torch.ones(6, device=DEV), None, None, None, 1e-5, True)
+
+
+# ------------------------------------------------------------------------------------------- SSD (K1)
+def test_ssd_golden_single_group():
+    z = load_npz("k1_single_group")
+    dt_raw = torch.log(torch.expm1(z["dt"]))  # kernel applies softplus(dt_raw + bias); fixture holds dt itself
+    y = ops.ssd_reduce(z["x"].to(DEV), z["B"].to(DEV), z["C"].to(DEV), dt_raw.to(DEV), torch.zeros(8, device=DEV),
+                       torch.log(-z["A"]).to(DEV), z["D"].to(DEV), 1)
+    assert_close(y, z["y"], OUT_TOL, "k1 y vs reference")
+
+
+def test_ssd_golden_grouped():
+    z = load_npz("k1_grouped")
+    dt_raw = torch.log(torch.expm1(z["dt"]))
+    y = ops.ssd_reduce(z["x"].to(DEV), z["B"].to(DEV), z["C"].to(DEV), dt_raw.to(DEV), torch.zeros(8, device=DEV),
+                       torch.log(-z["A"]).to(DEV), z["D"].to(DEV), 2)
+    assert_close(y, z["y"], OUT_TOL, "k1 grouped y vs reference")
+
+
+@pytest.mark.parametrize("B,L,H,P,N,G", [
+    (2, 300, 16, 4, 16, 2),     # refiner-like (both halves as 2 groups), ragged L
+    (4, 16384, 16, 4, 16, 2),   # config-2 refiner shape
+    (2, 256, 64, 4, 16, 1),     # enc4-like
+    (2, 16, 512, 4, 16, 2),     # decoder1-like: H spans 8 head blocks
+    (1, 70, 12, 4, 16, 2),      # H not a power of two
+    (1, 33, 24, 8, 8, 1),       # headdim 8
+    (3, 1, 4, 4, 8, 4),         # single token
+])
+def test_ssd_fwd_bwd(B, L, H, P, N, G):
+    x, Bm, Cm = T("s.x", (B, L, H, P)), T("s.B", (B, L, G * N)), T("s.C", (B, L, G * N))
+    dt_raw, bias = T("s.dt", (B, L, H), 2.0) - 3.0, T("s.bias", (H,), 0.5)
+    A_log, D = T("s.A", (H,), 1.0) + 1.0, 1 + 0.1 * T("s.D", (H,))
+    cot = T("s.cot", (B, L, H, P))
+    ins = [x, Bm, Cm, dt_raw, bias, A_log, D]
+    o = [leaf(t.double()) for t in ins]
+    dt = F.softplus(o[3] + o[4])
+    yo, kvo = O.ssd_reduce(o[0], dt, torch.exp(o[5]), o[1], o[2], o[6], groups=G)
+    (yo * cot.double()).sum().backward()
+    g = [leaf(t, DEV) for t in ins]
+    yg = ops.ssd_reduce(*g, G)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, OUT_TOL, "y")
+    for name, a, b_ in zip(["dx", "dB", "dC", "ddt", "dbias", "dA_log", "dD"], g, o):
+        assert_close(a.grad, b_.grad, GRAD_TOL, name, atol=1e-6)
+
+
+def test_ssd_linearity_full_size():
+    """Size-independent property at config-2 size: y is linear in x (for fixed B, C, dt)."""
+    B, L, H, P, N, G = 4, 16384, 16, 4, 16, 2
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    x1, x2 = torch.randn(B, L, H, P, generator=gen).to(DEV), torch.randn(B, L, H, P, generator=gen).to(DEV)
+    Bm, Cm = torch.randn(B, L, G * N, generator=gen).to(DEV), torch.randn(B, L, G * N, generator=gen).to(DEV)
+    dt = torch.randn(B, L, H, generator=gen).to(DEV)
+    bias, A_log, D = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV), torch.ones(H, device=DEV)
+    f = lambda x: ops.ssd_reduce(x, Bm, Cm, dt, bias, A_log, D, G)
+    assert_close(f(x1 + 2 * x2), f(x1) + 2 * f(x2), 1e-5, "linearity")
+    assert torch.equal(f(x1), f(x1)), "bitwise reproducible"
+
+
+def test_ssd_rejects_unsupported():
+    with pytest.raises(RuntimeError, match="not in"):
+        ops.ssd_reduce(torch.zeros(1, 4, 2, 16, device=DEV), torch.zeros(1, 4, 16, device=DEV), torch.zeros(1, 4, 16, device=DEV),
+                       torch.zeros(1, 4, 2, device=DEV), torch.zeros(2, device=DEV), torch.zeros(2, device=DEV), torch.zeros(2, device=DEV), 1)
+
+
+# ------------------------------------------------------------------------------------------- depthwise conv
+@pytest.mark.parametrize("B,H,W,C,K,act,bias", [
+    (2, 12, 12, 64, 3, lib.ACT_SILU, False),
+    (4, 128, 128, 128, 3, lib.ACT_SILU, False),   # refiner xBC conv
+    (1, 7, 9, 8, 3, lib.ACT_NONE, True),
+    (2, 4, 4, 4096, 3, lib.ACT_NONE, True),       # deep FFN dwconv
+    (2, 10, 14, 32, 5, lib.ACT_NONE, False),      # wavelet-domain 5x5
+    (1, 5, 3, 12, 5, lib.ACT_GELU, True),
+    (1, 1, 1, 4, 3, lib.ACT_SILU, True),
+])
+def test_dwconv(B, H, W, C, K, act, bias):
+    x, w = T("dw.x", (B, H * W, C)), T("dw.w", (C, 1, K, K), 0.5)
+    b = T("dw.b", (C,), 0.3) if bias else None
+    cot = T("dw.c", (B, H * W, C))
+    xo, wo = leaf(x.double()), leaf(w.double())
+    bo = leaf(b.double()) if bias else None
+    pre = F.conv2d(O.img(xo, H, W), wo, bo, padding=K // 2, groups=C)
+    yo = O.seq({lib.ACT_NONE: lambda t: t, lib.ACT_SILU: O.silu, lib.ACT_GELU: O.gelu}[act](pre))
+    (yo * cot.double()).sum().backward()
+    xg, wg = leaf(x, DEV), leaf(w, DEV)
+    bg = leaf(b, DEV) if bias else None
+    yg = ops.dwconv(xg, wg, bg, H, W, act)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, OUT_TOL, "y")
+    assert_close(xg.grad, xo.grad, GRAD_TOL, "dx")
+    assert_close(wg.grad, wo.grad, GRAD_TOL, "dw")
+    if bias:
+        assert_close(bg.grad, bo.grad, GRAD_TOL, "db")
+
+
+# ------------------------------------------------------------------------------------------- WTConv2d (K3)
+def _wt_args(params, C, Cp, levels, K, dev):
+    """Fold base_scale / wavelet_scale into tap-major taps, zero-padding C -> Cp channels."""
+    pad = lambda t, n: torch.cat([t, t.new_zeros((n - t.shape[0],) + tuple(t.shape[1:]))], 0) if n > t.shape[0] else t
+    bw = params["base_conv.weight"] * params["base_scale.weight"].reshape(C, 1, 1, 1)
+    bb = params["base_conv.bias"] * params["base_scale.weight"].reshape(C) if "base_conv.bias" in params else None
+    base_wt = ops.tap_major(pad(bw, Cp)).to(dev)
+    base_b = pad(bb, Cp).to(dev) if bb is not None else None
+    lws = []
+    for i in range(levels):
+        w = params[f"wavelet_convs.{i}.weight"] * params[f"wavelet_scale.{i}.weight"].reshape(4 * C, 1, 1, 1)
+        lws.append(ops.tap_major(pad(w, 4 * Cp)).to(dev))
+    return base_wt, base_b, lws
+
+
+@pytest.mark.parametrize("name,levels", [("wtconv_c5_l3_16x16", 3), ("wtconv_c8_l2_20x28", 2), ("wtconv_c4_l3_11x13_k3", 3)])
+def test_wtconv_golden(name, levels):
+    params, grads, ins, gins, outs, cots = load_case(name)
+    x = ins["x"]
+    B, C, H, W = x.shape
+    K = params["base_conv.weight"].shape[-1]
+    Cp = (C + 3) // 4 * 4
+    xt = F.pad(O.seq(x), (0, Cp - C)).to(DEV).requires_grad_(True)
+    base_wt, base_b, lws = _wt_args(params, C, Cp, levels, K, DEV)
+    base_wt.requires_grad_(True)
+    for t in lws:
+        t.requires_grad_(True)
+    if base_b is not None:
+        base_b.requires_grad_(True)
+    y = ops.wtconv(xt, H, W, K, base_wt, base_b, lws)
+    yo = O.seq(outs[0])
+    assert_close(y[..., :C], yo, OUT_TOL, "wtconv out vs reference")
+    (y[..., :C] * O.seq(cots[0]).to(DEV)).sum().backward()
+    assert_close(xt.grad[..., :C], O.seq(gins["x"]), GRAD_TOL, "wtconv dx vs reference")
+    # tap gradients -> reference parameter gradients (chain rule through the folded scale)
+    gw = base_wt.grad.t().reshape(Cp, 1, K, K)[:C].cpu()
+    sc = params["base_scale.weight"].reshape(C, 1, 1, 1)
+    assert_close(gw * sc, grads["base_conv.weight"], GRAD_TOL, "d base_conv.weight")
+    assert_close((gw * params["base_conv.weight"]).sum((1, 2, 3)), grads["base_scale.weight"].reshape(C), GRAD_TOL, "d base_scale", atol=1e-5)
+    for i in range(levels):
+        g = lws[i].grad.t().reshape(4 * Cp, 1, K, K)[: 4 * C].cpu()
+        assert_close(g * params[f"wavelet_scale.{i}.weight"].reshape(4 * C, 1, 1, 1), grads[f"wavelet_convs.{i}.weight"], GRAD_TOL,
+                     f"d wavelet_convs.{i}")
+
+
+def test_haar_roundtrip_full_size():
+    """IDWT(DWT(x)) == x at config-2 size (the Haar pair is orthogonal), incl. an odd size."""
+    for B, H, W, C in ((4, 128, 128, 32), (2, 33, 47, 8)):
+        x = torch.randn(B * H * W, C, device=DEV)
+        s = ops.k_haar_dwt(x, B, H, W, C)
+        back = ops.k_haar_idwt(s, None, B, H, W, C)
+        assert_close(back, x, 1e-6, "haar round trip")
+
+
+# ------------------------------------------------------------------------------------------- InstanceNorm
+@pytest.mark.parametrize("B,HW,C,act", [(4, 16384, 32, lib.ACT_NONE), (2, 1024, 64, lib.ACT_GELU), (2, 16, 1024, lib.ACT_NONE), (3, 77, 12, lib.ACT_GELU)])
+def test_instnorm(B, HW, C, act):
+    x = T("in.x", (B, HW, C), 2.0) + 3.0 * T("in.m", (1, 1, C))
+    cot = T("in.c", (B, HW, C))
+    sc, sh = torch.tensor(0.9), torch.tensor(0.15)
+    xo, sco, sho = leaf(x.double()), leaf(sc.double()), leaf(sh.double())
+    mu = xo.mean(1, keepdim=True)
+    var = ((xo - mu) ** 2).mean(1, keepdim=True)
+    yo = sco * (xo - mu) * torch.rsqrt(var + 1e-5) + sho
+    if act == lib.ACT_GELU:
+        yo = O.gelu(yo)
+    (yo * cot.double()).sum().backward()
+    xg, scg, shg = leaf(x, DEV), leaf(sc, DEV), leaf(sh, DEV)
+    yg = ops.instnorm(xg, scg, shg, 1e-5, act)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, OUT_TOL, "y")
+    assert_close(xg.grad, xo.grad, GRAD_TOL, "dx", atol=1e-7)
+    assert_close(scg.grad, sco.grad, GRAD_TOL, "dscale", atol=1e-4)
+    assert_close(shg.grad, sho.grad, GRAD_TOL, "dshift", atol=1e-4)
+
+
+def test_gate():
+    h, cot = T("g.h", (1000, 256), 3.0), T("g.c", (1000, 128))
+    ho = leaf(h.double())
+    yo = O.gelu(ho[:, :128]) * torch.sigmoid(ho[:, 128:])
+    (yo * cot.double()).sum().backward()
+    hg = leaf(h, DEV)
+    yg = ops.gate(hg)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, OUT_TOL, "gate")
+    assert_close(hg.grad, ho.grad, GRAD_TOL, "dgate")
+
+
+# ------------------------------------------------------------------------------------------- bf16 storage
+def test_bf16_storage_paths():
+    B, L, H, P, N, G = 2, 512, 16, 4, 16, 2
+    x, Bm, Cm = T("b.x", (B, L, H, P)), T("b.B", (B, L, G * N)), T("b.C", (B, L, G * N))
+    dt_raw, bias, A_log, D = T("b.dt", (B, L, H)) - 3, torch.zeros(H), torch.ones(H), torch.ones(H)
+    yo, _ = O.ssd_reduce(x, F.softplus(dt_raw), torch.exp(A_log), Bm, Cm, D, groups=G)
+    h16 = lambda t: t.to(DEV).bfloat16()
+    yg = ops.ssd_reduce(h16(x), h16(Bm), h16(Cm), h16(dt_raw), bias.to(DEV), A_log.to(DEV), D.to(DEV), G)
+    assert yg.dtype == torch.bfloat16
+    assert_close(yg.float(), yo, 2e-2, "bf16 ssd")
+    xr, w = T("b.rx", (333, 64)), torch.ones(64)
+    yr = ops.rownorm(h16(xr), w.to(DEV), None, None, None, 1e-6, False)
+    assert_close(yr.float(), O.rmsnorm(xr, w, 1e-6), 2e-2, "bf16 rmsnorm")
