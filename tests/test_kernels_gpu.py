@@ -206,7 +206,12 @@ def test_wtconv_golden(name, levels):
     gw = base_wt.grad.t().reshape(Cp, 1, K, K)[:C].cpu()
     sc = params["base_scale.weight"].reshape(C, 1, 1, 1)
     assert_close(gw * sc, grads["base_conv.weight"], GRAD_TOL, "d base_conv.weight")
-    assert_close((gw * params["base_conv.weight"]).sum((1, 2, 3)), grads["base_scale.weight"].reshape(C), GRAD_TOL, "d base_scale", atol=1e-5)
+    dscale = (gw * params["base_conv.weight"]).sum((1, 2, 3))
+    if base_b is not None:
+        gb = base_b.grad[:C].cpu()
+        dscale = dscale + gb * params["base_conv.bias"]
+        assert_close(gb * sc.reshape(C), grads["base_conv.bias"], GRAD_TOL, "d base_conv.bias")
+    assert_close(dscale, grads["base_scale.weight"].reshape(C), GRAD_TOL, "d base_scale", atol=1e-5)
     for i in range(levels):
         g = lws[i].grad.t().reshape(4 * Cp, 1, K, K)[: 4 * C].cpu()
         assert_close(g * params[f"wavelet_scale.{i}.weight"].reshape(4 * C, 1, 1, 1), grads[f"wavelet_convs.{i}.weight"], GRAD_TOL,
