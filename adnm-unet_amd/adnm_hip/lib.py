@@ -15,7 +15,7 @@ ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 _CT = {
     "const void*": ctypes.c_void_p, "void*": ctypes.c_void_p, "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p,
     "int64_t": ctypes.c_int64, "int": ctypes.c_int, "float": ctypes.c_float, "adnm_stream_t": ctypes.c_void_p,
-    "const char*": ctypes.c_char_p, "void": None,
+    "const char*": ctypes.c_char_p, "char*": ctypes.c_char_p, "void": None,
 }
 
 
@@ -63,10 +63,24 @@ def last_error():
     return load().adnm_last_error().decode()
 
 
+# bench.py sets this to a dict {entry_point: [(start_event, end_event), ...]} to time entry points with
+# HIP events on the stream they are launched on (torch's current stream); None = no instrumentation.
+EVENTS = None
+
+
 def call(name, *args):
     """Invoke an int-returning entry point; raises RuntimeError (as the reference's torch ops
     do on a shape mismatch) when the library rejects the call."""
-    rc = getattr(load(), name)(*args)
+    ev = EVENTS
+    if ev is not None and name in ev:
+        import torch
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = getattr(load(), name)(*args)
+        b.record()
+        ev[name].append((a, b))
+    else:
+        rc = getattr(load(), name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {last_error()}")
 

@@ -135,11 +135,11 @@ def k_dwconv_fwd(x, wt, bias, B, H, W, C, K, act, y=None, addend=None):
     return y
 
 
-def k_dwconv_bwd(dy, x, wt, bias, B, H, W, C, K, act, dx=None, want_bias=False):
+def k_dwconv_bwd(dy, x, wt, bias, B, H, W, C, K, act, dx=None, want_bias=False, want_w=True):
     dev = x.device
     if dx is None:
         dx = torch.empty((B * H * W, C), dtype=x.dtype, device=dev)
-    dwt = torch.empty((K * K, C), dtype=torch.float32, device=dev)
+    dwt = torch.empty((K * K, C), dtype=torch.float32, device=dev) if want_w else None
     db = torch.empty(C, dtype=torch.float32, device=dev) if want_bias else None
     dpre = torch.empty((B * H * W, C), dtype=x.dtype, device=dev) if act != lib.ACT_NONE else None
     nb = lib.query("adnm_dwconv_bwd_ws_bytes", B, H, W, C, K, K)
@@ -147,7 +147,7 @@ def k_dwconv_bwd(dy, x, wt, bias, B, H, W, C, K, act, dx=None, want_bias=False):
     pdy, lddy = _rows(dy)
     px, ldx = _rows(x)
     pdx, lddx = _rows(dx)
-    lib.call("adnm_dwconv_bwd", pdy, lddy, px, ldx, _p(wt), _p(bias), _p(dpre), pdx, lddx, dwt.data_ptr(), _p(db), ws.data_ptr(),
+    lib.call("adnm_dwconv_bwd", pdy, lddy, px, ldx, _p(wt), _p(bias), _p(dpre), pdx, lddx, _p(dwt), _p(db), ws.data_ptr(),
              nb, B, H, W, C, K, K, act, _dt(x), _stream())
     return dx, dwt, db
 
@@ -304,8 +304,9 @@ class DWConvFn(torch.autograd.Function):
         B, H, W, C, K, act, wshape = ctx.dims
         dy2 = dy.reshape(B * H * W, C)
         dy2 = dy2 if dy2.stride(-1) == 1 else dy2.contiguous()
-        dx, dwt, db = k_dwconv_bwd(dy2, x2, wt, bias, B, H, W, C, K, act, want_bias=bias is not None)
-        return dx.view(B, H * W, C), dwt.t().reshape(wshape), db, None, None, None
+        want_w = ctx.needs_input_grad[1]
+        dx, dwt, db = k_dwconv_bwd(dy2, x2, wt, bias, B, H, W, C, K, act, want_bias=bias is not None, want_w=want_w)
+        return dx.view(B, H * W, C), dwt.t().reshape(wshape) if want_w else None, db, None, None, None
 
 
 def dwconv(x, w, bias, H, W, act=lib.ACT_NONE):
@@ -420,3 +421,66 @@ class WTConvFn(torch.autograd.Function):
 
 def wtconv(x, H, W, K, base_wt, base_bias, level_wts):
     return WTConvFn.apply(x, H, W, K, base_wt, base_bias, *level_wts)
+
+
+class ADNMixerFn(torch.autograd.Function):
+    """ADNssd.Mamba2.forward (ADNssd.py:302-462) as one autograd node with a hand-written backward, so the
+    wide intermediate buffers are written once and never sliced/zero-filled by autograd.
+
+    Inputs are prepared by models.ADNssd.Mamba2 (tiny differentiable index ops on the PARAMETERS):
+      w_in   (d_in_proj, dm): in_proj rows reordered to [z | x' | B' | C' | dt]; x' pairs the even/odd
+             channel halves as alternating heads (head 2j+e <- half e, head j), B'/C' = [even | odd], so the
+             reference's index_select gathers (ADNssd.py:329-341,375-386) vanish and K1 runs ONCE with G=2.
+      cw     (9, di+2gN) tap-major effective 3x3 taps of every xBC channel in that order: conv2d taps for the
+             even channels, outer(conv_31, conv_13) for the four asymmetric chains (ADNssd.py:343-346; with
+             no bias and zero padding a 3x1 o 1x3 chain IS a separable 3x3).
+      czw    (9, di) taps of conv2d_z;  ln_w/ln_b permuted like x';  w_out (dm, 2di) = alpha1 * out_proj
+             with its y-columns permuted alike (ADNssd.py:459: alpha1 scales both halves).
+    """
+
+    @staticmethod
+    def forward(ctx, u, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N):
+        Bsz, L, dm = u.shape
+        M = Bsz * L
+        di = czw.shape[1]
+        cx = cw.shape[1]  # di + 2gN
+        nh = di // P
+        u2 = u.reshape(M, dm)
+        u2 = u2 if u2.is_contiguous() else u2.contiguous()
+        proj = torch.mm(u2, w_in.t())  # (M, 2di+2gN+nh)   rocBLAS
+        cat = torch.empty((M, 2 * di), dtype=u.dtype, device=u.device)  # [LN(y) | silu(conv_z(z))]
+        k_dwconv_fwd(proj[:, :di], czw, czb, Bsz, H, W, di, 3, lib.ACT_SILU, y=cat[:, di:])
+        xbc = k_dwconv_fwd(proj[:, di:di + cx], cw, cb, Bsz, H, W, cx, 3, lib.ACT_SILU)
+        y, kv = k_ssd_fwd(xbc[:, :di], xbc[:, di:di + 2 * N], xbc[:, di + 2 * N:], proj[:, di + cx:], dt_bias, A_log, D,
+                          Bsz, L, nh, P, N, 2)
+        _, mu, rstd = k_rownorm_fwd(y, ln_w, ln_b, None, None, 1e-5, True, out=cat[:, :di])
+        out = torch.mm(cat, w_out.t())
+        ctx.save_for_backward(u2, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, proj, xbc, y, kv, mu, rstd, cat)
+        ctx.dims = (Bsz, L, dm, H, W, P, N, di, cx, nh)
+        return out.view(Bsz, L, dm)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (u2, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, proj, xbc, y, kv, mu, rstd, cat) = ctx.saved_tensors
+        Bsz, L, dm, H, W, P, N, di, cx, nh = ctx.dims
+        M = Bsz * L
+        do = dout.reshape(M, dm)
+        do = do if do.is_contiguous() else do.contiguous()
+        dw_out = torch.mm(do.t(), cat)
+        dcat = torch.mm(do, w_out)  # (M, 2di)
+        dy, dln_w, dln_b, _, _ = k_rownorm_bwd(dcat[:, :di], y, ln_w, ln_b, None, mu, rstd, True, True, False)
+        dproj = torch.empty_like(proj)
+        dxbc = torch.empty_like(xbc)
+        ddtb, dA, dD = k_ssd_bwd(dy, xbc[:, :di], xbc[:, di:di + 2 * N], xbc[:, di + 2 * N:], proj[:, di + cx:], dt_bias, A_log, D, kv,
+                                 dxbc[:, :di], dxbc[:, di:di + 2 * N], dxbc[:, di + 2 * N:], dproj[:, di + cx:], Bsz, L, nh, P, N, 2)
+        _, dcw, dcb = k_dwconv_bwd(dxbc, proj[:, di:di + cx], cw, cb, Bsz, H, W, cx, 3, lib.ACT_SILU, dx=dproj[:, di:di + cx],
+                                   want_bias=cb is not None)
+        _, dczw, dczb = k_dwconv_bwd(dcat[:, di:], proj[:, :di], czw, czb, Bsz, H, W, di, 3, lib.ACT_SILU, dx=dproj[:, :di],
+                                     want_bias=czb is not None)
+        du = torch.mm(dproj, w_in)
+        dw_in = torch.mm(dproj.t(), u2)
+        return (du.view(Bsz, L, dm), dw_in, dcw, dcb, dczw, dczb, ddtb, dA, dD, dln_w, dln_b, dw_out, None, None, None, None)
+
+
+def adn_mixer(u, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N):
+    return ADNMixerFn.apply(u, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N)

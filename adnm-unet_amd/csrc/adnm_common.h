@@ -5,11 +5,22 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <string.h>
 #include "../../include/adnm_hip.h"
 
 #define ADNM_WAVE 64
 
 void adnm_set_error(const char* fmt, ...);
+
+// Opt-in per-kernel timing (see core.hip): declare one right before a launch, in its own scope:
+//   { ADNM_PROF("kernel_name", stream, algorithmic_bytes); kernel<<<...>>>(...); }
+struct AdnmProfScope {
+  AdnmProfScope(const char* name, hipStream_t st, double bytes);
+  ~AdnmProfScope();
+  hipStream_t st_;
+  long idx_;
+};
+#define ADNM_PROF(name, st, bytes) AdnmProfScope adnm_prof_scope__(name, st, (double)(bytes))
 
 #define ADNM_REQUIRE(cond, ...)            \
   do {                                     \

@@ -1,5 +1,10 @@
-// Error reporting and ABI version for libadnm_hip.
+// Error reporting, ABI version and the opt-in per-kernel HIP-event profiler of libadnm_hip.
 #include "adnm_common.h"
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -12,3 +17,71 @@ void adnm_set_error(const char* fmt, ...) {
 
 extern "C" const char* adnm_last_error(void) { return g_err; }
 extern "C" int adnm_abi_version(void) { return 1; }
+
+// ---- profiler: OFF by default (one relaxed atomic load per launch).  When bench.py enables it, every kernel
+// launch of the library is bracketed by hipEventRecord on the stream it is launched on; adnm_prof_collect()
+// synchronises the events and reports, per kernel name, launches / total ms / algorithmic bytes.
+namespace {
+struct Rec {
+  const char* name;
+  hipEvent_t a, b;
+  double bytes;
+};
+std::atomic<int> g_on{0};
+std::mutex g_mu;
+std::vector<Rec> g_recs;
+}  // namespace
+
+AdnmProfScope::AdnmProfScope(const char* name, hipStream_t st, double bytes) : st_(st), idx_(-1) {
+  if (!g_on.load(std::memory_order_relaxed)) return;
+  Rec r{name, nullptr, nullptr, bytes};
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  hipEventRecord(r.a, st);
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_recs.push_back(r);
+  idx_ = (long)g_recs.size() - 1;
+}
+
+AdnmProfScope::~AdnmProfScope() {
+  if (idx_ < 0) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if ((size_t)idx_ < g_recs.size()) hipEventRecord(g_recs[idx_].b, st_);
+}
+
+extern "C" int adnm_prof_enable(int on) {
+  g_on.store(on ? 1 : 0);
+  return ADNM_OK;
+}
+
+extern "C" int64_t adnm_prof_collect(char* buf, int64_t buflen) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  struct Agg {
+    long n = 0;
+    double ms = 0, bytes = 0;
+  };
+  std::map<std::string, Agg> agg;
+  for (auto& r : g_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      Agg& a = agg[r.name];
+      a.n += 1;
+      a.ms += ms;
+      a.bytes += r.bytes;
+    }
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  g_recs.clear();
+  std::string out;
+  char line[256];
+  for (auto& kv : agg) {
+    snprintf(line, sizeof(line), "%s\t%ld\t%.6f\t%.0f\n", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.bytes);
+    out += line;
+  }
+  if (buf && buflen > 0) {
+    const size_t n = out.size() < (size_t)buflen - 1 ? out.size() : (size_t)buflen - 1;
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return (int64_t)out.size();
+}

@@ -209,11 +209,11 @@ void launch_conv(const void* x, int64_t ldx, const float* wgt, const float* bias
   const int64_t total = B * H * adnm_cdiv(W, TW) * (C / 4);
   const unsigned grid = (unsigned)adnm_cdiv(total, kBlock);
   if (K == 3)
-    dwconv_kernel<T, 3, MODE><<<grid, kBlock, 0, st>>>((const T*)x, ldx, wgt, bias, (const T*)aux, ldaux, (T*)y, ldy, (int)B, (int)H,
-                                                       (int)W, (int)C, act);
+    { ADNM_PROF("dwconv_k3", st, (double)sizeof(T) * B * H * W * C * (MODE == 1 ? 3 : (aux ? 3 : 2))); dwconv_kernel<T, 3, MODE><<<grid, kBlock, 0, st>>>((const T*)x, ldx, wgt, bias, (const T*)aux, ldaux, (T*)y, ldy, (int)B, (int)H,
+                                                       (int)W, (int)C, act); }
   else
-    dwconv_kernel<T, 5, MODE><<<grid, kBlock, 0, st>>>((const T*)x, ldx, wgt, bias, (const T*)aux, ldaux, (T*)y, ldy, (int)B, (int)H,
-                                                       (int)W, (int)C, act);
+    { ADNM_PROF("dwconv_k5", st, (double)sizeof(T) * B * H * W * C * (MODE == 1 ? 3 : (aux ? 3 : 2))); dwconv_kernel<T, 5, MODE><<<grid, kBlock, 0, st>>>((const T*)x, ldx, wgt, bias, (const T*)aux, ldaux, (T*)y, ldy, (int)B, (int)H,
+                                                       (int)W, (int)C, act); }
 }
 
 template <typename T>
@@ -222,11 +222,11 @@ void launch_wgrad(const void* dpre, int64_t ldd, const void* x, int64_t ldx, flo
   const WGeo g = wgeo(B, H, W, C);
   const dim3 grid(g.gx, g.npb);
   if (K == 3)
-    dwconv_wgrad_kernel<T, 3><<<grid, kBlock, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb);
+    { ADNM_PROF("dwconv_wgrad_k3", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 3><<<grid, kBlock, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb); }
   else
-    dwconv_wgrad_kernel<T, 5><<<grid, kBlock, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb);
+    { ADNM_PROF("dwconv_wgrad_k5", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 5><<<grid, kBlock, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb); }
   const int n = (K * K + 1) * (int)C;
-  dwconv_wgrad_fold<<<(unsigned)adnm_cdiv(n, 256), 256, 0, st>>>(part, g.rows, K * K, (int)C, dwgt, dbias);
+  { ADNM_PROF("dwconv_wgrad_fold", st, 4.0 * (g.rows + 1) * n); dwconv_wgrad_fold<<<(unsigned)adnm_cdiv(n, 256), 256, 0, st>>>(part, g.rows, K * K, (int)C, dwgt, dbias); }
 }
 
 }  // namespace
@@ -255,7 +255,7 @@ extern "C" int adnm_dwconv_bwd(const void* dy, int64_t lddy, const void* x, int6
                                void* dpre, void* dx, int64_t lddx, float* dwgt, float* dbias, void* ws, int64_t ws_bytes, int64_t B,
                                int64_t H, int64_t W, int64_t C, int KH, int KW, int act, int dtype, adnm_stream_t stream) {
   if (int rc = check("dwconv_bwd", x, B, H, W, C, KH, KW, act, dtype)) return rc;
-  ADNM_REQUIRE(dy && wgt && dx && dwgt, "dwconv_bwd: null pointer");
+  ADNM_REQUIRE(dy && wgt && dx, "dwconv_bwd: null pointer");
   ADNM_REQUIRE(act == ADNM_ACT_NONE || dpre, "dwconv_bwd: dpre scratch required when an activation is fused");
   ADNM_REQUIRE(ldx >= C && lddy >= C && lddx >= C && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0,
                "dwconv_bwd: pixel strides must be >= C and multiples of 4");
@@ -272,14 +272,14 @@ extern "C" int adnm_dwconv_bwd(const void* dy, int64_t lddy, const void* x, int6
       g = dpre; ldg = C;
     }
     launch_conv<float, 2>(g, ldg, wgt, nullptr, nullptr, 0, dx, lddx, B, H, W, C, KH, 0, st);
-    launch_wgrad<float>(g, ldg, x, ldx, (float*)ws, dwgt, dbias, B, H, W, C, KH, st);
+    if (dwgt) launch_wgrad<float>(g, ldg, x, ldx, (float*)ws, dwgt, dbias, B, H, W, C, KH, st);
   } else {
     if (act != ADNM_ACT_NONE) {
       launch_conv<uint16_t, 1>(x, ldx, wgt, bias, dy, lddy, dpre, C, B, H, W, C, KH, act, st);
       g = dpre; ldg = C;
     }
     launch_conv<uint16_t, 2>(g, ldg, wgt, nullptr, nullptr, 0, dx, lddx, B, H, W, C, KH, 0, st);
-    launch_wgrad<uint16_t>(g, ldg, x, ldx, (float*)ws, dwgt, dbias, B, H, W, C, KH, st);
+    if (dwgt) launch_wgrad<uint16_t>(g, ldg, x, ldx, (float*)ws, dwgt, dbias, B, H, W, C, KH, st);
   }
   ADNM_CHECK_LAUNCH("dwconv_bwd");
   return ADNM_OK;

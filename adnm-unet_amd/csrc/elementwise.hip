@@ -53,8 +53,8 @@ extern "C" int adnm_gate_fwd(const void* h, int64_t ldh, void* y, int64_t ldy, i
                (long long)M, (long long)F);
   ADNM_REQUIRE(dtype == ADNM_F32 || dtype == ADNM_BF16, "gate_fwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == ADNM_F32) gate_fwd_kernel<float><<<grid_for(M * F / 4), kBlock, 0, st>>>((const float*)h, ldh, (float*)y, ldy, M, (int)F);
-  else gate_fwd_kernel<uint16_t><<<grid_for(M * F / 4), kBlock, 0, st>>>((const uint16_t*)h, ldh, (uint16_t*)y, ldy, M, (int)F);
+  if (dtype == ADNM_F32) { ADNM_PROF("gate_fwd", st, 4.0 * M * F * 3); gate_fwd_kernel<float><<<grid_for(M * F / 4), kBlock, 0, st>>>((const float*)h, ldh, (float*)y, ldy, M, (int)F); }
+  else { ADNM_PROF("gate_fwd", st, 2.0 * M * F * 3); gate_fwd_kernel<uint16_t><<<grid_for(M * F / 4), kBlock, 0, st>>>((const uint16_t*)h, ldh, (uint16_t*)y, ldy, M, (int)F); }
   ADNM_CHECK_LAUNCH("gate_fwd");
   return ADNM_OK;
 }
@@ -67,9 +67,9 @@ extern "C" int adnm_gate_bwd(const void* dy, int64_t lddy, const void* h, int64_
   ADNM_REQUIRE(dtype == ADNM_F32 || dtype == ADNM_BF16, "gate_bwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == ADNM_F32)
-    gate_bwd_kernel<float><<<grid_for(M * F / 4), kBlock, 0, st>>>((const float*)dy, lddy, (const float*)h, ldh, (float*)dh, lddh, M, (int)F);
+    { ADNM_PROF("gate_bwd", st, 4.0 * M * F * 5); gate_bwd_kernel<float><<<grid_for(M * F / 4), kBlock, 0, st>>>((const float*)dy, lddy, (const float*)h, ldh, (float*)dh, lddh, M, (int)F); }
   else
-    gate_bwd_kernel<uint16_t><<<grid_for(M * F / 4), kBlock, 0, st>>>((const uint16_t*)dy, lddy, (const uint16_t*)h, ldh, (uint16_t*)dh, lddh, M, (int)F);
+    { ADNM_PROF("gate_bwd", st, 2.0 * M * F * 5); gate_bwd_kernel<uint16_t><<<grid_for(M * F / 4), kBlock, 0, st>>>((const uint16_t*)dy, lddy, (const uint16_t*)h, ldh, (uint16_t*)dh, lddh, M, (int)F); }
   ADNM_CHECK_LAUNCH("gate_bwd");
   return ADNM_OK;
 }

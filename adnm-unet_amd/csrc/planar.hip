@@ -345,11 +345,11 @@ extern "C" int adnm_haar_dwt(const void* x, int64_t ldx, int64_t cx, void* y, in
   const unsigned grid = (unsigned)adnm_cdiv(total, kBlock);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == ADNM_F32) {
-    if (cx == 1) haar_dwt_kernel<float, 1><<<grid, kBlock, 0, st>>>((const float*)x, ldx, (float*)y, (int)B, (int)H, (int)W, (int)C);
-    else haar_dwt_kernel<float, 4><<<grid, kBlock, 0, st>>>((const float*)x, ldx, (float*)y, (int)B, (int)H, (int)W, (int)C);
+    if (cx == 1) { ADNM_PROF("haar_dwt", st, 4.0 * B * H * W * C * 2); haar_dwt_kernel<float, 1><<<grid, kBlock, 0, st>>>((const float*)x, ldx, (float*)y, (int)B, (int)H, (int)W, (int)C); }
+    else { ADNM_PROF("haar_dwt", st, 4.0 * B * H * W * C * 2); haar_dwt_kernel<float, 4><<<grid, kBlock, 0, st>>>((const float*)x, ldx, (float*)y, (int)B, (int)H, (int)W, (int)C); }
   } else {
-    if (cx == 1) haar_dwt_kernel<uint16_t, 1><<<grid, kBlock, 0, st>>>((const uint16_t*)x, ldx, (uint16_t*)y, (int)B, (int)H, (int)W, (int)C);
-    else haar_dwt_kernel<uint16_t, 4><<<grid, kBlock, 0, st>>>((const uint16_t*)x, ldx, (uint16_t*)y, (int)B, (int)H, (int)W, (int)C);
+    if (cx == 1) { ADNM_PROF("haar_dwt", st, 2.0 * B * H * W * C * 2); haar_dwt_kernel<uint16_t, 1><<<grid, kBlock, 0, st>>>((const uint16_t*)x, ldx, (uint16_t*)y, (int)B, (int)H, (int)W, (int)C); }
+    else { ADNM_PROF("haar_dwt", st, 2.0 * B * H * W * C * 2); haar_dwt_kernel<uint16_t, 4><<<grid, kBlock, 0, st>>>((const uint16_t*)x, ldx, (uint16_t*)y, (int)B, (int)H, (int)W, (int)C); }
   }
   ADNM_CHECK_LAUNCH("haar_dwt");
   return ADNM_OK;
@@ -364,9 +364,9 @@ extern "C" int adnm_haar_idwt(const void* s, const void* ll_add, void* y, int64_
   const unsigned grid = (unsigned)adnm_cdiv(total, kBlock);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == ADNM_F32)
-    haar_idwt_kernel<float><<<grid, kBlock, 0, st>>>((const float*)s, (const float*)ll_add, (float*)y, (int)B, (int)H, (int)W, (int)C);
+    { ADNM_PROF("haar_idwt", st, 4.0 * B * H * W * C * (ll_add ? 2.25 : 2)); haar_idwt_kernel<float><<<grid, kBlock, 0, st>>>((const float*)s, (const float*)ll_add, (float*)y, (int)B, (int)H, (int)W, (int)C); }
   else
-    haar_idwt_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)s, (const uint16_t*)ll_add, (uint16_t*)y, (int)B, (int)H, (int)W, (int)C);
+    { ADNM_PROF("haar_idwt", st, 2.0 * B * H * W * C * (ll_add ? 2.25 : 2)); haar_idwt_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)s, (const uint16_t*)ll_add, (uint16_t*)y, (int)B, (int)H, (int)W, (int)C); }
   ADNM_CHECK_LAUNCH("haar_idwt");
   return ADNM_OK;
 }
@@ -397,13 +397,13 @@ extern "C" int adnm_instnorm_fwd(const void* x, const float* scale, const float*
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)ws;
   if (dtype == ADNM_F32) {
-    instnorm_stats_kernel<float><<<grid, kBlock, 0, st>>>((const float*)x, part, HW, (int)C, g.cgb, g.pix_per_chunk);
-    instnorm_apply_kernel<float><<<grid, kBlock, 0, st>>>((const float*)x, part, scale, shift, (float*)y, mu, rstd, HW, (int)C, g.cgb,
-                                                          g.pix_per_chunk, g.nchunk, eps, act);
+    { ADNM_PROF("instnorm_stats", st, 4.0 * B * HW * C); instnorm_stats_kernel<float><<<grid, kBlock, 0, st>>>((const float*)x, part, HW, (int)C, g.cgb, g.pix_per_chunk); }
+    { ADNM_PROF("instnorm_apply", st, 4.0 * B * HW * C * 2); instnorm_apply_kernel<float><<<grid, kBlock, 0, st>>>((const float*)x, part, scale, shift, (float*)y, mu, rstd, HW, (int)C, g.cgb,
+                                                          g.pix_per_chunk, g.nchunk, eps, act); }
   } else {
-    instnorm_stats_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)x, part, HW, (int)C, g.cgb, g.pix_per_chunk);
-    instnorm_apply_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)x, part, scale, shift, (uint16_t*)y, mu, rstd, HW, (int)C,
-                                                             g.cgb, g.pix_per_chunk, g.nchunk, eps, act);
+    { ADNM_PROF("instnorm_stats", st, 2.0 * B * HW * C); instnorm_stats_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)x, part, HW, (int)C, g.cgb, g.pix_per_chunk); }
+    { ADNM_PROF("instnorm_apply", st, 2.0 * B * HW * C * 2); instnorm_apply_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)x, part, scale, shift, (uint16_t*)y, mu, rstd, HW, (int)C,
+                                                             g.cgb, g.pix_per_chunk, g.nchunk, eps, act); }
   }
   ADNM_CHECK_LAUNCH("instnorm_fwd");
   return ADNM_OK;
@@ -419,17 +419,17 @@ extern "C" int adnm_instnorm_bwd(const void* dy, const void* x, const float* sca
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)ws;
   if (dtype == ADNM_F32) {
-    instnorm_bwd_stats_kernel<float><<<grid, kBlock, 0, st>>>((const float*)dy, (const float*)x, scale, shift, mu, rstd, part, HW, (int)C,
-                                                              g.cgb, g.pix_per_chunk, act);
-    instnorm_bwd_apply_kernel<float><<<grid, kBlock, 0, st>>>((const float*)dy, (const float*)x, part, scale, shift, mu, rstd, (float*)dx,
-                                                              HW, (int)C, g.cgb, g.pix_per_chunk, g.nchunk, act);
+    { ADNM_PROF("instnorm_bwd_stats", st, 4.0 * B * HW * C * 2); instnorm_bwd_stats_kernel<float><<<grid, kBlock, 0, st>>>((const float*)dy, (const float*)x, scale, shift, mu, rstd, part, HW, (int)C,
+                                                              g.cgb, g.pix_per_chunk, act); }
+    { ADNM_PROF("instnorm_bwd_apply", st, 4.0 * B * HW * C * 3); instnorm_bwd_apply_kernel<float><<<grid, kBlock, 0, st>>>((const float*)dy, (const float*)x, part, scale, shift, mu, rstd, (float*)dx,
+                                                              HW, (int)C, g.cgb, g.pix_per_chunk, g.nchunk, act); }
   } else {
-    instnorm_bwd_stats_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)dy, (const uint16_t*)x, scale, shift, mu, rstd, part, HW,
-                                                                 (int)C, g.cgb, g.pix_per_chunk, act);
-    instnorm_bwd_apply_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)dy, (const uint16_t*)x, part, scale, shift, mu, rstd,
-                                                                 (uint16_t*)dx, HW, (int)C, g.cgb, g.pix_per_chunk, g.nchunk, act);
+    { ADNM_PROF("instnorm_bwd_stats", st, 2.0 * B * HW * C * 2); instnorm_bwd_stats_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)dy, (const uint16_t*)x, scale, shift, mu, rstd, part, HW,
+                                                                 (int)C, g.cgb, g.pix_per_chunk, act); }
+    { ADNM_PROF("instnorm_bwd_apply", st, 2.0 * B * HW * C * 3); instnorm_bwd_apply_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)dy, (const uint16_t*)x, part, scale, shift, mu, rstd,
+                                                                 (uint16_t*)dx, HW, (int)C, g.cgb, g.pix_per_chunk, g.nchunk, act); }
   }
-  if (dscale || dshift) instnorm_bwd_scalar_kernel<<<1, 256, 0, st>>>(part, (int)(B * g.nchunk), (int)C, dscale, dshift);
+  if (dscale || dshift) { ADNM_PROF("instnorm_bwd_scalar", st, 4.0 * B * g.nchunk * 2 * C); instnorm_bwd_scalar_kernel<<<1, 256, 0, st>>>(part, (int)(B * g.nchunk), (int)C, dscale, dshift); }
   ADNM_CHECK_LAUNCH("instnorm_bwd");
   return ADNM_OK;
 }

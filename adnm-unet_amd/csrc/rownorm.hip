@@ -210,6 +210,7 @@ int launch_fwd(const void* x, int64_t ldx, const float* w, const float* b, const
 #define FWD(IT)                                                                                               \
   rownorm_fwd_kernel<T, MEAN, IT><<<grid, kBlock, 0, st>>>((const T*)x, ldx, w, b, scale, shift, (T*)y, ldy, mu, \
                                                             rstd, M, (int)d, eps, lpr)
+  ADNM_PROF("rownorm_fwd", st, (double)sizeof(T) * M * d * 2);
   if (it <= 1) FWD(1);
   else if (it <= 2) FWD(2);
   else if (it <= 4) FWD(4);
@@ -231,15 +232,18 @@ int launch_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const f
 #define BWD(IT)                                                                                                  \
   rownorm_bwd_kernel<T, MEAN, IT><<<nblk, kBlock, smem, st>>>((const T*)dy, lddy, (const T*)x, ldx, w, b, scale, mu, \
                                                               rstd, (T*)dx, lddx, part, M, (int)d, lpr)
+  {
+  ADNM_PROF("rownorm_bwd", st, (double)sizeof(T) * M * d * 3);
   if (it <= 1) BWD(1);
   else if (it <= 2) BWD(2);
   else if (it <= 4) BWD(4);
   else if (it <= 8) BWD(8);
   else BWD(16);
 #undef BWD
+  }
   ADNM_CHECK_LAUNCH("rownorm_bwd");
   const int stride = (int)(2 * d + 2);
-  rownorm_bwd_finalize<<<(unsigned)adnm_cdiv(stride, 256), 256, 0, st>>>(part, nblk, (int)d, dw, db, dscale, dshift);
+  { ADNM_PROF("rownorm_bwd_finalize", st, 4.0 * (nblk + 1) * stride); rownorm_bwd_finalize<<<(unsigned)adnm_cdiv(stride, 256), 256, 0, st>>>(part, nblk, (int)d, dw, db, dscale, dshift); }
   ADNM_CHECK_LAUNCH("rownorm_bwd_finalize");
   return ADNM_OK;
 }

@@ -404,23 +404,23 @@ void run_outer(bool weighted, const void* V, int64_t ldv, const void* K, int64_t
   const dim3 grid(g.nchunk, g.nhb, (unsigned)B);
   const size_t smem = (size_t)g.hb * N * P * sizeof(float);
   if (weighted)
-    ssd_outer_reduce_kernel<T, P, N, true><<<grid, kBlock, smem, st>>>((const T*)V, ldv, (const T*)K, ldk, (const T*)dt_raw, lddt,
+    { ADNM_PROF("ssd_outer_reduce", st, (double)sizeof(T) * B * L * (H * P + G * N + H)); ssd_outer_reduce_kernel<T, P, N, true><<<grid, kBlock, smem, st>>>((const T*)V, ldv, (const T*)K, ldk, (const T*)dt_raw, lddt,
                                                                        dt_hs, dt_bias, A_log, p_hs, part, L, (int)H, (int)G,
-                                                                       g.hb, g.tok1, g.nchunk);
+                                                                       g.hb, g.tok1, g.nchunk); }
   else
-    ssd_outer_reduce_kernel<T, P, N, false><<<grid, kBlock, smem, st>>>((const T*)V, ldv, (const T*)K, ldk, nullptr, 0, 0, nullptr,
+    { ADNM_PROF("ssd_outer_reduce", st, (double)sizeof(T) * B * L * (H * P + G * N)); ssd_outer_reduce_kernel<T, P, N, false><<<grid, kBlock, smem, st>>>((const T*)V, ldv, (const T*)K, ldk, nullptr, 0, 0, nullptr,
                                                                         nullptr, 0, part, L, (int)H, (int)G, g.hb, g.tok1,
-                                                                        g.nchunk);
+                                                                        g.nchunk); }
   const int64_t E = H * N * P;
-  ssd_fold_kernel<<<dim3((unsigned)adnm_cdiv(E, 64), (unsigned)B), 256, 0, st>>>(part, out, g.nchunk, E);
+  { ADNM_PROF("ssd_fold", st, 4.0 * B * E * (g.nchunk + 1)); ssd_fold_kernel<<<dim3((unsigned)adnm_cdiv(E, 64), (unsigned)B), 256, 0, st>>>(part, out, g.nchunk, E); }
 }
 
 template <typename T, int P, int N>
 void run_apply(const void* x, int64_t ldx, const void* Cm, int64_t ldc, const float* D, int64_t p_hs, const float* kv, void* y,
                int64_t ldy, int64_t B, int64_t L, int64_t H, int64_t G, hipStream_t st) {
   const Geo g = make_geo(L, H);
-  ssd_apply_kernel<T, P, N><<<dim3(g.nblk2, g.nhb, (unsigned)B), kBlock, 0, st>>>((const T*)x, ldx, (const T*)Cm, ldc, D, p_hs, kv,
-                                                                                  (T*)y, ldy, L, (int)H, (int)G, g.hb, g.tok2);
+  { ADNM_PROF("ssd_apply", st, (double)sizeof(T) * B * L * (2 * H * P + G * N)); ssd_apply_kernel<T, P, N><<<dim3(g.nblk2, g.nhb, (unsigned)B), kBlock, 0, st>>>((const T*)x, ldx, (const T*)Cm, ldc, D, p_hs, kv,
+                                                                                  (T*)y, ldy, L, (int)H, (int)G, g.hb, g.tok2); }
 }
 
 template <typename T, int P, int N>
@@ -430,17 +430,17 @@ void run_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const voi
              int64_t lddc, void* ddt_raw, int64_t ldddt, float* hpart, float* bcpart, float* ddt_bias, float* dA_log, float* dD,
              int64_t B, int64_t L, int64_t H, int64_t G, hipStream_t st) {
   const Geo g = make_geo(L, H);
-  ssd_bwd_kernel<T, P, N><<<dim3(g.nblk2, g.nhb, (unsigned)B), kBlock, 0, st>>>(
+  { ADNM_PROF("ssd_bwd", st, (double)sizeof(T) * B * L * (3 * H * P + 4 * G * N + 2 * H)); ssd_bwd_kernel<T, P, N><<<dim3(g.nblk2, g.nhb, (unsigned)B), kBlock, 0, st>>>(
       (const T*)dy, lddy, (const T*)x, ldx, (const T*)Bm, ldb, (const T*)Cm, ldc, (const T*)dt_raw, lddt, dt_hs, dt_bias, A_log, D,
       p_hs, kv, dkv, (T*)dx, lddx, (T*)dBm, lddb, (T*)dCm, lddc, (T*)ddt_raw, ldddt, hpart, bcpart, L, (int)H, (int)G, g.hb,
-      g.tok2, g.nblk2, g.nhb);
+      g.tok2, g.nblk2, g.nhb); }
   if (g.nhb > 1) {
     const int64_t tot = B * L * 2 * G * N;
-    ssd_bc_fold_kernel<T><<<(unsigned)adnm_cdiv(tot, 256), 256, 0, st>>>(bcpart, g.nhb, B * L, (int)(G * N), (T*)dBm, lddb, (T*)dCm,
-                                                                         lddc);
+    { ADNM_PROF("ssd_bc_fold", st, 4.0 * tot * g.nhb); ssd_bc_fold_kernel<T><<<(unsigned)adnm_cdiv(tot, 256), 256, 0, st>>>(bcpart, g.nhb, B * L, (int)(G * N), (T*)dBm, lddb, (T*)dCm,
+                                                                         lddc); }
   }
-  ssd_head_fold_kernel<<<(unsigned)adnm_cdiv(3 * H, 256), 256, 0, st>>>(hpart, (int)(B * g.nblk2 * kWaves), (int)H, dD, ddt_bias,
-                                                                        dA_log);
+  { ADNM_PROF("ssd_head_fold", st, 4.0 * B * g.nblk2 * kWaves * 3 * H); ssd_head_fold_kernel<<<(unsigned)adnm_cdiv(3 * H, 256), 256, 0, st>>>(hpart, (int)(B * g.nblk2 * kWaves), (int)H, dD, ddt_bias,
+                                                                        dA_log); }
 }
 
 }  // namespace

@@ -1,0 +1,335 @@
+"""ADNM-UNet — drop-in for the reference's models/ADNMUNet.py: `create_ADNMUNet(input_frames,
+output_frames, frame_interval)`, `VisionMamba`, `Encoder`, `Decoder`, `Refiner`, `Block`, `Attention`,
+`create_block` with the reference's constructor arguments, forward signatures and the same 992
+state_dict keys, so the reference's train.py / validate.py run unchanged against this package.
+
+Differences that do not change results:
+  * tokens stay channels-last (B, H*W, C) end to end; the hot ops are HIP kernels (adnm_hip.ops);
+  * skip tensors / features are locals, not module-level dicts (the reference's dicts are shared by
+    nn.DataParallel replicas and race);
+  * `Decoder` uses self.img_size where the reference hard-codes 256 (ADNMUNet.py:634), so 128x128 works;
+  * e2ds[3..6] / att1..4 — computed and never read by the reference (ADNMUNet.py:612-613) — are skipped
+    unless `compute_dead_branches=True`; their parameters still exist and, as in the reference, never
+    receive a gradient.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .ADNssd import Mamba2, StandardAttention
+from .model_untils import *  # noqa: F401,F403  (same star-import surface as the reference, ADNMUNet.py:34)
+from .model_untils import (BiasFree_LayerNorm, RMSNorm, Mlp, Swish, FeedForward, PatchEmbed, WTLayer, DownSample, UpSample,
+                           Channel_Att_Bridge, EncoderToDecoder, OutProj, Conv2dLayer, DropPath, _hw)
+
+
+def _merge(mod, x, residual, features):
+    """Skip / feature merge at the head of Block and Attention (ADNMUNet.py:124-131, :214-221)."""
+    if residual is not None:
+        x = torch.cat((mod.alpha1 * x, mod.alpha2 * residual), dim=-1)
+        if features is not None:
+            x = x + torch.cat((mod.alpha3 * features, mod.alpha4 * features), dim=-1)
+    elif features is not None:
+        x = x + mod.alpha3 * features
+    return x
+
+
+def _normed(norm, x, scale, shift):
+    if isinstance(norm, (RMSNorm, BiasFree_LayerNorm)):
+        return norm(x, scale, shift)  # scalar affine fused into the HIP row-norm
+    return scale * norm(x) + shift
+
+
+class Block(nn.Module):
+    def __init__(self, dim, out_dim, mixer, norm_layer=BiasFree_LayerNorm, fused_add_norm=False, residual_in_fp32=False,
+                 drop_path=0., drop=0., patches_resolution=[64, 64], mlp_ratio=4, num_layers=1, act_layer=nn.SiLU, attn=False):
+        super().__init__()
+        self.residual_in_fp32 = residual_in_fp32
+        self.fused_add_norm = fused_add_norm
+        self.dim, self.out_dim, self.num_layers = dim, out_dim, num_layers
+        self.alpha1 = nn.Parameter(torch.tensor(1, dtype=torch.float))
+        self.alpha2 = nn.Parameter(torch.tensor(1, dtype=torch.float))
+        self.alpha3 = nn.Parameter(torch.tensor(1, dtype=torch.float))
+        self.alpha4 = nn.Parameter(torch.tensor(1, dtype=torch.float))
+        self.beta1 = nn.Parameter(torch.ones(num_layers))
+        self.beta2 = nn.Parameter(torch.ones(num_layers))
+        self.beta3 = nn.Parameter(torch.ones(num_layers))
+        self.beta4 = nn.Parameter(torch.ones(num_layers))
+        self.mixer_layers = nn.ModuleList([mixer() for _ in range(num_layers)])
+        self.drop_path_layers = nn.ModuleList([DropPath(drop_path) if drop_path > 0. else nn.Identity() for _ in range(num_layers)])
+        self.norm1_layers = nn.ModuleList([norm_layer(dim) for _ in range(num_layers)])
+        self.ffns = nn.ModuleList([FeedForward(dim=dim, ffn_expansion_factor=2, bias=True) for _ in range(num_layers)])
+        self.norm2_layers = nn.ModuleList([norm_layer(dim) for _ in range(num_layers)])
+        self.scale1 = nn.ParameterList([nn.Parameter(torch.tensor(1.)) for _ in range(num_layers)])
+        self.shift1 = nn.ParameterList([nn.Parameter(torch.tensor(0.)) for _ in range(num_layers)])
+        self.scale2 = nn.ParameterList([nn.Parameter(torch.tensor(1.)) for _ in range(num_layers)])
+        self.shift2 = nn.ParameterList([nn.Parameter(torch.tensor(0.)) for _ in range(num_layers)])
+        self.act = Swish()
+        if self.dim != self.out_dim:
+            self.out_proj = nn.Linear(dim, out_dim)
+        self.gamma = nn.Parameter(1 * torch.ones(dim))
+
+    def forward(self, hidden_states, residual=None, features=None, inference_params=None, use_checkpoint=False):
+        x = _merge(self, hidden_states, residual, features)
+        b, l, d = x.shape
+        h, w = _hw(l)
+        for i in range(self.num_layers):
+            beta1, beta2 = self.beta1[i], self.beta2[i]  # beta3/beta4 alias beta1/beta2 in the reference (:145-146)
+            xn = _normed(self.norm1_layers[i], x, self.scale1[i], self.shift1[i])
+            x = beta1 * x + beta2 * self.drop_path_layers[i](self.mixer_layers[i](xn, h, w))
+            xn = _normed(self.norm2_layers[i], x, self.scale2[i], self.shift2[i])
+            x = beta1 * x + beta2 * self.ffns[i].forward_tokens(xn, h, w)
+        x = x * self.gamma
+        if self.dim != self.out_dim:
+            x = self.out_proj(x)
+        return x
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, out_dim=None, headdim=4):
+        super().__init__()
+        self.dim = dim
+        self.out_dim = out_dim or dim
+        self.attn_norm1 = BiasFree_LayerNorm(dim)
+        self.attn_norm2 = BiasFree_LayerNorm(dim)
+        self.attn_layer = StandardAttention(dim, heads=dim // headdim, dim_head=headdim, dropout=0.)
+        self.attn_mlp = Mlp(dim)
+        self.attn_scale1 = nn.Parameter(torch.tensor(1.))
+        self.attn_shift1 = nn.Parameter(torch.tensor(0.))
+        self.attn_scale2 = nn.Parameter(torch.tensor(1.))
+        self.attn_shift2 = nn.Parameter(torch.tensor(0.))
+        if self.dim != self.out_dim:
+            self.out_proj = nn.Linear(dim, out_dim)
+        self.gamma = nn.Parameter(1 * torch.ones(dim))
+        for n in ("alpha1", "alpha2", "alpha3", "alpha4", "beta1", "beta2", "beta3", "beta4"):
+            setattr(self, n, nn.Parameter(torch.tensor(1, dtype=torch.float)))
+
+    def forward(self, hidden_states, residual=None, features=None, inference_params=None, use_checkpoint=False):
+        x = _merge(self, hidden_states, residual, features)
+        b, l, d = x.shape
+        h, w = _hw(l)
+        xn = self.attn_norm1(x, self.attn_scale1, self.attn_shift1)
+        x = self.beta1 * x + self.beta2 * self.attn_layer(xn, h, w)
+        xn = self.attn_norm2(x, self.attn_scale2, self.attn_shift2)
+        x = self.beta3 * x + self.beta4 * self.attn_mlp(xn)
+        x = x * self.gamma
+        if self.dim != self.out_dim:
+            x = self.out_proj(x)
+        return x
+
+
+def create_block(d_model, out_dim, headdim=None, ssm_cfg=None, num_layers=1, norm_epsilon=1e-5, drop_path=0., drop=0.,
+                 rms_norm=True, residual_in_fp32=True, fused_add_norm=True, layer_idx=None, d_state=16, device=None, dtype=None):
+    if ssm_cfg is None:
+        ssm_cfg = {}
+    if headdim is None:
+        headdim = 4 if d_model <= 32 else 8 if d_model <= 256 else 16 if d_model <= 512 else 24 if d_model <= 768 else 32
+    mixer = partial(Mamba2, layer_idx=layer_idx, d_model=d_model, headdim=headdim, linear_attn_duality=True, d_state=d_state, **ssm_cfg)
+    norm_layer = partial(nn.LayerNorm if not rms_norm else RMSNorm, eps=norm_epsilon)
+    block = Block(dim=d_model, out_dim=out_dim, mixer=mixer, num_layers=num_layers, norm_layer=norm_layer, drop_path=drop_path,
+                  drop=drop, fused_add_norm=fused_add_norm, residual_in_fp32=residual_in_fp32)
+    block.layer_idx = layer_idx
+    return block
+
+
+def _init_weights(module, n_layer, initializer_range=0.02, rescale_prenorm_residual=True, n_residuals_per_layer=1):
+    """Second init pass of the reference (ADNMUNet.py:294-313)."""
+    if isinstance(module, nn.Linear):
+        if module.bias is not None and not getattr(module.bias, "_no_reinit", False):
+            nn.init.zeros_(module.bias)
+    elif isinstance(module, nn.Embedding):
+        nn.init.normal_(module.weight, std=initializer_range)
+    if rescale_prenorm_residual:
+        for name, p in module.named_parameters():
+            if name in ("out_proj.weight", "fc2.weight"):
+                nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+                with torch.no_grad():
+                    p /= math.sqrt(n_residuals_per_layer * n_layer)
+
+
+def segm_init_weights(m):
+    """First init pass of the reference (ADNMUNet.py:316-323)."""
+    if isinstance(m, nn.Linear):
+        nn.init.trunc_normal_(m.weight, std=0.02, a=-2.0, b=2.0)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.constant_(m.bias, 0)
+        nn.init.constant_(m.weight, 1.0)
+
+
+class Encoder(nn.Module):
+    def __init__(self, img_size=256, depth=[1, 1, 1], embed_dim=[64, 128, 128], headdim=8, in_channels=5, kernel=[5, 4, 3],
+                 ratio=[2, 2, 2], wt_levels=[4, 3, 2], simple_patch=False, norm_epsilon=1e-5, ssm_cfg=None, InstanceNorm=True):
+        super().__init__()
+        if simple_patch:
+            raise NotImplementedError("simple_patch=True is unused by create_ADNMUNet")
+        self.img_size, self.depth, self.embed_dim = img_size, depth, embed_dim
+        self.in_channels, self.kernel, self.ratio = in_channels, kernel, ratio
+        self.encoder1 = PatchEmbed(img_size=img_size, patch_size=ratio[0], in_channels=in_channels, embed_dim=embed_dim[0],
+                                   kernel=kernel[0], wt_levels=wt_levels[0], InstanceNorm=InstanceNorm)
+        self.down_sample1 = DownSample(dim=embed_dim[0], ratio=ratio[0])
+        self.encoder2 = WTLayer(embed_dim[0], embed_dim[1], kernel=kernel[1], wt_levels=wt_levels[1], InstanceNorm=InstanceNorm)
+        self.down_sample2 = DownSample(dim=embed_dim[1], ratio=ratio[1])
+        self.encoder3 = WTLayer(embed_dim[1], embed_dim[2], kernel=kernel[2], wt_levels=wt_levels[2], InstanceNorm=InstanceNorm)
+        self.down_sample3 = DownSample(dim=embed_dim[2], ratio=ratio[2])
+        self.attn = Attention(dim=embed_dim[2], headdim=headdim)
+        blk = lambda i, n: create_block(d_model=embed_dim[i], out_dim=embed_dim[i + 1], headdim=headdim, num_layers=n,
+                                        ssm_cfg=ssm_cfg, norm_epsilon=norm_epsilon)
+        self.encoder4 = blk(2, depth[0])
+        self.down_sample4 = DownSample(dim=embed_dim[3], ratio=ratio[3])
+        self.encoder5 = blk(3, depth[1])
+        self.down_sample5 = DownSample(dim=embed_dim[4], ratio=ratio[4])
+        self.encoder6 = blk(4, depth[2])
+        self.attn2 = Attention(embed_dim[5], headdim=headdim)
+
+    def forward(self, x):
+        """x: (B, T_in, H, W) -> (bottleneck tokens, [7 skips], last input frame) (ADNMUNet.py:437-483)."""
+        x = x.flatten(2).transpose(1, 2)
+        skips = []
+        x, res = self.encoder1(x)
+        skips.append(x)
+        x = self.encoder2(self.down_sample1(x))
+        skips.append(x)
+        x = self.encoder3(self.down_sample2(x))
+        skips.append(x)
+        x = self.attn(self.down_sample3(x))
+        skips.append(x)
+        x = self.encoder4(x)
+        skips.append(x)
+        x = self.encoder5(self.down_sample4(x))
+        skips.append(x)
+        x = self.encoder6(self.down_sample5(x))
+        skips.append(x)
+        x = self.attn2(x)
+        return x, skips, res
+
+
+class Decoder(nn.Module):
+    def __init__(self, img_size=256, depth=[1, 1, 1], embed_dim=[64, 128, 128], headdim=8, refine_dim=[32, 32, 32], kernel=[5, 4, 3],
+                 ratio=[2, 2, 2], wt_levels=[4, 3, 2], simple_patch=False, norm_epsilon=1e-5, ssm_cfg=None, InstanceNorm=True,
+                 compute_dead_branches=False):
+        super().__init__()
+        self.img_size, self.depth, self.embed_dim, self.kernel, self.ratio = img_size, depth, embed_dim, kernel, ratio
+        self.compute_dead_branches = compute_dead_branches
+        blk = lambda d, o, n: create_block(d_model=d, out_dim=o, headdim=headdim, num_layers=n, ssm_cfg=ssm_cfg, norm_epsilon=norm_epsilon)
+        self.decoder1 = blk(embed_dim[5], embed_dim[4], depth[2])
+        self.up_sample1 = UpSample(dim=embed_dim[4], ratio=ratio[4])
+        self.decoder2 = blk(embed_dim[4] * 2, embed_dim[3], depth[1])
+        self.up_sample2 = UpSample(dim=embed_dim[3], ratio=ratio[3])
+        self.decoder3 = blk(embed_dim[3] * 2, embed_dim[2], depth[0])
+        self.attn = Attention(embed_dim[2], embed_dim[2], headdim=headdim)
+        self.up_sample3 = UpSample(dim=embed_dim[2], ratio=ratio[2])
+        self.decoder4 = WTLayer(embed_dim[2] * 2, embed_dim[1], kernel=kernel[2], wt_levels=wt_levels[2], if_res=True, InstanceNorm=InstanceNorm)
+        self.up_sample4 = UpSample(dim=embed_dim[1], ratio=ratio[1])
+        self.decoder5 = WTLayer(embed_dim[1] * 2, embed_dim[0], kernel=kernel[1], wt_levels=wt_levels[1], if_res=True, InstanceNorm=InstanceNorm)
+        self.up_sample5 = UpSample(dim=embed_dim[0], ratio=ratio[0])
+        self.decoder6 = WTLayer(embed_dim[0] * 2, embed_dim[0], kernel=kernel[0], wt_levels=wt_levels[0], if_res=True, InstanceNorm=InstanceNorm)
+        self.decoder6_s = Conv2dLayer(embed_dim[0], refine_dim[0], kernel_size=1, stride=1, padding=0)
+        c_list = list(embed_dim)
+        c_list.insert(2, c_list[2])  # the attention stage's skip (the reference mutates the shared list, ADNMUNet.py:590)
+        embed_dim.insert(2, embed_dim[2])
+        self.fusion = Channel_Att_Bridge(c_list=c_list)
+        self.e2ds = nn.ModuleList([EncoderToDecoder(embed_dim=c_list[len(c_list) - 1 - i], InstanceNorm=InstanceNorm)
+                                   for i in range(len(c_list))])
+
+    def forward(self, x, skips):
+        """(ADNMUNet.py:603-636 of the reference).  skips[i] = encoder_layer_residual[i]."""
+        dead = self.compute_dead_branches
+        gates = self.fusion(skips, live=None if dead else {4, 5, 6})
+        feats = {}
+        for i in range(7 if dead else 3):
+            feats[i] = self.e2ds[i](x=skips[6 - i], res=gates[6 - i])
+        x = self.up_sample1(self.decoder1(x, features=feats[0]))
+        x = self.up_sample2(self.decoder2(x, residual=skips[5], features=feats[1]))
+        x = self.decoder3(x, residual=skips[4], features=feats[2])
+        x = self.up_sample3(self.attn(x))
+        x = self.up_sample4(self.decoder4(x, residual=skips[2], features=feats.get(4)))
+        x = self.up_sample5(self.decoder5(x, residual=skips[1], features=feats.get(5)))
+        x = self.decoder6(x, residual=skips[0], features=feats.get(6))
+        return self.decoder6_s.forward_tokens(x, self.img_size, self.img_size)
+
+
+class Refiner(nn.Module):
+    def __init__(self, img_size=256, refine_depth=[1, 1, 1, 1], refine_dim=[64, 128, 128], wt_levels=[4, 3, 2], out_channels=3,
+                 refine_headdim=[4, 4, 4, 4], norm_epsilon=1e-5, out_expand=2, ssm_cfg=None, InstanceNorm=True):
+        super().__init__()
+        self.img_size, self.refine_depth = img_size, refine_depth
+        blk = lambda i, o: create_block(d_model=refine_dim[i], out_dim=refine_dim[o], num_layers=refine_depth[i], ssm_cfg=ssm_cfg,
+                                        norm_epsilon=norm_epsilon, headdim=refine_headdim[i])
+        self.refiner1 = blk(0, 1)
+        self.refiner2 = blk(1, 2)
+        self.refiner3 = blk(2, 3)
+        self.refiner4 = blk(3, -1)
+        self.out_proj = OutProj(num_frames=out_channels, embed_dim=refine_dim[-1], img_size=[img_size, img_size],
+                                wt_levels=wt_levels[0], out_expand=out_expand, InstanceNorm=InstanceNorm)
+
+    def forward(self, x, res):
+        x = self.refiner4(self.refiner3(self.refiner2(self.refiner1(x))))
+        return self.out_proj(x, res)
+
+
+class VisionMamba(nn.Module):
+    def __init__(self, img_size=256, depth=[1, 1, 1], refine_depth=[1, 1], refine_dim=[32, 32, 32], refine_headdim=[8, 4],
+                 embed_dim=[64, 128, 128], headdim=8, channels=5, out_channels=3, ssm_cfg=None, norm_epsilon=1e-5,
+                 initializer_cfg=None, kernel=[5, 4, 3], ratio=[2, 2, 2], wt_levels=[4, 3, 2], out_expand=2, InstanceNorm=True,
+                 simple_patch=False, e2d=True, compute_dead_branches=False, **kwargs):
+        super().__init__()
+        self.depth = depth
+        self.encoder = Encoder(img_size=img_size, depth=depth, embed_dim=embed_dim, headdim=headdim, in_channels=channels, kernel=kernel,
+                               ratio=ratio, wt_levels=wt_levels, simple_patch=simple_patch, norm_epsilon=norm_epsilon, InstanceNorm=InstanceNorm)
+        self.decoder = Decoder(img_size=img_size, depth=depth, embed_dim=embed_dim, headdim=headdim, refine_dim=refine_dim, kernel=kernel,
+                               ratio=ratio, wt_levels=wt_levels, norm_epsilon=norm_epsilon, InstanceNorm=InstanceNorm,
+                               compute_dead_branches=compute_dead_branches)
+        self.refiner = Refiner(img_size=img_size, refine_depth=refine_depth, refine_dim=refine_dim, refine_headdim=refine_headdim,
+                               out_channels=out_channels, wt_levels=wt_levels, out_expand=out_expand, norm_epsilon=norm_epsilon,
+                               InstanceNorm=InstanceNorm)
+        self.apply(segm_init_weights)
+        self.apply(partial(_init_weights, n_layer=len(depth), **(initializer_cfg if initializer_cfg is not None else {})))
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"pos_embed", "cls_token", "temporal_pos_embedding"}
+
+    def forward(self, x, mask=None):
+        """x: (B, T_in, 1, H, W) float32 -> (B, T_out, 1, H, W) (ADNMUNet.py:824-829 of the reference)."""
+        x = x.squeeze(2)
+        x, skips, res = self.encoder(x)
+        x = self.decoder(x, skips)
+        out = self.refiner(x, res)
+        return out.unsqueeze(2)
+
+
+def get_scalar_parameters(model):
+    return [p for p in model.parameters() if p.requires_grad and p.nelement() == 1]
+
+
+def create_vm(img_size=256, depth=[1, 1, 1], refine_depth=[1, 1, 1, 1], refine_headdim=[4, 4, 4, 4], refine_dim=[32, 32, 32, 32],
+              embed_dim=[32, 64, 128, 256, 512, 1024], headdim=4, channels=3, out_channels=3, ssm_cfg=None, norm_epsilon=1e-6,
+              kernel=[5, 3, 3], ratio=[2, 2, 2, 2, 2, 2], wt_levels=[3, 1, 1], out_expand=2, InstanceNorm=True, initializer_cfg=None):
+    return VisionMamba(img_size=img_size, depth=depth, refine_depth=refine_depth, refine_headdim=refine_headdim, refine_dim=refine_dim,
+                       embed_dim=list(embed_dim), headdim=headdim, channels=channels, out_channels=out_channels, ssm_cfg=ssm_cfg,
+                       norm_epsilon=norm_epsilon, initializer_cfg=initializer_cfg, kernel=kernel, ratio=ratio, wt_levels=wt_levels,
+                       out_expand=out_expand, InstanceNorm=InstanceNorm)
+
+
+def videomamba_middle(pretrained=False, **kwargs):
+    model = create_vm(img_size=256, channels=5, norm_epsilon=1e-5, **kwargs)
+    model.default_cfg = {}
+    return model
+
+
+def create_ADNMUNet(input_frames, output_frames, frame_interval, img_size=256, **overrides):
+    """Same recipe as the reference factory (ADNMUNet.py:906-940).  `img_size` (default 256, the
+    reference's hard-wired value) is the one extra, optional argument: BASELINE configs use 128."""
+    refine_dim = [32, 32, 32, 32] if output_frames > 5 else [32, 32, 16, 16]
+    if frame_interval < 120 / input_frames:
+        InstanceNorm, kernel = True, [5, 5, 5]
+    else:
+        InstanceNorm, kernel = False, [5, 3, 3]
+    return VisionMamba(img_size=img_size, depth=[1, 1, 1], refine_depth=[1, 1, 1, 1], refine_headdim=[4, 4, 4, 4], refine_dim=refine_dim,
+                       embed_dim=[32, 64, 128, 256, 512, 1024], headdim=4, channels=input_frames, out_channels=output_frames,
+                       ssm_cfg=None, norm_epsilon=1e-6, initializer_cfg=None, kernel=kernel, ratio=[2, 2, 2, 2, 2, 2],
+                       wt_levels=[3, 2, 1], out_expand=2, InstanceNorm=InstanceNorm, **overrides)

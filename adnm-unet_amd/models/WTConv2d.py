@@ -1,0 +1,109 @@
+"""WTConv2d — drop-in for the reference's models/WTConv2d.py (same constructor, forward and
+state_dict keys: wt_filter, iwt_filter, base_conv.*, base_scale.weight, wavelet_convs.i.weight,
+wavelet_scale.i.weight), executed by hand-written HIP kernels on the channels-last token layout.
+
+Reference behaviour (WTConv2d.py:100-153): a `wt_levels`-deep Haar (db1) pyramid; at each level a
+depthwise KxK conv + per-channel scale on the 4C sub-bands of the RAW low-pass of the level above;
+reconstruction from the deepest level, adding the deeper reconstruction to the convolved LL band;
+plus base_scale * base_conv(x).  Here: adnm_haar_dwt / adnm_dwconv_fwd / adnm_haar_idwt through
+adnm_hip.ops.WTConvFn (hand-written backward).  The per-channel scales are folded into the conv taps
+(tiny differentiable parameter ops), so no scale pass over the activations exists.
+"""
+import math
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from adnm_hip import ops
+
+
+def create_wavelet_filter(wave, in_size, out_size, type=torch.float):
+    """Frozen Haar analysis / synthesis filter banks with the reference's layout (WTConv2d.py:9-29):
+    (4*C, 1, 2, 2), channel c*4+k, k = LL, (rows differ), (cols differ), (diagonal)."""
+    if wave != "db1":
+        raise NotImplementedError("only the Haar wavelet ('db1') is implemented")
+    s = torch.tensor(1.0 / math.sqrt(2.0), dtype=type)
+    h = float(s * s)  # the reference stores float32(1/sqrt2)^2 = 0.49999997, keep the checkpoints bit-compatible
+    bank = torch.tensor([[[h, h], [h, h]], [[h, h], [-h, -h]], [[h, -h], [h, -h]], [[h, -h], [-h, h]]], dtype=type)
+    dec = bank[:, None].repeat(in_size, 1, 1, 1)
+    rec = bank[:, None].repeat(out_size, 1, 1, 1)
+    return dec, rec
+
+
+class _ScaleModule(nn.Module):
+    def __init__(self, dims, init_scale=1.0, init_bias=0):
+        super().__init__()
+        self.dims = dims
+        self.weight = nn.Parameter(torch.ones(*dims) * init_scale)
+        self.bias = None
+
+    def forward(self, x):
+        return torch.mul(self.weight, x)
+
+
+def _pad_rows(t, n):
+    if t is None or t.shape[0] == n:
+        return t
+    return torch.cat([t, t.new_zeros((n - t.shape[0],) + tuple(t.shape[1:]))], 0)
+
+
+class WTConv2d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=5, stride=1, bias=True, wt_levels=2, wt_type='db1'):
+        super().__init__()
+        assert in_channels == out_channels
+        self.in_channels = in_channels
+        self.wt_levels = wt_levels
+        self.stride = stride
+        self.dilation = 1
+        self.kernel_size = kernel_size
+        wt, iwt = create_wavelet_filter(wt_type, in_channels, in_channels, torch.float)
+        self.wt_filter = nn.Parameter(wt, requires_grad=False)
+        self.iwt_filter = nn.Parameter(iwt, requires_grad=False)
+        self.base_conv = nn.Conv2d(in_channels, in_channels, kernel_size, padding='same', stride=1, dilation=1,
+                                   groups=in_channels, bias=bias)
+        self.base_scale = _ScaleModule([1, in_channels, 1, 1])
+        self.wavelet_convs = nn.ModuleList(
+            [nn.Conv2d(in_channels * 4, in_channels * 4, kernel_size, padding='same', stride=1, dilation=1,
+                       groups=in_channels * 4, bias=False) for _ in range(wt_levels)])
+        self.wavelet_scale = nn.ModuleList(
+            [_ScaleModule([1, in_channels * 4, 1, 1], init_scale=0.1) for _ in range(wt_levels)])
+        if stride > 1:
+            self.stride_filter = nn.Parameter(torch.ones(in_channels, 1, 1, 1), requires_grad=False)
+
+    def _taps(self):
+        """Tap-major fp32 taps with the scales folded in; channels zero-padded to a multiple of 4
+        (the 5-frame input stage) so every kernel works on 16-byte channel quads."""
+        C = self.in_channels
+        Cp = (C + 3) // 4 * 4
+        bs = self.base_scale.weight.reshape(C, 1, 1, 1)
+        base = ops.tap_major(_pad_rows(self.base_conv.weight * bs, Cp))
+        bias = None
+        if self.base_conv.bias is not None:
+            bias = _pad_rows(self.base_conv.bias * bs.reshape(C), Cp).float().contiguous()
+        levels = []
+        for conv, sc in zip(self.wavelet_convs, self.wavelet_scale):
+            w = conv.weight * sc.weight.reshape(4 * C, 1, 1, 1)
+            if Cp != C:
+                w = _pad_rows(w.reshape(C, 4, *w.shape[1:]), Cp).reshape(4 * Cp, *w.shape[1:])
+            levels.append(ops.tap_major(w))
+        return Cp, base, bias, levels
+
+    def forward_tokens(self, x, H, W):
+        """x: (B, H*W, C) channels-last tokens -> same shape."""
+        C = self.in_channels
+        Cp, base, bias, levels = self._taps()
+        if Cp != C:
+            x = F.pad(x, (0, Cp - C))
+        y = ops.wtconv(x, H, W, self.kernel_size, base, bias, levels)
+        if Cp != C:
+            y = y[..., :C]
+        return y
+
+    def forward(self, x):
+        """x: (B, C, H, W), as the reference (WTConv2d.py:100)."""
+        B, C, H, W = x.shape
+        y = self.forward_tokens(x.permute(0, 2, 3, 1).reshape(B, H * W, C), H, W)
+        y = y.reshape(B, H, W, C).permute(0, 3, 1, 2)
+        if self.stride > 1:  # do_stride: a ones 1x1 depthwise conv with stride s == subsampling (WTConv2d.py:93-96,149-151)
+            y = y[:, :, ::self.stride, ::self.stride]
+        return y

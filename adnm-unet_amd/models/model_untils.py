@@ -1,0 +1,555 @@
+"""Building blocks of the ADNM-UNet conv stack — drop-in for the reference's models/model_untils.py
+(same class names, constructor arguments, forward signatures and state_dict keys).
+
+What runs where (DESIGN.md has the table): depthwise convs, the Haar wavelet pyramid (WTConv2d),
+InstanceNorm(+scalar affine, +GELU), BiasFree/Layer/RMS norms and the gated-FFN activation are
+hand-written HIP kernels working directly on the channels-last token layout (B, H*W, C) that the
+reference keeps between stages; dense 3x3 / transposed convs and the 1x1 / Linear projections are
+plain library GEMM/conv calls (rocBLAS / MIOpen through torch) on channels-last views.  Modules whose
+reference forward takes NCHW keep accepting NCHW; parents call the `*_tokens` methods so no
+BLD<->BCHW copies (13.5 % of the reference's CPU step) remain on the token path.
+"""
+import math
+import numbers
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from adnm_hip import ops, lib
+from models.WTConv2d import WTConv2d
+
+
+def to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+def to_bchw(x):
+    b, l, d = x.shape
+    h = w = int(math.isqrt(l))
+    return x.reshape(b, h, w, d).permute(0, 3, 1, 2)
+
+
+def to_bld(x):
+    return x.flatten(2).transpose(1, 2)
+
+
+def _hw(l):
+    h = int(math.isqrt(l))
+    return h, h
+
+
+def nchw_view(x, h, w):
+    """(B, L, C) tokens -> (B, C, H, W) logical NCHW tensor with channels-last strides (no copy)."""
+    b, l, c = x.shape
+    return x.reshape(b, h, w, c).permute(0, 3, 1, 2)
+
+
+def tokens_of(y):
+    """(B, C, H, W) -> (B, H*W, C); free when y is channels-last."""
+    b, c, h, w = y.shape
+    return y.permute(0, 2, 3, 1).reshape(b, h * w, c)
+
+
+class DropPath(nn.Module):
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        return x * mask / keep
+
+
+class BiasFree_LayerNorm(nn.Module):
+    """model_untils.py:29-48 of the reference: (x - mu) / sqrt(var + 1e-5) * weight."""
+
+    def __init__(self, normalized_shape):
+        super().__init__()
+        if isinstance(normalized_shape, numbers.Integral):
+            normalized_shape = (normalized_shape,)
+        normalized_shape = torch.Size(normalized_shape)
+        assert len(normalized_shape) == 1
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.normalized_shape = normalized_shape
+
+    def forward(self, x, scale=None, shift=None):
+        return ops.rownorm(x, self.weight, None, scale, shift, 1e-5, True)
+
+
+class RMSNorm(nn.Module):
+    """Stands in for mamba_ssm.ops.triton.layer_norm.RMSNorm (bound at ADNMUNet.py:278 of the reference):
+    x * rsqrt(mean(x^2) + eps) * weight; `scale`/`shift` fuse Block's scalar affine (ADNMUNet.py:149,155)."""
+
+    def __init__(self, hidden_size, eps=1e-5, **kwargs):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.register_parameter("bias", None)
+
+    def forward(self, x, scale=None, shift=None):
+        return ops.rownorm(x, self.weight, None, scale, shift, self.eps, False)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, out_features=None, hidden_features=None, act_func=nn.GELU, drop=0., bias=True):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features * 2
+        self.fc1 = nn.Linear(in_features, hidden_features, bias=bias)
+        self.act1 = act_func()
+        self.fc2 = nn.Linear(hidden_features, out_features, bias=bias)
+        self.drop = nn.Dropout(drop)
+        self.act2 = act_func()
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act1(self.fc1(x)))))
+
+
+class Swish(nn.Module):
+    def __init__(self, beta_init=1.0):
+        super().__init__()
+        self.beta = nn.Parameter(torch.tensor(beta_init, dtype=torch.float))
+
+    def forward(self, x):
+        return x * torch.sigmoid(self.beta * x)
+
+
+def _act_code(act):
+    if act is None:
+        return lib.ACT_NONE
+    if isinstance(act, nn.GELU):
+        return lib.ACT_GELU
+    if isinstance(act, nn.SiLU):
+        return lib.ACT_SILU
+    return None
+
+
+class Conv2dLayer(nn.Module):
+    """conv -> [scale*norm+shift] -> [act] (model_untils.py:73-93 of the reference)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1),
+                 dilation=(1, 1), groups=1, bias=True, dropout=0, norm=None, act_func=None):
+        super().__init__()
+        self.dropout = nn.Dropout2d(dropout) if dropout > 0 else None
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        self.norm = norm
+        self.act = act_func() if act_func else None
+        if norm:
+            self.scale = nn.Parameter(torch.tensor(1.))
+            self.shift = nn.Parameter(torch.tensor(0.))
+
+    def _is_depthwise_same(self):
+        c = self.conv
+        k = c.kernel_size
+        return (c.groups == c.in_channels == c.out_channels and k[0] == k[1] and k[0] in (3, 5) and c.stride == (1, 1)
+                and c.dilation == (1, 1) and c.padding in ((k[0] // 2, k[0] // 2), 'same') and c.in_channels % 4 == 0)
+
+    def _is_pointwise(self):
+        c = self.conv
+        return c.kernel_size == (1, 1) and c.groups == 1 and c.stride == (1, 1) and c.padding in ((0, 0), 'same', 'valid')
+
+    def forward_tokens(self, x, h, w):
+        """(B, H*W, Cin) -> (B, H*W, Cout) (stride-1 'same' convs only)."""
+        if self.dropout:
+            x = tokens_of(self.dropout(nchw_view(x, h, w)))
+        code = _act_code(self.act)
+        fused_act = False
+        if self._is_depthwise_same() and not self.norm and code is not None:
+            x = ops.dwconv(x, self.conv.weight, self.conv.bias, h, w, code)  # HIP stencil, act fused
+            fused_act = True
+        elif self._is_depthwise_same():
+            x = ops.dwconv(x, self.conv.weight, self.conv.bias, h, w, lib.ACT_NONE)
+        elif self._is_pointwise():
+            x = F.linear(x, self.conv.weight.reshape(self.conv.out_channels, -1), self.conv.bias)
+        else:
+            x = tokens_of(self.conv(nchw_view(x, h, w)))
+        if self.norm:
+            x, fused_act = self._norm_tokens(x, h, w, code)
+        if self.act and not fused_act:
+            x = self.act(x)
+        return x
+
+    def _norm_tokens(self, x, h, w, code):
+        n = self.norm
+        if isinstance(n, nn.InstanceNorm2d) and not n.affine and not n.track_running_stats and x.shape[-1] % 4 == 0:
+            fuse = code in (lib.ACT_NONE, lib.ACT_GELU)
+            return ops.instnorm(x, self.scale, self.shift, n.eps, code if fuse else lib.ACT_NONE), fuse
+        return self.scale * tokens_of(n(nchw_view(x, h, w))) + self.shift, False
+
+    def _keeps_shape(self):
+        c = self.conv
+        if c.stride != (1, 1):
+            return False
+        if isinstance(c.padding, str):
+            return c.padding == 'same'
+        return all(2 * p == d * (k - 1) for p, d, k in zip(c.padding, c.dilation, c.kernel_size))
+
+    def forward(self, x):
+        if not self._keeps_shape():  # shape-changing conv: generic library path, NCHW as the reference
+            if self.dropout:
+                x = self.dropout(x)
+            x = self.conv(x)
+            if self.norm:
+                x = self.scale * self.norm(x) + self.shift
+            return self.act(x) if self.act else x
+        b, c, h, w = x.shape
+        return nchw_view(self.forward_tokens(tokens_of(x), h, w), h, w)
+
+
+class WTConvLayer(nn.Module):
+    """WTConv2d -> [scale*norm+shift] -> [act] (model_untils.py:96-116 of the reference)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, wt_levels=2, bias=True,
+                 dropout=0, norm=None, act_func=None):
+        super().__init__()
+        self.dropout = nn.Dropout2d(dropout) if dropout > 0 else None
+        self.conv = WTConv2d(in_channels, out_channels, kernel_size, stride, bias, wt_levels=wt_levels)
+        self.norm = norm
+        self.act = act_func() if act_func else None
+        if norm:
+            self.scale = nn.Parameter(torch.tensor(1.))
+            self.shift = nn.Parameter(torch.tensor(0.))
+
+    def forward_tokens(self, x, h, w):
+        if self.dropout:
+            x = tokens_of(self.dropout(nchw_view(x, h, w)))
+        x = self.conv.forward_tokens(x, h, w)
+        code = _act_code(self.act)
+        fused = False
+        if self.norm:
+            n = self.norm
+            if isinstance(n, nn.InstanceNorm2d) and not n.affine and x.shape[-1] % 4 == 0 and code in (lib.ACT_NONE, lib.ACT_GELU):
+                x = ops.instnorm(x, self.scale, self.shift, n.eps, code)  # IN + scalar affine + GELU in one pass
+                fused = True
+            else:
+                x = self.scale * tokens_of(n(nchw_view(x, h, w))) + self.shift
+        if self.act and not fused:
+            x = self.act(x)
+        return x
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        y = nchw_view(self.forward_tokens(tokens_of(x), h, w), h, w)
+        if self.conv.stride > 1:
+            y = y[:, :, ::self.conv.stride, ::self.conv.stride]
+        return y
+
+
+class DeConv2dLayer(nn.Module):
+    def __init__(self, in_channels, out_channels, ratio=4, kernel_size=(3, 3), groups=1,
+                 bias=True, dropout=0, norm=None, act_func=None):
+        super().__init__()
+        padding_w = max(0, (kernel_size[1] - ratio + 1) // 2)
+        output_padding_w = ratio - kernel_size[1] + 2 * padding_w
+        if not (0 <= output_padding_w < ratio):
+            raise ValueError(f"output_padding {output_padding_w} must satisfy 0 <= output_padding < {ratio}")
+        self.dropout = nn.Dropout3d(dropout, inplace=False) if dropout > 0 else None
+        self.trans_conv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size, stride=(ratio, ratio),
+                                             padding=(padding_w, padding_w),
+                                             output_padding=(output_padding_w, output_padding_w), groups=groups, bias=bias)
+        self.norm = norm if norm else None
+        self.act = act_func() if act_func else None
+        if norm:
+            self.scale = nn.Parameter(torch.tensor(1.))
+            self.shift = nn.Parameter(torch.tensor(0.))
+
+    def forward(self, x):
+        if self.dropout is not None:
+            x = self.dropout(x)
+        x = self.trans_conv(x)
+        if self.norm:
+            x = self.scale * self.norm(x) + self.shift
+        if self.act:
+            x = self.act(x)
+        return x
+
+
+class FeedForward(nn.Module):
+    """Gated conv FFN (model_untils.py:172-197 of the reference): 1x1 d->4d, depthwise 3x3,
+    gelu(x1)*sigmoid(x2), 1x1 2d->d.  Token path: GEMM, HIP stencil, HIP gate, GEMM."""
+
+    def __init__(self, dim, ffn_expansion_factor=2, bias=True):
+        super().__init__()
+        hidden = int(dim * ffn_expansion_factor)
+        self.project_in = Conv2dLayer(dim, hidden * 2, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0), bias=bias)
+        self.dwconv = Conv2dLayer(hidden * 2, hidden * 2, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1),
+                                  groups=hidden * 2, bias=bias)
+        self.project_out = Conv2dLayer(hidden, dim, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0), bias=bias)
+
+    def forward_tokens(self, x, h, w):
+        x = self.project_in.forward_tokens(x, h, w)
+        x = self.dwconv.forward_tokens(x, h, w)
+        x = ops.gate(x) if x.shape[-1] % 8 == 0 else F.gelu(x[..., :x.shape[-1] // 2]) * torch.sigmoid(x[..., x.shape[-1] // 2:])
+        return self.project_out.forward_tokens(x, h, w)
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        return nchw_view(self.forward_tokens(tokens_of(x), h, w), h, w)
+
+
+class ConvFFD(nn.Module):
+    def __init__(self, dim, bias=True):
+        super().__init__()
+        self.in_proj = nn.Linear(dim, dim * 2, bias=bias)
+        self.dw_conv = Conv2dLayer(dim * 2, dim * 2, kernel_size=3, stride=1, padding=1, bias=bias, groups=dim * 2)
+        self.out_proj = nn.Linear(dim * 2, dim, bias=bias)
+        self.act = nn.GELU()
+
+    def forward(self, x):
+        b, l, d = x.shape
+        h, w = _hw(l)
+        x = self.in_proj(x)
+        c = self.dw_conv.conv
+        if x.shape[-1] % 4 == 0:
+            x = ops.dwconv(x, c.weight, c.bias, h, w, lib.ACT_GELU)  # conv + GELU (model_untils.py:219-220)
+        else:
+            x = self.act(self.dw_conv.forward_tokens(x, h, w))
+        return self.out_proj(x)
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=256, patch_size=2, in_channels=3, embed_dim=256, kernel=6, num_frames=5, target_frames=3,
+                 wt_levels=2, ls_init_value=1, act=nn.GELU, InstanceNorm=True):
+        super().__init__()
+        img_size = to_2tuple(img_size)
+        patch_size = to_2tuple(patch_size)
+        self.num_patches = (img_size[1] // patch_size[1]) * (img_size[0] // patch_size[0])
+        self.patches_resolution = [img_size[0] // patch_size[0], img_size[1] // patch_size[1]]
+        self.img_size, self.patch_size = img_size, patch_size
+        self.embed_dim, self.num_frames, self.target_frames = embed_dim, num_frames, target_frames
+        self.gamma = nn.Parameter(ls_init_value * torch.ones(embed_dim)) if ls_init_value is not None else None
+        self.conv1 = nn.Sequential(WTConvLayer(in_channels, in_channels, kernel_size=kernel, stride=1, bias=False,
+                                               wt_levels=wt_levels, act_func=nn.GELU))
+        self.conv2 = nn.Sequential(Conv2dLayer(in_channels, embed_dim, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1),
+                                               groups=1, bias=False, act_func=nn.GELU))
+        self.conv3 = nn.Sequential(WTConvLayer(embed_dim, embed_dim, kernel_size=kernel, stride=1, bias=False, wt_levels=wt_levels,
+                                               norm=nn.InstanceNorm2d(embed_dim) if InstanceNorm else nn.GroupNorm(4, embed_dim)))
+        self.alpha1 = nn.Parameter(torch.tensor(1, dtype=torch.float))
+        self.beta1 = nn.Parameter(torch.tensor(1, dtype=torch.float))
+        self.alpha2 = nn.Parameter(torch.tensor(1, dtype=torch.float))
+        self.beta2 = nn.Parameter(torch.tensor(1, dtype=torch.float))
+
+    def forward(self, x):
+        """x: (B, L, T_in) tokens -> ((B, L, embed_dim), last input frame (B, H, W)) (model_untils.py:299-314)."""
+        b, l, d = x.shape
+        h, w = _hw(l)
+        res = x[..., -1].reshape(b, h, w)
+        x = self.alpha1 * self.conv1[0].forward_tokens(x, h, w) + self.beta1 * x
+        shortcut = self.conv2[0].forward_tokens(x, h, w)
+        x = self.alpha2 * self.conv3[0].forward_tokens(shortcut, h, w) + self.beta2 * shortcut
+        if self.gamma is not None:
+            x = x * self.gamma
+        return x, res
+
+
+class WTLayer(nn.Module):
+    def __init__(self, this_dim=128, next_dim=256, kernel=5, bias=True, wt_levels=2, ls_init_value=1, act=nn.GELU,
+                 if_res=False, InstanceNorm=True):
+        super().__init__()
+        self.next_dim = next_dim
+        norm_group = 8 if if_res else 4
+        self.wtconv = WTConvLayer(this_dim, this_dim, kernel_size=kernel, stride=1, bias=bias, wt_levels=wt_levels,
+                                  norm=nn.InstanceNorm2d(this_dim) if InstanceNorm else nn.GroupNorm(norm_group, this_dim))
+        self.conv = Conv2dLayer(this_dim, next_dim, kernel_size=3, padding=1, stride=1, bias=True, act_func=nn.GELU)
+        self.mlp = Mlp(this_dim)
+        self.gamma = nn.Parameter(ls_init_value * torch.ones(this_dim)) if ls_init_value is not None else None
+        self.alpha = nn.Parameter(torch.tensor(1, dtype=torch.float))
+        self.beta = nn.Parameter(torch.tensor(1, dtype=torch.float))
+        self.gama1 = nn.Parameter(torch.tensor(1, dtype=torch.float))
+        self.gama2 = nn.Parameter(torch.tensor(1, dtype=torch.float))
+        self.gama3 = nn.Parameter(torch.tensor(1, dtype=torch.float))
+        self.gama4 = nn.Parameter(torch.tensor(1, dtype=torch.float))
+
+    def forward(self, x, residual=None, features=None):
+        """(model_untils.py:402-426 of the reference).  With a residual the reference builds the feature
+        concat and discards it (:408), so `features` does not enter the result on that branch."""
+        if residual is not None:
+            x = torch.cat((self.gama1 * x, self.gama2 * residual), dim=-1)
+        elif features is not None:
+            x = x + self.gama3 * features
+        b, l, d = x.shape
+        h, w = _hw(l)
+        x = self.alpha * self.wtconv.forward_tokens(x, h, w) + self.beta * x
+        x = self.mlp(x)
+        if self.gamma is not None:
+            x = x * self.gamma
+        return self.conv.forward_tokens(x, h, w)
+
+
+class DownSample(nn.Module):
+    def __init__(self, dim=256, kernel=3, ratio=2):
+        super().__init__()
+        self.ratio = ratio
+        self.dim = dim
+        self.max_pool = nn.MaxPool2d(kernel_size=ratio, stride=ratio, padding=0)
+
+    def forward(self, x):
+        b, l, d = x.shape
+        h, w = _hw(l)
+        return tokens_of(self.max_pool(nchw_view(x, h, w)))
+
+
+class UpSample(nn.Module):
+    def __init__(self, dim=128, kernel=3, ratio=2, bias=True):
+        super().__init__()
+        self.ratio = ratio
+        self.trans_conv = DeConv2dLayer(dim, dim, ratio=ratio, kernel_size=(kernel, kernel), bias=bias, act_func=None)
+
+    def forward(self, x):
+        b, l, d = x.shape
+        h, w = _hw(l)
+        return tokens_of(self.trans_conv(nchw_view(x, h, w)))
+
+
+class IntensityGate(nn.Module):
+    def __init__(self, threshold=0.):
+        super().__init__()
+        self.threshold = nn.Parameter(torch.tensor(threshold, dtype=torch.float))
+        self.enhance = nn.Parameter(torch.tensor(1, dtype=torch.float))
+        self.act = nn.SiLU()
+
+    def forward(self, x):
+        return self.act(self.enhance * (x - self.threshold))
+
+
+class Channel_Att_Bridge(nn.Module):
+    """Channel-attention bridge over the 7 encoder skips (model_untils.py:535-616 of the reference):
+    GAP -> Conv1d(k=3) across the concatenated channels -> 7 Linear heads -> IntensityGate.
+    Returns (B, 1, C_i) gates; broadcasting replaces the reference's expand_as over L.  `live`
+    restricts the heads to the ones whose result is consumed (att5..7 feed e2ds[0..2]; att1..4 feed
+    only branches that Decoder.forward never reads, ADNMUNet.py:612-613)."""
+
+    def __init__(self, c_list=[8, 16, 32, 64, 128, 256], split_att='fc'):
+        super().__init__()
+        if split_att != 'fc':
+            raise NotImplementedError("only split_att='fc' (the reference default) is implemented")
+        c_list_sum = sum(c_list)
+        self.split_att = split_att
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.get_all_att = nn.Conv1d(1, 1, kernel_size=3, padding=1, bias=True)
+        for i in range(7):
+            setattr(self, f"att{i + 1}", nn.Linear(c_list_sum, c_list[i]))
+        self.sigmoid1 = IntensityGate()
+
+    def forward(self, t, live=None):
+        att = torch.cat([t[i].mean(1) for i in range(len(t))], dim=-1).unsqueeze(1)  # (B,1,sum C)
+        att = self.get_all_att(att)
+        out = {}
+        for i in range(7):
+            if live is not None and i not in live:
+                continue
+            out[i] = self.sigmoid1(getattr(self, f"att{i + 1}")(att))
+        return out
+
+
+class EncoderToDecoder(nn.Module):
+    """Skip-connection gating block (model_untils.py:620-794 of the reference).  Pools / grouped convs
+    run through the library on channels-last views; norm, FFN and ConvFFD use the HIP token kernels."""
+
+    def __init__(self, embed_dim=256, InstanceNorm=True):
+        super().__init__()
+        g = embed_dim // 4
+        mk = lambda k, p: Conv2dLayer(embed_dim, embed_dim, kernel_size=k, stride=(1, 1), padding=p, bias=True, groups=g, act_func=nn.GELU)
+        pw = lambda: Conv2dLayer(embed_dim, embed_dim, kernel_size=1, stride=1, padding=0, groups=embed_dim, bias=True)
+        self.conv13pool = mk((1, 3), (0, 1))
+        self.ffd13 = pw()
+        self.act_func13 = IntensityGate()
+        self.conv31pool = mk((3, 1), (1, 0))
+        self.ffd31 = pw()
+        self.act_func31 = IntensityGate()
+        self.conv33pool = mk((3, 3), (1, 1))
+        self.ffd33 = pw()
+        self.act_func33 = IntensityGate()
+        self.max_pool_13 = nn.MaxPool2d((1, 3), (1, 1), (0, 1))
+        self.avg_pool_13 = nn.AvgPool2d((1, 3), (1, 1), (0, 1))
+        self.max_pool_31 = nn.MaxPool2d((3, 1), (1, 1), (1, 0))
+        self.avg_pool_31 = nn.AvgPool2d((3, 1), (1, 1), (1, 0))
+        self.max_pool_33 = nn.MaxPool2d((3, 3), (1, 1), (1, 1))
+        self.avg_pool_33 = nn.AvgPool2d((3, 3), (1, 1), (1, 1))
+        self.conv33 = mk((3, 3), (1, 1))
+        self.ffd = FeedForward(dim=embed_dim, bias=True)
+        self.act = IntensityGate()
+        self.norm = nn.InstanceNorm2d(embed_dim) if InstanceNorm else nn.GroupNorm(4, embed_dim)
+        self.alpha1 = nn.Parameter(torch.tensor(0.33, dtype=torch.float))
+        self.alpha2 = nn.Parameter(torch.tensor(0.33, dtype=torch.float))
+        self.alpha3 = nn.Parameter(torch.tensor(0.33, dtype=torch.float))
+        self.gama = nn.Parameter(torch.tensor(1, dtype=torch.float))
+        self.gamma = nn.Parameter(1 * torch.ones(embed_dim))
+        self.mlp = ConvFFD(embed_dim, bias=True)
+        self.scale = nn.Parameter(torch.tensor(1.))
+        self.shift = nn.Parameter(torch.tensor(0.))
+
+    def _avg_pools(self, x, h, w):
+        """AvgPool2d(k, stride 1, zero pad, count_include_pad=True) (model_untils.py:696-725) is a depthwise
+        conv with constant taps 1/|k|: runs on the HIP stencil, on tokens.  (torch-ROCm 2.10's avg_pool2d
+        backward is also wrong for channels-last views — measured rel. error 1.2-1.6 — one more reason.)"""
+        d = x.shape[-1]
+        if d % 4:
+            xi = nchw_view(x, h, w).contiguous()
+            return self.avg_pool_31(xi), self.avg_pool_13(xi), self.avg_pool_33(xi)
+        taps = x.new_zeros((3, d, 1, 3, 3))
+        taps[0, :, 0, :, 1] = 1.0 / 3.0   # (3,1): a column
+        taps[1, :, 0, 1, :] = 1.0 / 3.0   # (1,3): a row
+        taps[2] = 1.0 / 9.0
+        return tuple(nchw_view(ops.dwconv(x, taps[i], None, h, w, lib.ACT_NONE), h, w) for i in range(3))
+
+    @staticmethod
+    def _pw(layer, x):
+        """ffd13/ffd33: a 1x1 conv with groups == channels is a per-channel scale + bias."""
+        return x * layer.conv.weight.reshape(-1) + layer.conv.bias
+
+    def forward(self, x, res):
+        """x: (B, L, d) skip; res: the bridge gate, (B, 1, d) or (B, L, d)."""
+        b, l, d = x.shape
+        h, w = _hw(l)
+        x = self.act(x + self.gama * res)
+        if isinstance(self.norm, nn.InstanceNorm2d) and d % 4 == 0:
+            x = ops.instnorm(x, self.scale, self.shift, self.norm.eps, lib.ACT_NONE)
+        else:
+            x = self.scale * tokens_of(self.norm(nchw_view(x, h, w))) + self.shift
+        xi = nchw_view(x, h, w)
+        a31, a13, a33 = self._avg_pools(x, h, w)
+        # the reference applies ffd13/act_func13 to both the 1x3 and the 3x1 branch (:770-777)
+        x1 = self.act_func13(self._pw(self.ffd13, x * tokens_of(self.conv13pool.act(self.conv13pool.conv(self.max_pool_31(xi) + a31)))))
+        x2 = self.act_func13(self._pw(self.ffd13, x * tokens_of(self.conv31pool.act(self.conv31pool.conv(self.max_pool_13(xi) + a13)))))
+        x3 = self.act_func33(self._pw(self.ffd33, x * tokens_of(self.conv33pool.act(self.conv33pool.conv(self.max_pool_33(xi) + a33)))))
+        xp = (self.alpha1 * x1 + self.alpha2 * x2 + self.alpha3 * x3) * self.gamma
+        return self.mlp(self.ffd.forward_tokens(xp, h, w))
+
+
+class OutProj(nn.Module):
+    def __init__(self, num_frames=3, embed_dim=256, img_size=[256, 256], act_func=Swish, wt_levels=2, ls_init_value=1,
+                 out_expand=2, InstanceNorm=True):
+        super().__init__()
+        self.img_size = img_size
+        self.embed_dim = embed_dim
+        self.activation = act_func
+        self.wtconv = WTConvLayer(embed_dim, embed_dim, kernel_size=5, stride=1, bias=False, wt_levels=3, act_func=nn.GELU,
+                                  norm=nn.InstanceNorm2d(embed_dim) if InstanceNorm else nn.GroupNorm(4, embed_dim))
+        self.conv = nn.Sequential(
+            Conv2dLayer(embed_dim, embed_dim * out_expand, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1), bias=False, act_func=nn.GELU),
+            Conv2dLayer(embed_dim * out_expand, num_frames, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0), bias=False, act_func=nn.GELU))
+        self.conv2 = Conv2dLayer(num_frames, num_frames, kernel_size=3, stride=1, bias=False, act_func=self.activation)
+        self.alpha1 = nn.Parameter(torch.tensor(1., dtype=torch.float))
+        self.alpha2 = nn.Parameter(torch.tensor(1., dtype=torch.float))
+        self.gamma = nn.Parameter(ls_init_value * torch.ones(embed_dim)) if ls_init_value is not None else None
+        self.alpha = nn.Parameter(torch.tensor(1., dtype=torch.float))
+        self.beta = nn.Parameter(torch.tensor(1., dtype=torch.float))
+
+    def forward(self, x, residual):
+        """x: (B, L, d) tokens, residual: last input frame (B, H, W) -> (B, T_out, H, W) (model_untils.py:871-892)."""
+        h, w = self.img_size[0], self.img_size[1]
+        b, l, d = x.shape
+        x = self.alpha * self.wtconv.forward_tokens(x, h, w) + self.beta * x
+        if self.gamma is not None:
+            x = x * self.gamma
+        x = self.conv[0].forward_tokens(x, h, w)
+        x = self.conv[1].forward_tokens(x, h, w)
+        if residual is not None:
+            x = self.alpha1 * x + self.alpha2 * residual.reshape(b, l, 1)
+        x = self.conv2.forward_tokens(x, h, w)
+        return nchw_view(x, h, w)

@@ -39,6 +39,13 @@ enum { ADNM_OK = 0, ADNM_EINVAL = -1, ADNM_ELAUNCH = -2, ADNM_EWORKSPACE = -3 };
 const char* adnm_last_error(void);
 int adnm_abi_version(void);
 
+/* Opt-in measurement aid (off by default): when enabled every kernel launch of the library is bracketed by
+ * hipEventRecord on its own stream.  adnm_prof_collect synchronises those events and writes one line per kernel
+ * name "name\tlaunches\ttotal_ms\talgorithmic_bytes\n" into buf (returns the full length).  bench.py uses it
+ * for the roofline figures; nothing else calls it. */
+int adnm_prof_enable(int on);
+int64_t adnm_prof_collect(char* buf, int64_t buflen);
+
 /* ---------------------------------------------------------------- row norms (K2, K7)
  * y = scale * ( xhat * w + b ) + shift,  xhat = (x - mu) * rstd
  *   RMSNorm   (mamba_ssm RMSNorm bound at ADNMUNet.py:278, used ADNMUNet.py:149,155): subtract_mean=0, b=NULL
@@ -95,7 +102,8 @@ int adnm_dwconv_fwd(const void* x, int64_t ldx, const float* wgt, const float* b
                     int64_t ldadd, void* y, int64_t ldy, int64_t B, int64_t H, int64_t W, int64_t C, int KH,
                     int KW, int act, int dtype, adnm_stream_t stream);
 /* dpre:(B,H,W,C) contiguous scratch in activation dtype (ignored when act==NONE).
- * dwgt:(KH,KW,C) tap-major, dbias:(C) or NULL: OVERWRITTEN. */
+ * dwgt:(KH,KW,C) tap-major, dbias:(C) or NULL: OVERWRITTEN.  dwgt == NULL skips the weight-gradient pass
+ * (constant taps, e.g. the average pools of EncoderToDecoder expressed as a depthwise conv). */
 int64_t adnm_dwconv_bwd_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t C, int KH, int KW);
 int adnm_dwconv_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* wgt,
                     const float* bias, void* dpre, void* dx, int64_t lddx, float* dwgt, float* dbias, void* ws,

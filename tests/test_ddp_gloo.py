@@ -1,0 +1,79 @@
+"""N>1 path on CPU: 2 gloo ranks, the gradient bucketer (adnm_hip.ddp.GradBuckets) must reproduce the
+average of the per-rank gradients, leave never-used parameters with grad=None, survive
+optimizer.zero_grad(set_to_none=True) between steps, and keep replicas bit-identical after AdamW steps."""
+import os
+import socket
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+class Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.a = nn.Linear(8, 16)
+        self.dead = nn.Linear(16, 16)   # never used in forward: must keep grad None (like e2ds[3..6])
+        self.b = nn.Linear(16, 4)
+        self.s = nn.Parameter(torch.tensor(1.0))
+
+    def forward(self, x):
+        return self.b(torch.tanh(self.a(x))) * self.s
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adnm-unet_amd"))
+    from adnm_hip.ddp import GradBuckets
+    model = Toy()
+    buckets = GradBuckets(model, bucket_mb=0.0005)  # force several buckets
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, eps=1e-9, weight_decay=1e-2)
+    torch.manual_seed(100 + rank)
+    out = {}
+    for step in range(3):
+        x = torch.randn(5, 8)
+        loss = model(x).pow(2).mean()
+        loss.backward()
+        local = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        buckets.finalize()
+        if step == 0:
+            out["local"], out["avg"] = local, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+            out["dead_none"] = model.dead.weight.grad is None
+            out["nbuckets"] = len(buckets.buckets)
+        opt.step()
+        if step == 1:
+            opt.zero_grad(set_to_none=True)   # train.py's call: drops the flat views, hooks must re-attach
+        else:
+            buckets.zero_grad()
+    out["final"] = {k: p.detach().clone() for k, p in model.named_parameters()}
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = res[0], res[1]
+    assert a["dead_none"] and b["dead_none"]
+    assert a["nbuckets"] > 1
+    for k in a["local"]:
+        expect = (a["local"][k] + b["local"][k]) / 2
+        assert torch.allclose(a["avg"][k], expect, atol=1e-7), k
+        assert torch.equal(a["avg"][k], b["avg"][k]), k
+    for k in a["final"]:
+        assert torch.equal(a["final"][k], b["final"][k]), f"replicas diverged at {k}"
