@@ -50,6 +50,9 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python adnm-unet_amd/build.py` (or __graft_entry__.build()). "
             "There is no PyTorch/CPU fallback for the HIP kernels.")
+    # torch ships its own libamdhip64; import it FIRST so libadnm_hip.so binds to the same HIP runtime (and
+    # therefore the same device context and streams) instead of pulling a second copy from /opt/rocm/lib.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (ret, types) in parse_header().items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -484,3 +484,69 @@ class ADNMixerFn(torch.autograd.Function):
 
 def adn_mixer(u, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N):
     return ADNMixerFn.apply(u, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N)
+
+
+class LinCombFn(torch.autograd.Function):
+    """y = gamma * (s0*x0 + s1*x1 + s2*x2): scalars are 1-element parameters, gamma a per-channel vector."""
+
+    @staticmethod
+    def forward(ctx, gamma, *args):
+        n = len(args) // 2
+        xs, ss = args[:n], args[n:]
+        shp = xs[0].shape
+        C = shp[-1]
+        x2 = []
+        for x in xs:
+            t = x.reshape(-1, C)
+            x2.append(t if t.stride(-1) == 1 else t.contiguous())
+        M = x2[0].shape[0]
+        y = torch.empty((M, C), dtype=xs[0].dtype, device=xs[0].device)
+        ptr = [(None, 0)] * 3
+        for i, t in enumerate(x2):
+            ptr[i] = _rows(t)
+        sp = [_p(s) for s in ss] + [None] * (3 - n)
+        _need_gpu(x2[0])
+        lib.call("adnm_lincomb_fwd", ptr[0][0], ptr[0][1], ptr[1][0], ptr[1][1], ptr[2][0], ptr[2][1], sp[0], sp[1], sp[2], _p(gamma),
+                 y.data_ptr(), C, M, C, _dt(y), _stream())
+        ctx.save_for_backward(gamma, *x2, *[s for s in ss if s is not None])
+        ctx.meta = (n, shp, [s is not None for s in ss])
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, shp, has_s = ctx.meta
+        saved = ctx.saved_tensors
+        gamma, x2 = saved[0], saved[1:1 + n]
+        it = iter(saved[1 + n:])
+        ss = [next(it) if h else None for h in has_s]
+        C = shp[-1]
+        M = x2[0].shape[0]
+        dev = x2[0].device
+        g = dy.reshape(M, C)
+        g = g if g.stride(-1) == 1 else g.contiguous()
+        need_x = ctx.needs_input_grad[1:1 + n]
+        dxs = [torch.empty((M, C), dtype=x2[0].dtype, device=dev) if need_x[i] else None for i in range(n)]
+        dss = [torch.empty_like(ss[i]) if ss[i] is not None else None for i in range(n)]
+        dgamma = torch.empty_like(gamma) if gamma is not None else None
+        nb = lib.query("adnm_lincomb_bwd_ws_bytes", M, C)
+        ws = _ws(nb, dev)
+        xp = [_rows(t) for t in x2] + [(None, 0)] * (3 - n)
+        dxp = [(_p(t), C) for t in dxs] + [(None, 0)] * (3 - n)
+        sp = [_p(s) for s in ss] + [None] * (3 - n)
+        dsp = [_p(s) for s in dss] + [None] * (3 - n)
+        pg, ldg = _rows(g)
+        lib.call("adnm_lincomb_bwd", pg, ldg, xp[0][0], xp[0][1], xp[1][0], xp[1][1], xp[2][0], xp[2][1], sp[0], sp[1], sp[2], _p(gamma),
+                 dxp[0][0], dxp[0][1], dxp[1][0], dxp[1][1], dxp[2][0], dxp[2][1], dsp[0], dsp[1], dsp[2], _p(dgamma), ws.data_ptr(), nb,
+                 M, C, _dt(g), _stream())
+        return (dgamma, *[d.view(shp) if d is not None else None for d in dxs], *dss)
+
+
+def lincomb(xs, scalars, gamma=None):
+    """xs: 1-3 same-shape token tensors; scalars: matching list of 1-element parameters (or None = 1)."""
+    C = xs[0].shape[-1]
+    if C % 4 or C > 2048 or any(s is not None and s.numel() != 1 for s in scalars):
+        y = 0
+        for x, s in zip(xs, scalars):
+            y = y + (x if s is None else s * x)
+        return y if gamma is None else y * gamma
+    return LinCombFn.apply(gamma, *xs, *scalars)

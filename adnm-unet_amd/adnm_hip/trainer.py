@@ -1,0 +1,148 @@
+"""The training step around the hot path, MI355X-style:
+
+    [hipGraph replay]  forward -> loss -> backward -> gather gradients into ONE flat fp32 buffer
+    [RCCL]             all-reduce(AVG) of that flat buffer over xGMI            (world > 1 only)
+    [3 HIP launches]   global grad-norm, clip_grad_norm_ scaling, AdamW on flat p / g / m / v
+
+replacing the reference's nn.DataParallel scatter/replicate/gather (train.py:99-102), its per-tensor
+clip_grad_norm_ (train.py:140) and torch.optim.AdamW over 669 tensors (train_untils.py:35-42).
+
+  * Parameters that receive gradients are re-homed as views into one flat buffer (state_dict unchanged), so the
+    optimiser is a single streaming kernel and the gradient collective is ONE large message — the right shape for
+    xGMI rings (few, large transfers).  The 307 parameters the reference never gives a gradient (e2ds[3..6], att1..4,
+    ...) are discovered by a dry-run backward and left out: they are never decayed nor updated, exactly like
+    torch.optim.AdamW skipping p.grad is None.
+  * The whole fwd+bwd is captured once as a hipGraph (our kernels are enqueued through ctypes on torch's capture
+    stream; all memory comes from torch's graph-private pool) and replayed: the ~3.5k launches of a step no longer
+    cost host time.  The collective and the optimiser stay outside the graph, so learning-rate schedules and the
+    adaptive clip threshold of train.py:122-130 remain ordinary host-side floats.
+"""
+import torch
+import torch.distributed as dist
+
+from . import lib
+
+
+class FlatTrainer:
+    def __init__(self, model, loss_fn, lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2, max_norm=0.0,
+                 process_group=None, use_graph=True, fused=True):
+        self.model, self.loss_fn = model, loss_fn
+        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.use_graph, self.fused = use_graph, fused
+        self.used = None
+        self.graph = None
+        self._steps = 0
+
+    # ------------------------------------------------------------------ one-time setup
+    def _fwd_bwd(self, x, tgt):
+        out = self.model(x)
+        loss = self.loss_fn(out, tgt)
+        loss.backward()
+        return loss
+
+    @torch.no_grad()
+    def _flatten(self):
+        used = [p for p in self.model.parameters() if p.requires_grad and p.grad is not None]
+        dev, dt = used[0].device, used[0].dtype
+        offs, total = [], 0
+        for p in used:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4  # keep every tensor 16-byte aligned inside the flat buffers
+        self.flat_p = torch.zeros(total, dtype=dt, device=dev)
+        self.flat_g = torch.zeros(total, dtype=dt, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=dt, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=dt, device=dev)
+        self.state = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.g_views = []
+        for p, o in zip(used, offs):
+            view = self.flat_p[o:o + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            self.g_views.append(self.flat_g[o:o + p.numel()].view_as(p))
+            p.grad = None
+        self.used, self.n = used, total
+        if self.fused:
+            self.ws = torch.empty(int(lib.query("adnm_adamw_ws_bytes")), dtype=torch.uint8, device=dev)
+
+    def _gather(self):
+        torch._foreach_copy_(self.g_views, [p.grad for p in self.used])
+
+    def prepare(self, x, tgt):
+        """Dry-run backward (finds the parameters that receive gradients), flatten, and capture the graph."""
+        self.model.zero_grad(set_to_none=True)
+        self._fwd_bwd(x, tgt)
+        self._flatten()
+        if not self.use_graph:
+            return
+        self.sx, self.st = x.clone(), tgt.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                for p in self.used:
+                    p.grad = None
+                self._fwd_bwd(self.sx, self.st)
+                self._gather()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for p in self.used:
+            p.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_loss = self._fwd_bwd(self.sx, self.st)
+            self._gather()
+
+    # ------------------------------------------------------------------ per step
+    def step(self, x, tgt):
+        if self.used is None:
+            self.prepare(x, tgt)
+        if self.graph is not None:
+            if x.data_ptr() != self.sx.data_ptr():
+                self.sx.copy_(x, non_blocking=True)
+                self.st.copy_(tgt, non_blocking=True)
+            self.graph.replay()
+            loss = self.static_loss
+        else:
+            loss = self._fwd_bwd(x, tgt)
+            self._gather()
+            for p in self.used:
+                p.grad = None
+        if self.world > 1:
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_reduce(self.flat_g, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+                self.flat_g.div_(self.world)
+        self._optimizer_step()
+        self._steps += 1
+        return loss
+
+    def _optimizer_step(self):
+        if self.fused:
+            lib.call("adnm_adamw_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+                     self.exp_avg_sq.data_ptr(), self.n, self.state.data_ptr(), float(self.lr), float(self.betas[0]), float(self.betas[1]),
+                     float(self.eps), float(self.wd), float(self.max_norm), self.ws.data_ptr(), self.ws.numel(),
+                     torch.cuda.current_stream().cuda_stream)
+        else:
+            self._torch_adamw_for_tests()
+
+    @torch.no_grad()
+    def _torch_adamw_for_tests(self):
+        """Same arithmetic in torch ops — exists only so the CPU (gloo) tests can exercise the N>1 logic and the
+        GPU test has an independent statement of the fused kernel's update rule.  bench.py never takes it."""
+        g = self.flat_g
+        if self.max_norm > 0:
+            g = g * torch.clamp(self.max_norm / (g.norm() + 1e-6), max=1.0)
+        step = self._steps + 1
+        b1, b2 = self.betas
+        self.flat_p.mul_(1 - self.lr * self.wd)
+        self.exp_avg.lerp_(g, 1 - b1)
+        self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (self.exp_avg_sq.sqrt() / (1 - b2 ** step) ** 0.5).add_(self.eps)
+        self.flat_p.addcdiv_(self.exp_avg, denom, value=-self.lr / (1 - b1 ** step))
+
+    def grad_norm(self):
+        """Pre-clip total gradient norm of the last step (device scalar; train.py:141 reads it with .item())."""
+        return self.state[1].sqrt() if self.fused else self.flat_g.norm()

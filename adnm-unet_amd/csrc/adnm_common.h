@@ -22,6 +22,15 @@ struct AdnmProfScope {
 };
 #define ADNM_PROF(name, st, bytes) AdnmProfScope adnm_prof_scope__(name, st, (double)(bytes))
 
+// out[c] = sum_{r<rows} part[r*n + c], c in [0,n), scattered to up to 4 contiguous output segments
+// (segment k holds columns [off_k, off_k+len_k); a NULL pointer skips it).  Deterministic tree order.
+struct AdnmFoldSeg {
+  float* ptr;
+  int len;
+};
+void adnm_launch_fold(const char* prof_name, const float* part, int rows, int n, AdnmFoldSeg s0, AdnmFoldSeg s1, AdnmFoldSeg s2,
+                      AdnmFoldSeg s3, hipStream_t st);
+
 #define ADNM_REQUIRE(cond, ...)            \
   do {                                     \
     if (!(cond)) {                         \

@@ -85,3 +85,51 @@ extern "C" int64_t adnm_prof_collect(char* buf, int64_t buflen) {
   }
   return (int64_t)out.size();
 }
+
+// ---- shared cross-block fold of fp32 partial rows (second stage of every deterministic reduction in the library)
+namespace {
+constexpr int kFoldCols = 64, kFoldSlices = 16;
+struct FoldSegs {
+  float* ptr[4];
+  int end[4];
+};
+__global__ __launch_bounds__(kFoldCols* kFoldSlices) void fold_rows_kernel(const float* __restrict__ part, int rows, int n,
+                                                                           FoldSegs segs) {
+  __shared__ float sm[kFoldSlices][kFoldCols + 1];
+  const int cl = threadIdx.x & (kFoldCols - 1), sl = threadIdx.x / kFoldCols;
+  const int c = blockIdx.x * kFoldCols + cl;
+  float acc = 0.f;
+  if (c < n)
+    for (int r = sl; r < rows; r += kFoldSlices) acc += part[(int64_t)r * n + c];
+  sm[sl][cl] = acc;
+  __syncthreads();
+  if (sl == 0 && c < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < kFoldSlices; ++k) t += sm[k][cl];
+    int begin = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (c < segs.end[k]) {
+        if (segs.ptr[k]) segs.ptr[k][c - begin] = t;
+        break;
+      }
+      begin = segs.end[k];
+    }
+  }
+}
+}  // namespace
+
+void adnm_launch_fold(const char* prof_name, const float* part, int rows, int n, AdnmFoldSeg s0, AdnmFoldSeg s1, AdnmFoldSeg s2,
+                      AdnmFoldSeg s3, hipStream_t st) {
+  FoldSegs f;
+  const AdnmFoldSeg in[4] = {s0, s1, s2, s3};
+  int end = 0;
+  for (int k = 0; k < 4; ++k) {
+    end += in[k].len;
+    f.ptr[k] = in[k].ptr;
+    f.end[k] = end;
+  }
+  ADNM_PROF(prof_name, st, 4.0 * ((double)rows + 1) * n);
+  fold_rows_kernel<<<(unsigned)adnm_cdiv(n, kFoldCols), kFoldCols * kFoldSlices, 0, st>>>(part, rows, n, f);
+}

@@ -162,16 +162,6 @@ __global__ __launch_bounds__(kBlock) void dwconv_wgrad_kernel(const T* __restric
   }
 }
 
-__global__ void dwconv_wgrad_fold(const float* __restrict__ part, int rows, int NT, int C, float* __restrict__ dwgt,
-                                  float* __restrict__ dbias) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (NT + 1) * C) return;
-  float t = 0.f;
-  for (int r = 0; r < rows; ++r) t += part[(int64_t)r * (NT + 1) * C + i];
-  if (i < NT * C) dwgt[i] = t;
-  else if (dbias) dbias[i - NT * C] = t;
-}
-
 struct WGeo {
   int cgb, gx, npb, rows;
 };
@@ -184,7 +174,7 @@ WGeo wgeo(int64_t B, int64_t H, int64_t W, int64_t C) {
   const int slots = kBlock / g.cgb;
   const int64_t tiles = B * H * adnm_cdiv(W, TW);
   int64_t npb = adnm_cdiv(tiles, (int64_t)slots * 4);
-  const int64_t cap = (512 / g.gx) > 1 ? (512 / g.gx) : 1;
+  const int64_t cap = (256 / g.gx) > 1 ? (256 / g.gx) : 1;
   if (npb > cap) npb = cap;
   if (npb < 1) npb = 1;
   g.npb = (int)npb;
@@ -225,8 +215,7 @@ void launch_wgrad(const void* dpre, int64_t ldd, const void* x, int64_t ldx, flo
     { ADNM_PROF("dwconv_wgrad_k3", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 3><<<grid, kBlock, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb); }
   else
     { ADNM_PROF("dwconv_wgrad_k5", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 5><<<grid, kBlock, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb); }
-  const int n = (K * K + 1) * (int)C;
-  { ADNM_PROF("dwconv_wgrad_fold", st, 4.0 * (g.rows + 1) * n); dwconv_wgrad_fold<<<(unsigned)adnm_cdiv(n, 256), 256, 0, st>>>(part, g.rows, K * K, (int)C, dwgt, dbias); }
+  adnm_launch_fold("dwconv_wgrad_fold", part, g.rows, (K * K + 1) * (int)C, {dwgt, K * K * (int)C}, {dbias, (int)C}, {nullptr, 0}, {nullptr, 0}, st);
 }
 
 }  // namespace

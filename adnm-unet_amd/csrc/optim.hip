@@ -1,0 +1,93 @@
+// Fused step glue over FLAT fp32 buffers: global gradient norm, clip_grad_norm_ scaling
+// (train.py:140) and the AdamW update (train_untils.py:35-42: betas (0.9,0.999), eps 1e-9, decoupled weight decay)
+// in three launches instead of torch's ~100 multi-tensor launches over 669 tensors.  HBM-bound: 7 floats of
+// traffic per parameter (read p,g,m,v; write p,m,v) + one extra read of g for the norm.
+// The step counter and the bias corrections live on the device (state[0..3]) so the sequence is graph-replayable.
+#include "adnm_common.h"
+
+namespace {
+constexpr int kBlock = 256;
+constexpr int kNormBlocks = 1024;
+
+__global__ __launch_bounds__(kBlock) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
+  __shared__ float sm[kBlock / 64];
+  float acc = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float t = g[(n4 << 2) + threadIdx.x];
+    acc = fmaf(t, t, acc);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// state: [0] step, [1] sum of squares of the gradient, [2] 1 - beta1^step, [3] sqrt(1 - beta2^step)
+__global__ void optim_tick_kernel(float* __restrict__ state, float beta1, float beta2) {
+  const float step = state[0] + 1.0f;
+  state[0] = step;
+  state[2] = 1.0f - powf(beta1, step);
+  state[3] = sqrtf(1.0f - powf(beta2, step));
+}
+
+__global__ __launch_bounds__(kBlock) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, int64_t n, const float* __restrict__ state, float lr,
+                                                       float beta1, float beta2, float eps, float wd, float max_norm) {
+  float coef = 1.0f;
+  if (max_norm > 0.f) {  // torch.nn.utils.clip_grad_norm_: coef = clamp(max_norm / (norm + 1e-6), max=1)
+    coef = max_norm / (sqrtf(state[1]) + 1e-6f);
+    coef = coef > 1.0f ? 1.0f : coef;
+  }
+  const float bc1 = state[2], bc2s = state[3];
+  const float decay = 1.0f - lr * wd, step_size = lr / bc1;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    float* P = &pp.x;
+    const float* G = &gg.x;
+    float* M = &mm.x;
+    float* V = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = G[k] * coef;
+      P[k] *= decay;                                   // p.mul_(1 - lr*wd)
+      M[k] = M[k] + (1.0f - beta1) * (gk - M[k]);      // exp_avg.lerp_(g, 1-beta1)
+      V[k] = V[k] * beta2 + (1.0f - beta2) * gk * gk;  // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
+      const float denom = sqrtf(V[k]) / bc2s + eps;
+      P[k] -= step_size * (M[k] / denom);              // p.addcdiv_(exp_avg, denom, value=-lr/bc1)
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+}
+}  // namespace
+
+extern "C" int64_t adnm_adamw_ws_bytes(void) { return kNormBlocks * (int64_t)sizeof(float); }
+
+extern "C" int adnm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float* state, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, float max_norm, void* ws, int64_t ws_bytes, adnm_stream_t stream) {
+  ADNM_REQUIRE(p && g && m && v && state, "adamw_step: null pointer");
+  ADNM_REQUIRE(n > 0 && n % 4 == 0, "adamw_step: n=%lld must be a positive multiple of 4 (pad the flat buffers)", (long long)n);
+  if (!ws || ws_bytes < adnm_adamw_ws_bytes()) {
+    adnm_set_error("adamw_step: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_adamw_ws_bytes());
+    return ADNM_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)ws;
+  { ADNM_PROF("grad_sumsq", st, 4.0 * n); sumsq_partial_kernel<<<kNormBlocks, kBlock, 0, st>>>(g, n, part); }
+  adnm_launch_fold("grad_sumsq_fold", part, kNormBlocks, 1, {state + 1, 1}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
+  optim_tick_kernel<<<1, 1, 0, st>>>(state, beta1, beta2);
+  int64_t blocks = adnm_cdiv(n / 4, kBlock);
+  if (blocks > 4096) blocks = 4096;
+  { ADNM_PROF("adamw_update", st, 4.0 * n * 7); adamw_kernel<<<(unsigned)blocks, kBlock, 0, st>>>(p, g, m, v, n, state, lr, beta1, beta2, eps, weight_decay, max_norm); }
+  ADNM_CHECK_LAUNCH("adamw_step");
+  return ADNM_OK;
+}

@@ -176,25 +176,6 @@ __global__ __launch_bounds__(kBlock) void rownorm_bwd_kernel(
   }
 }
 
-__global__ void rownorm_bwd_finalize(const float* __restrict__ part, int nblk, int d, float* __restrict__ dw,
-                                     float* __restrict__ db, float* __restrict__ dscale,
-                                     float* __restrict__ dshift) {
-  const int stride = 2 * d + 2;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= stride) return;
-  float t = 0.f;
-  for (int k = 0; k < nblk; ++k) t += part[(int64_t)k * stride + c];
-  if (c < d) {
-    dw[c] = t;
-  } else if (c < 2 * d) {
-    if (db) db[c - d] = t;
-  } else if (c == 2 * d) {
-    if (dscale) *dscale = t;
-  } else {
-    if (dshift) *dshift = t;
-  }
-}
-
 int bwd_blocks(int64_t M, int64_t d) {
   const int lpr = lanes_per_row(d);
   int64_t nb = adnm_cdiv(M, kBlock / lpr);
@@ -242,8 +223,7 @@ int launch_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const f
 #undef BWD
   }
   ADNM_CHECK_LAUNCH("rownorm_bwd");
-  const int stride = (int)(2 * d + 2);
-  { ADNM_PROF("rownorm_bwd_finalize", st, 4.0 * (nblk + 1) * stride); rownorm_bwd_finalize<<<(unsigned)adnm_cdiv(stride, 256), 256, 0, st>>>(part, nblk, (int)d, dw, db, dscale, dshift); }
+  adnm_launch_fold("rownorm_bwd_fold", part, nblk, (int)(2 * d + 2), {dw, (int)d}, {db, (int)d}, {dscale, 1}, {dshift, 1}, st);
   ADNM_CHECK_LAUNCH("rownorm_bwd_finalize");
   return ADNM_OK;
 }

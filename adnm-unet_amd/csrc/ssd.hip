@@ -345,17 +345,6 @@ __global__ void ssd_bc_fold_kernel(const float* __restrict__ bcpart, int nhb, in
   else Io<T>::st(dCm + row * lddc + (c - GN), t);
 }
 
-// out[j*H + h] = sum_k hpart[k, j, h]  (j: dD, ddt_bias, dA_log), k over B * nblk * waves
-__global__ void ssd_head_fold_kernel(const float* __restrict__ hpart, int nk, int H, float* __restrict__ dD,
-                                     float* __restrict__ ddt_bias, float* __restrict__ dA_log) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 3 * H) return;
-  float t = 0.f;
-  for (int k = 0; k < nk; ++k) t += hpart[(int64_t)k * 3 * H + i];
-  const int j = i / H, h = i % H;
-  (j == 0 ? dD : j == 1 ? ddt_bias : dA_log)[h] = t;
-}
-
 struct Ws {
   float *part, *dkv, *hpart, *bcpart;
   int64_t bytes;
@@ -439,8 +428,7 @@ void run_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const voi
     { ADNM_PROF("ssd_bc_fold", st, 4.0 * tot * g.nhb); ssd_bc_fold_kernel<T><<<(unsigned)adnm_cdiv(tot, 256), 256, 0, st>>>(bcpart, g.nhb, B * L, (int)(G * N), (T*)dBm, lddb, (T*)dCm,
                                                                          lddc); }
   }
-  { ADNM_PROF("ssd_head_fold", st, 4.0 * B * g.nblk2 * kWaves * 3 * H); ssd_head_fold_kernel<<<(unsigned)adnm_cdiv(3 * H, 256), 256, 0, st>>>(hpart, (int)(B * g.nblk2 * kWaves), (int)H, dD, ddt_bias,
-                                                                        dA_log); }
+  adnm_launch_fold("ssd_head_fold", hpart, (int)(B * g.nblk2 * kWaves), 3 * (int)H, {dD, (int)H}, {ddt_bias, (int)H}, {dA_log, (int)H}, {nullptr, 0}, st);
 }
 
 }  // namespace

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from adnm_hip import ops
 from .ADNssd import Mamba2, StandardAttention
 from .model_untils import *  # noqa: F401,F403  (same star-import surface as the reference, ADNMUNet.py:34)
 from .model_untils import (BiasFree_LayerNorm, RMSNorm, Mlp, Swish, FeedForward, PatchEmbed, WTLayer, DownSample, UpSample,
@@ -32,7 +33,7 @@ def _merge(mod, x, residual, features):
         if features is not None:
             x = x + torch.cat((mod.alpha3 * features, mod.alpha4 * features), dim=-1)
     elif features is not None:
-        x = x + mod.alpha3 * features
+        x = ops.lincomb([x, features], [None, mod.alpha3])
     return x
 
 
@@ -76,12 +77,13 @@ class Block(nn.Module):
         b, l, d = x.shape
         h, w = _hw(l)
         for i in range(self.num_layers):
-            beta1, beta2 = self.beta1[i], self.beta2[i]  # beta3/beta4 alias beta1/beta2 in the reference (:145-146)
+            # beta3/beta4 alias beta1/beta2 in the reference (:145-146)
+            beta1, beta2 = (self.beta1, self.beta2) if self.num_layers == 1 else (self.beta1[i:i + 1], self.beta2[i:i + 1])
             xn = _normed(self.norm1_layers[i], x, self.scale1[i], self.shift1[i])
-            x = beta1 * x + beta2 * self.drop_path_layers[i](self.mixer_layers[i](xn, h, w))
+            x = ops.lincomb([x, self.drop_path_layers[i](self.mixer_layers[i](xn, h, w))], [beta1, beta2])
             xn = _normed(self.norm2_layers[i], x, self.scale2[i], self.shift2[i])
-            x = beta1 * x + beta2 * self.ffns[i].forward_tokens(xn, h, w)
-        x = x * self.gamma
+            x = ops.lincomb([x, self.ffns[i].forward_tokens(xn, h, w)], [beta1, beta2])
+        x = ops.lincomb([x], [None], self.gamma)
         if self.dim != self.out_dim:
             x = self.out_proj(x)
         return x
@@ -111,10 +113,10 @@ class Attention(nn.Module):
         b, l, d = x.shape
         h, w = _hw(l)
         xn = self.attn_norm1(x, self.attn_scale1, self.attn_shift1)
-        x = self.beta1 * x + self.beta2 * self.attn_layer(xn, h, w)
+        x = ops.lincomb([x, self.attn_layer(xn, h, w)], [self.beta1, self.beta2])
         xn = self.attn_norm2(x, self.attn_scale2, self.attn_shift2)
-        x = self.beta3 * x + self.beta4 * self.attn_mlp(xn)
-        x = x * self.gamma
+        x = ops.lincomb([x, self.attn_mlp(xn)], [self.beta3, self.beta4])
+        x = ops.lincomb([x], [None], self.gamma)
         if self.dim != self.out_dim:
             x = self.out_proj(x)
         return x

@@ -340,9 +340,7 @@ class PatchEmbed(nn.Module):
         res = x[..., -1].reshape(b, h, w)
         x = self.alpha1 * self.conv1[0].forward_tokens(x, h, w) + self.beta1 * x
         shortcut = self.conv2[0].forward_tokens(x, h, w)
-        x = self.alpha2 * self.conv3[0].forward_tokens(shortcut, h, w) + self.beta2 * shortcut
-        if self.gamma is not None:
-            x = x * self.gamma
+        x = ops.lincomb([self.conv3[0].forward_tokens(shortcut, h, w), shortcut], [self.alpha2, self.beta2], self.gamma)
         return x, res
 
 
@@ -373,10 +371,10 @@ class WTLayer(nn.Module):
             x = x + self.gama3 * features
         b, l, d = x.shape
         h, w = _hw(l)
-        x = self.alpha * self.wtconv.forward_tokens(x, h, w) + self.beta * x
+        x = ops.lincomb([self.wtconv.forward_tokens(x, h, w), x], [self.alpha, self.beta])
         x = self.mlp(x)
         if self.gamma is not None:
-            x = x * self.gamma
+            x = ops.lincomb([x], [None], self.gamma)
         return self.conv.forward_tokens(x, h, w)
 
 
@@ -517,7 +515,7 @@ class EncoderToDecoder(nn.Module):
         x1 = self.act_func13(self._pw(self.ffd13, x * tokens_of(self.conv13pool.act(self.conv13pool.conv(self.max_pool_31(xi) + a31)))))
         x2 = self.act_func13(self._pw(self.ffd13, x * tokens_of(self.conv31pool.act(self.conv31pool.conv(self.max_pool_13(xi) + a13)))))
         x3 = self.act_func33(self._pw(self.ffd33, x * tokens_of(self.conv33pool.act(self.conv33pool.conv(self.max_pool_33(xi) + a33)))))
-        xp = (self.alpha1 * x1 + self.alpha2 * x2 + self.alpha3 * x3) * self.gamma
+        xp = ops.lincomb([x1, x2, x3], [self.alpha1, self.alpha2, self.alpha3], self.gamma)
         return self.mlp(self.ffd.forward_tokens(xp, h, w))
 
 
@@ -544,9 +542,7 @@ class OutProj(nn.Module):
         """x: (B, L, d) tokens, residual: last input frame (B, H, W) -> (B, T_out, H, W) (model_untils.py:871-892)."""
         h, w = self.img_size[0], self.img_size[1]
         b, l, d = x.shape
-        x = self.alpha * self.wtconv.forward_tokens(x, h, w) + self.beta * x
-        if self.gamma is not None:
-            x = x * self.gamma
+        x = ops.lincomb([self.wtconv.forward_tokens(x, h, w), x], [self.alpha, self.beta], self.gamma)
         x = self.conv[0].forward_tokens(x, h, w)
         x = self.conv[1].forward_tokens(x, h, w)
         if residual is not None:

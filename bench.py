@@ -39,19 +39,32 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--prof-steps", type=int, default=3)
-    ap.add_argument("--graph", type=int, default=0, help="1: replay the step as a captured hipGraph")
+    ap.add_argument("--graph", type=int, default=1, help="1 (default): replay fwd+bwd as a captured hipGraph; 0: eager launches")
+    ap.add_argument("--blas", default="hipblas", choices=["default", "hipblas", "hipblaslt"],
+                    help="library used for the plain GEMMs (default rocBLAS: its long-reduction weight-grad GEMMs are 6x faster here)")
     return ap.parse_args()
 
 
 def collect_profile(lib):
-    n = lib.query("adnm_prof_collect", None, 0)
-    buf = ctypes.create_string_buffer(int(n) + 4096)
+    buf = ctypes.create_string_buffer(1 << 20)  # one call: collecting also clears the records
     lib.query("adnm_prof_collect", buf, len(buf))
     rows = {}
     for line in buf.value.decode().splitlines():
         name, cnt, ms, nbytes = line.split("\t")
         rows[name] = {"launches": int(cnt), "ms": float(ms), "bytes": float(nbytes)}
     return rows
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask, cgroup quota, and the 16-per-GPU share of the box."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("ADNM_CPU_THREADS", "16"))))
 
 
 def cpu_baseline(args, steps):
@@ -63,8 +76,9 @@ def cpu_baseline(args, steps):
         manifest = json.load(f)
     if (args.in_frames, args.out_frames) != (5, 20):
         return None
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: oracle on {cores} host threads ...", file=sys.stderr, flush=True)
     sd = recipe.state_dict_from_manifest(manifest)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if manifest[k]["trainable"]}
     full = dict(sd)
@@ -82,6 +96,7 @@ def cpu_baseline(args, steps):
         opt.step()
         opt.zero_grad(set_to_none=True)
         times.append(time.perf_counter() - t0)
+        print(f"[bench] cpu_baseline step {i}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
     t = sorted(times[1:])[len(times[1:]) // 2]
     return {"value": args.batch / t, "unit": "sequences/s", "cores": cores, "kind": "port",
             "sample": f"{steps} timed full training steps (+1 warm-up) of the oracle at B={args.batch}, {args.size}x{args.size}, fp32, "
@@ -102,31 +117,26 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from adnm_hip import lib, recipe
-    from adnm_hip.ddp import GradBuckets
+    from adnm_hip.trainer import FlatTrainer
     from models.ADNMUNet import create_ADNMUNet
     from models.loss import enRainfallLoss
     lib.load()
+    if args.blas != "default":
+        torch.backends.cuda.preferred_blas_library(args.blas)  # plain library GEMMs: rocBLAS ("hipblas") or hipBLASLt
 
     model = create_ADNMUNet(args.in_frames, args.out_frames, 6, img_size=args.size)
     recipe.fill_parameters(model)  # identical replicas on every rank, same parameters as the parity fixtures
     model = model.to(dev).train()
     criterion = enRainfallLoss(omega_t=0.57, alpha=0.25, gamma=0.).to(dev)  # train_untils.py:43
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2)  # :35-42
-    buckets = GradBuckets(model)
+    # AdamW recipe of train_untils.py:35-42; clip threshold = norm_max of the warm-up epochs (train.py:87,122-124)
+    trainer = FlatTrainer(model, criterion, lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2, max_norm=0.025,
+                          use_graph=bool(args.graph))
     frames = recipe.radar_batch(args.batch, args.in_frames + args.out_frames, args.size, salt=rank, name="bench").to(dev)
     x, tgt = frames[:, :args.in_frames].contiguous(), frames[:, args.in_frames:].contiguous()
-    clip = 0.025  # norm_max of the warm-up epochs (train.py:87,122-124)
-    params = [p for p in model.parameters()]
+    trainer.prepare(x, tgt)
 
     def step():
-        out = model(x)
-        loss = criterion(out, tgt)
-        loss.backward()
-        buckets.finalize()
-        torch.nn.utils.clip_grad_norm_(params, clip)
-        opt.step()
-        buckets.zero_grad()
-        return loss
+        return trainer.step(x, tgt)
 
     def sync():
         if world > 1:
@@ -136,6 +146,8 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    if rank == 0:
+        print("[bench] warm-up done, timing ...", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -145,7 +157,19 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
+    if rank == 0:
+        print(f"[bench] timed region: {1e3 * dt / args.steps:.2f} ms/step", file=sys.stderr, flush=True)
+
+    def eager_step():  # same work, launched eagerly: per-launch HIP events cannot be recorded inside a graph replay
+        g = trainer.graph
+        trainer.graph = None
+        for p in trainer.used:
+            p.grad = None
+        try:
+            return trainer.step(x, tgt)
+        finally:
+            trainer.graph = g
 
     # ---- instrumented steps (outside the timed region): per-kernel HIP-event timing inside libadnm_hip
     prof = {}
@@ -155,7 +179,7 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.prof_steps):
-            step()
+            eager_step()
         e1.record()
         torch.cuda.synchronize()
         lib.query("adnm_prof_enable", 0)
@@ -190,7 +214,8 @@ def main():
             "config": {"workload": f"ADNM-UNet create_ADNMUNet({args.in_frames},{args.out_frames},6) {args.size}x{args.size} full training step "
                                    "(fwd + enRainfallLoss + bwd + clip_grad_norm_ + AdamW), recipe parameters, synthetic radar frames in HBM",
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch, "frames": f"{args.in_frames}->{args.out_frames}",
-                       "parallelism": f"dp{world}" if world > 1 else "single", "loss": round(loss_val, 6)},
+                       "parallelism": f"dp{world}" if world > 1 else "single", "launch": "hipGraph replay" if args.graph else "eager",
+                       "loss": round(loss_val, 6)},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -143,6 +143,33 @@ int adnm_gate_fwd(const void* h, int64_t ldh, void* y, int64_t ldy, int64_t M, i
 int adnm_gate_bwd(const void* dy, int64_t lddy, const void* h, int64_t ldh, void* dh, int64_t lddh, int64_t M,
                   int64_t F, int dtype, adnm_stream_t stream);
 
+/* ---------------------------------------------------------------- fused scalar / channel-affine mixes
+ * y[m,c] = gamma[c] * ( s0*x0[m,c] + s1*x1[m,c] + s2*x2[m,c] )      x1,x2 optional (NULL), s_k NULL = 1, gamma NULL = 1
+ * replaces the broadcast mul/add chains around the learnable scalars of Block.forward (ADNMUNet.py:152,158,161),
+ * Attention.forward (:226,232,234), WTLayer / PatchEmbed / OutProj (model_untils.py:306-310,418-421,881-883) and
+ * EncoderToDecoder (:785-787).  bwd: dx_k = s_k*gamma*dy (NULL skips), ds_k = sum dy*gamma*x_k, dgamma[c] = sum_m dy*mix;
+ * ds_k / dgamma are OVERWRITTEN (NULL skips).  C % 4 == 0, C <= 2048. */
+int adnm_lincomb_fwd(const void* x0, int64_t ld0, const void* x1, int64_t ld1, const void* x2, int64_t ld2,
+                     const float* s0, const float* s1, const float* s2, const float* gamma, void* y, int64_t ldy,
+                     int64_t M, int64_t C, int dtype, adnm_stream_t stream);
+int64_t adnm_lincomb_bwd_ws_bytes(int64_t M, int64_t C);
+int adnm_lincomb_bwd(const void* dy, int64_t lddy, const void* x0, int64_t ld0, const void* x1, int64_t ld1,
+                     const void* x2, int64_t ld2, const float* s0, const float* s1, const float* s2,
+                     const float* gamma, void* dx0, int64_t lddx0, void* dx1, int64_t lddx1, void* dx2, int64_t lddx2,
+                     float* ds0, float* ds1, float* ds2, float* dgamma, void* ws, int64_t ws_bytes, int64_t M, int64_t C,
+                     int dtype, adnm_stream_t stream);
+
+/* ---------------------------------------------------------------- fused step glue on flat fp32 buffers (§8f rank 1)
+ * clip_grad_norm_(max_norm) (train.py:140) + AdamW (train_untils.py:35-42) over n parameters laid out flat:
+ *   state[1] = sum g^2;  coef = min(1, max_norm / (sqrt(state[1]) + 1e-6))  (max_norm <= 0: no clipping)
+ *   state[0] += 1 (step);  p *= 1 - lr*wd;  m = lerp(m, coef*g, 1-beta1);  v = beta2*v + (1-beta2)(coef*g)^2
+ *   p -= lr/(1-beta1^step) * m / (sqrt(v)/sqrt(1-beta2^step) + eps)        — torch.optim.AdamW's exact update order.
+ * state: 4 device floats [step, sumsq, bc1, sqrt(bc2)], zero-initialised by the caller; n % 4 == 0. */
+int64_t adnm_adamw_ws_bytes(void);
+int adnm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float* state, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, float max_norm, void* ws, int64_t ws_bytes,
+                    adnm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

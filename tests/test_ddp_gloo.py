@@ -9,6 +9,28 @@ import torch.multiprocessing as mp
 import torch.nn as nn
 
 
+def _plain(o):
+    """tensors -> numpy before crossing the process boundary (no shared-memory handles that outlive the worker)."""
+    if torch.is_tensor(o):
+        return o.detach().numpy().copy()
+    if isinstance(o, dict):
+        return {k: _plain(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_plain(v) for v in o]
+    return o
+
+
+def _torchify(o):
+    import numpy as np
+    if isinstance(o, np.ndarray):
+        return torch.from_numpy(o)
+    if isinstance(o, dict):
+        return {k: _torchify(v) for k, v in o.items()}
+    if isinstance(o, list):
+        return [_torchify(v) for v in o]
+    return o
+
+
 class Toy(nn.Module):
     def __init__(self):
         super().__init__()
@@ -49,7 +71,7 @@ def _worker(rank, world, port, q):
         else:
             buckets.zero_grad()
     out["final"] = {k: p.detach().clone() for k, p in model.named_parameters()}
-    q.put((rank, out))
+    q.put((rank, _plain(out)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -64,7 +86,7 @@ def test_two_rank_gradient_average():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(2))
+    res = {r: _torchify(o) for r, o in (q.get(timeout=120) for _ in range(2))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -77,3 +99,56 @@ def test_two_rank_gradient_average():
         assert torch.equal(a["avg"][k], b["avg"][k]), k
     for k in a["final"]:
         assert torch.equal(a["final"][k], b["final"][k]), f"replicas diverged at {k}"
+
+
+def _trainer_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adnm-unet_amd"))
+    from adnm_hip.trainer import FlatTrainer
+    model = Toy()
+    tr = FlatTrainer(model, lambda o, t: (o - t).pow(2).mean(), lr=1e-2, eps=1e-9, weight_decay=1e-2, max_norm=0.5,
+                     use_graph=False, fused=False)  # CPU: exercises flattening + all-reduce; the HIP optimiser needs a GPU
+    torch.manual_seed(100 + rank)
+    xs = [torch.randn(5, 8) for _ in range(3)]
+    ts = [torch.randn(5, 4) for _ in range(3)]
+    for x, t in zip(xs, ts):
+        tr.step(x, t)
+    q.put((rank, _plain({"final": {k: p.detach().clone() for k, p in model.named_parameters()}, "xs": xs, "ts": ts,
+                         "n_used": len(tr.used)})))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_trainer_two_ranks_equals_global_batch():
+    """2 ranks x batch 5 with averaged gradients == 1 process with the concatenated batch of 10 (mean loss)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: _torchify(o) for r, o in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = res[0], res[1]
+    for k in a["final"]:
+        assert torch.equal(a["final"][k], b["final"][k]), f"replicas diverged at {k}"
+    assert a["n_used"] == 5  # a.weight, a.bias, b.weight, b.bias, s — not the two `dead` tensors
+    # single-process reference on the global batch
+    model = Toy()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, eps=1e-9, weight_decay=1e-2)
+    for i in range(3):
+        x = torch.cat([a["xs"][i], b["xs"][i]])
+        t = torch.cat([a["ts"][i], b["ts"][i]])
+        (model(x) - t).pow(2).mean().backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    for k, p in model.named_parameters():
+        assert torch.allclose(a["final"][k], p, atol=2e-6, rtol=1e-5), k

@@ -274,3 +274,31 @@ def test_bf16_storage_paths():
     xr, w = T("b.rx", (333, 64)), torch.ones(64)
     yr = ops.rownorm(h16(xr), w.to(DEV), None, None, None, 1e-6, False)
     assert_close(yr.float(), O.rmsnorm(xr, w, 1e-6), 2e-2, "bf16 rmsnorm")
+
+
+# ------------------------------------------------------------------------------------------- fused mixes
+@pytest.mark.parametrize("M,C,K,use_gamma", [(4 * 16384, 32, 2, False), (1000, 32, 1, True), (64, 1024, 2, True), (333, 64, 3, True), (7, 2048, 2, False)])
+def test_lincomb(M, C, K, use_gamma):
+    xs = [T(f"lc.x{k}", (M, C)) for k in range(K)]
+    ss = [torch.tensor([0.7 + 0.3 * k]) for k in range(K)]
+    ss[0] = None if K > 1 else ss[0]
+    gamma = 1 + 0.2 * T("lc.g", (C,)) if use_gamma else None
+    cot = T("lc.c", (M, C))
+    xo = [leaf(x.double()) for x in xs]
+    so = [leaf(s.double()) if s is not None else None for s in ss]
+    go = leaf(gamma.double()) if use_gamma else None
+    yo = sum((x if s is None else s * x) for x, s in zip(xo, so))
+    yo = yo * go if use_gamma else yo
+    (yo * cot.double()).sum().backward()
+    xg = [leaf(x, DEV) for x in xs]
+    sg = [leaf(s, DEV) if s is not None else None for s in ss]
+    gg = leaf(gamma, DEV) if use_gamma else None
+    yg = ops.lincomb(xg, sg, gg)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, OUT_TOL, "y")
+    for k in range(K):
+        assert_close(xg[k].grad, xo[k].grad, GRAD_TOL, f"dx{k}")
+        if ss[k] is not None:
+            assert_close(sg[k].grad, so[k].grad, GRAD_TOL, f"ds{k}", atol=1e-4)
+    if use_gamma:
+        assert_close(gg.grad, go.grad, GRAD_TOL, "dgamma", atol=1e-5)
