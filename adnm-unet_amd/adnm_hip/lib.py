@@ -16,6 +16,7 @@ _CT = {
     "const void*": ctypes.c_void_p, "void*": ctypes.c_void_p, "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p,
     "int64_t": ctypes.c_int64, "int": ctypes.c_int, "float": ctypes.c_float, "adnm_stream_t": ctypes.c_void_p,
     "const char*": ctypes.c_char_p, "char*": ctypes.c_char_p, "void": None,
+    "float* const*": ctypes.c_void_p,
 }
 
 
@@ -86,6 +87,14 @@ def call(name, *args):
         rc = getattr(load(), name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {last_error()}")
+
+
+def ptr_table(tensors):
+    """Host array of device pointers (None -> NULL) for the `float* const*` parameters."""
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
 
 
 def query(name, *args):

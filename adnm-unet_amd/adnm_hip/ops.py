@@ -550,3 +550,106 @@ def lincomb(xs, scalars, gamma=None):
             y = y + (x if s is None else s * x)
         return y if gamma is None else y * gamma
     return LinCombFn.apply(gamma, *xs, *scalars)
+
+
+class AdnPrepFn(torch.autograd.Function):
+    """Reference-layout ADN-SSD parameters -> the kernel-layout tensors ADNMixerFn consumes (one HIP launch each way;
+    see csrc/paramprep.hip).  Argument order = the `params[15]` table of include/adnm_hip.h."""
+
+    @staticmethod
+    def forward(ctx, dm, di, gn, P, *params):
+        params = [p.contiguous() for p in params]
+        dev = params[0].device
+        _need_gpu(params[0])
+        nh, cx = di // P, di + 2 * gn
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        outs = [f(2 * di + 2 * gn + nh, dm), f(9, cx), f(9, di), f(di), f(di), f(dm, 2 * di)]
+        lib.call("adnm_adnprep_fwd", lib.ptr_table(params), lib.ptr_table(outs), dm, di, gn, P, _stream())
+        ctx.save_for_backward(*params)
+        ctx.dims = (dm, di, gn, P)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        params = ctx.saved_tensors
+        dm, di, gn, P = ctx.dims
+        gouts = [g.contiguous() for g in gouts]
+        dparams = [torch.empty_like(p) for p in params]
+        nb = lib.query("adnm_adnprep_bwd_ws_bytes")
+        ws = _ws(nb, params[0].device)
+        lib.call("adnm_adnprep_bwd", lib.ptr_table(params), lib.ptr_table(gouts), lib.ptr_table(dparams), dm, di, gn, P, ws.data_ptr(), nb,
+                 _stream())
+        return (None, None, None, None, *dparams)
+
+
+def adn_prep(dm, di, gn, P, params):
+    return AdnPrepFn.apply(dm, di, gn, P, *params)
+
+
+class WtPrepFn(torch.autograd.Function):
+    """WTConv2d parameters -> tap-major taps with the per-channel scales folded in and channels zero-padded to Cp.
+    args: C, Cp, K, levels, bias|None, then (1+levels) conv weights, then (1+levels) scale tensors."""
+
+    @staticmethod
+    def forward(ctx, C, Cp, K, levels, bias, *ws_):
+        n = 1 + levels
+        w = [t.contiguous() for t in ws_[:n]]
+        s = [t.contiguous() for t in ws_[n:]]
+        dev = w[0].device
+        _need_gpu(w[0])
+        taps = [torch.empty((K * K, Cp if k == 0 else 4 * Cp), dtype=torch.float32, device=dev) for k in range(n)]
+        bias_t = torch.empty(Cp, dtype=torch.float32, device=dev) if bias is not None else None
+        lib.call("adnm_wtprep_fwd", lib.ptr_table(w), lib.ptr_table(s), _p(bias), lib.ptr_table(taps), _p(bias_t), C, Cp, K, levels, _stream())
+        ctx.save_for_backward(bias, *w, *s)
+        ctx.dims = (C, Cp, K, levels)
+        return (bias_t, *taps)
+
+    @staticmethod
+    def backward(ctx, gbias_t, *gtaps):
+        C, Cp, K, levels = ctx.dims
+        n = 1 + levels
+        saved = ctx.saved_tensors
+        bias, w, s = saved[0], saved[1:1 + n], saved[1 + n:]
+        gtaps = [g.contiguous() for g in gtaps]
+        dw = [torch.empty_like(t) for t in w]
+        ds = [torch.empty_like(t) for t in s]
+        dbias = torch.empty_like(bias) if bias is not None else None
+        if bias is not None:
+            gbias_t = gbias_t.contiguous() if gbias_t is not None else torch.zeros(Cp, dtype=torch.float32, device=bias.device)
+        lib.call("adnm_wtprep_bwd", lib.ptr_table(w), lib.ptr_table(s), _p(bias), lib.ptr_table(gtaps), _p(gbias_t) if bias is not None else None,
+                 lib.ptr_table(dw), lib.ptr_table(ds), _p(dbias), C, Cp, K, levels, _stream())
+        return (None, None, None, None, dbias, *dw, *ds)
+
+
+def wt_prep(C, Cp, K, levels, bias, weights, scales):
+    out = WtPrepFn.apply(C, Cp, K, levels, bias, *weights, *scales)
+    return out[0], out[1], list(out[2:])
+
+
+class MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool2d on (B, H*W, C) tokens: stride == kernel (DownSample) or stride 1 'same' (EncoderToDecoder)."""
+
+    @staticmethod
+    def forward(ctx, x, H, W, kh, kw, stride):
+        B, L, C = x.shape
+        x = x.contiguous()
+        _need_gpu(x)
+        Ho, Wo = (H, W) if stride == 1 else (H // stride, W // stride)
+        y = torch.empty((B, Ho * Wo, C), dtype=x.dtype, device=x.device)
+        lib.call("adnm_maxpool_fwd", x.data_ptr(), y.data_ptr(), B, H, W, C, kh, kw, stride, _dt(x), _stream())
+        ctx.save_for_backward(x)
+        ctx.dims = (B, H, W, C, kh, kw, stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, H, W, C, kh, kw, stride = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        lib.call("adnm_maxpool_bwd", dy.data_ptr(), x.data_ptr(), dx.data_ptr(), B, H, W, C, kh, kw, stride, _dt(x), _stream())
+        return dx, None, None, None, None, None
+
+
+def maxpool(x, H, W, kh, kw, stride):
+    return MaxPoolFn.apply(x, H, W, kh, kw, stride)

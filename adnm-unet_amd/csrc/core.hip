@@ -99,8 +99,20 @@ __global__ __launch_bounds__(kFoldCols* kFoldSlices) void fold_rows_kernel(const
   const int cl = threadIdx.x & (kFoldCols - 1), sl = threadIdx.x / kFoldCols;
   const int c = blockIdx.x * kFoldCols + cl;
   float acc = 0.f;
-  if (c < n)
-    for (int r = sl; r < rows; r += kFoldSlices) acc += part[(int64_t)r * n + c];
+  if (c < n) {
+    // independent loads: 8 in flight per lane, two accumulators (fixed order -> still deterministic)
+    float acc2 = 0.f;
+    int r = sl;
+    for (; r + 7 * kFoldSlices < rows; r += 8 * kFoldSlices) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(r + u * kFoldSlices) * n + c];
+      acc += (v[0] + v[1]) + (v[2] + v[3]);
+      acc2 += (v[4] + v[5]) + (v[6] + v[7]);
+    }
+    for (; r < rows; r += kFoldSlices) acc += part[(int64_t)r * n + c];
+    acc += acc2;
+  }
   sm[sl][cl] = acc;
   __syncthreads();
   if (sl == 0 && c < n) {

@@ -98,87 +98,93 @@ __global__ __launch_bounds__(kBlock) void dwconv_kernel(const T* __restrict__ x,
   }
 }
 
-// (c) weight / bias gradients.  block = CGB channel quads x PS pixel slots; grid = (C4/CGB, NPB).
-// part[(blockIdx.y*waves + wave), tap, c]  (+ tap index K*K holds dbias)
+// (c) weight / bias gradients.  block = K waves, wave i owns tap ROW i of every channel quad it sees, so a lane
+// keeps only K float4 accumulators (not K*K) and reads ONE input row per tile; the K waves of a block share the
+// tile's dpre strip through L1.  lane = (channel quad, pixel slot); grid = (C4/cgb, npb).  No cross-wave reduction:
+// wave i writes taps [i*K, i*K+K) of the block's partial row; the middle wave also writes the bias gradient.
+// part[blockIdx.y, tap, c]  (tap index K*K holds dbias)
 template <typename T, int K>
-__global__ __launch_bounds__(kBlock) void dwconv_wgrad_kernel(const T* __restrict__ dpre, int64_t ldd, const T* __restrict__ x,
+__global__ __launch_bounds__(64 * K) void dwconv_wgrad_kernel(const T* __restrict__ dpre, int64_t ldd, const T* __restrict__ x,
                                                               int64_t ldx, float* __restrict__ part, int B, int H, int W, int C,
                                                               int cgb) {
   constexpr int R = K / 2;
   constexpr int NT = K * K;
   const int C4 = C >> 2;
-  const int cgl = threadIdx.x & (cgb - 1);
-  const int slot = threadIdx.x / cgb;
-  const int slots = kBlock / cgb;
+  const int i = threadIdx.x >> 6;  // tap row of this wave
+  const int lane = threadIdx.x & 63;
+  const int cgl = lane & (cgb - 1);
+  const int slot = lane / cgb;
+  const int slots = 64 / cgb;
   const int cg = blockIdx.x * cgb + cgl;
   const bool cv = cg < C4;
   const int c = cv ? cg * 4 : 0;
   const int WT = (W + TW - 1) / TW;
   const int64_t tiles = (int64_t)B * H * WT;
-  float4 aw[NT];
+  float4 aw[K];
   float4 ab = f4zero();
 #pragma unroll
-  for (int k = 0; k < NT; ++k) aw[k] = f4zero();
+  for (int k = 0; k < K; ++k) aw[k] = f4zero();
   if (cv) {
     for (int64_t t = (int64_t)blockIdx.y * slots + slot; t < tiles; t += (int64_t)gridDim.y * slots) {
       const int wt = (int)(t % WT);
       const int h = (int)((t / WT) % H);
       const int b = (int)(t / ((int64_t)WT * H));
+      const int hh = h + i - R;
+      if (hh < 0 || hh >= H) continue;
       const int w0 = wt * TW;
       float4 g[TW];
 #pragma unroll
       for (int p = 0; p < TW; ++p) {
         const int ww = w0 + p;
         g[p] = ww < W ? Io<T>::ld4(dpre + (((int64_t)b * H + h) * W + ww) * ldd + c) : f4zero();
-        ab.x += g[p].x; ab.y += g[p].y; ab.z += g[p].z; ab.w += g[p].w;
+      }
+      if (i == R) {
+#pragma unroll
+        for (int p = 0; p < TW; ++p) { ab.x += g[p].x; ab.y += g[p].y; ab.z += g[p].z; ab.w += g[p].w; }
+      }
+      const T* xr = x + ((int64_t)b * H + hh) * W * ldx + c;
+      float4 row[TW + K - 1];
+#pragma unroll
+      for (int j = 0; j < TW + K - 1; ++j) {
+        const int ww = w0 + j - R;
+        row[j] = (ww >= 0 && ww < W) ? Io<T>::ld4(xr + (int64_t)ww * ldx) : f4zero();
       }
 #pragma unroll
-      for (int i = 0; i < K; ++i) {
-        const int hh = h + i - R;
-        if (hh < 0 || hh >= H) continue;
-        const T* xr = x + ((int64_t)b * H + hh) * W * ldx + c;
-        float4 row[TW + K - 1];
+      for (int j = 0; j < K; ++j)
 #pragma unroll
-        for (int j = 0; j < TW + K - 1; ++j) {
-          const int ww = w0 + j - R;
-          row[j] = (ww >= 0 && ww < W) ? Io<T>::ld4(xr + (int64_t)ww * ldx) : f4zero();
-        }
-#pragma unroll
-        for (int j = 0; j < K; ++j)
-#pragma unroll
-          for (int p = 0; p < TW; ++p) fma4(aw[i * K + j], g[p], row[p + j]);
-      }
+        for (int p = 0; p < TW; ++p) fma4(aw[j], g[p], row[p + j]);
     }
   }
-  // fold the pixel slots that share a wave; one partial row per wave
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float* dst = part + ((int64_t)blockIdx.y * (kBlock / 64) + wave) * (NT + 1) * C;
+  float* dst = part + (int64_t)blockIdx.y * (NT + 1) * C;
 #pragma unroll
-  for (int k = 0; k <= NT; ++k) {
-    float4 v = k < NT ? aw[k] : ab;
+  for (int j = 0; j <= K; ++j) {
+    if (j == K && i != R) break;
+    float4 v = j < K ? aw[j] : ab;
     v.x = wave_sum_from(v.x, cgb); v.y = wave_sum_from(v.y, cgb);
     v.z = wave_sum_from(v.z, cgb); v.w = wave_sum_from(v.w, cgb);
-    if (lane < cgb && cv) *reinterpret_cast<float4*>(dst + (int64_t)k * C + c) = v;
+    if (lane < cgb && cv) *reinterpret_cast<float4*>(dst + (int64_t)(j < K ? i * K + j : NT) * C + c) = v;
   }
 }
 
 struct WGeo {
   int cgb, gx, npb, rows;
 };
-WGeo wgeo(int64_t B, int64_t H, int64_t W, int64_t C) {
+WGeo wgeo(int64_t B, int64_t H, int64_t W, int64_t C, int K) {
   WGeo g;
   const int64_t C4 = C / 4;
   g.cgb = 1;
   while (g.cgb < 64 && g.cgb < C4) g.cgb <<= 1;
   g.gx = (int)adnm_cdiv(C4, g.cgb);
-  const int slots = kBlock / g.cgb;
+  const int slots = 64 / g.cgb;
   const int64_t tiles = B * H * adnm_cdiv(W, TW);
-  int64_t npb = adnm_cdiv(tiles, (int64_t)slots * 4);
-  const int64_t cap = (256 / g.gx) > 1 ? (256 / g.gx) : 1;
+  int64_t npb = adnm_cdiv(tiles, (int64_t)slots * 8);          // ~8 tiles per lane
+  int64_t cap = (4 << 20) / ((int64_t)(K * K + 1) * C * 4);     // keep the partials under ~4 MB
+  if (cap > 1024) cap = 1024;
+  if (cap < 32) cap = 32;
   if (npb > cap) npb = cap;
   if (npb < 1) npb = 1;
   g.npb = (int)npb;
-  g.rows = g.npb * (kBlock / 64);
+  g.rows = g.npb;
   return g;
 }
 
@@ -209,12 +215,12 @@ void launch_conv(const void* x, int64_t ldx, const float* wgt, const float* bias
 template <typename T>
 void launch_wgrad(const void* dpre, int64_t ldd, const void* x, int64_t ldx, float* part, float* dwgt, float* dbias, int64_t B, int64_t H,
                   int64_t W, int64_t C, int K, hipStream_t st) {
-  const WGeo g = wgeo(B, H, W, C);
+  const WGeo g = wgeo(B, H, W, C, K);
   const dim3 grid(g.gx, g.npb);
   if (K == 3)
-    { ADNM_PROF("dwconv_wgrad_k3", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 3><<<grid, kBlock, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb); }
+    { ADNM_PROF("dwconv_wgrad_k3", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 3><<<grid, 64 * 3, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb); }
   else
-    { ADNM_PROF("dwconv_wgrad_k5", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 5><<<grid, kBlock, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb); }
+    { ADNM_PROF("dwconv_wgrad_k5", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 5><<<grid, 64 * 5, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb); }
   adnm_launch_fold("dwconv_wgrad_fold", part, g.rows, (K * K + 1) * (int)C, {dwgt, K * K * (int)C}, {dbias, (int)C}, {nullptr, 0}, {nullptr, 0}, st);
 }
 
@@ -236,7 +242,7 @@ extern "C" int adnm_dwconv_fwd(const void* x, int64_t ldx, const float* wgt, con
 
 extern "C" int64_t adnm_dwconv_bwd_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t C, int KH, int KW) {
   if (B <= 0 || H <= 0 || W <= 0 || C < 4) return 0;
-  const WGeo g = wgeo(B, H, W, C);
+  const WGeo g = wgeo(B, H, W, C, KH);
   return (int64_t)g.rows * (KH * KW + 1) * C * (int64_t)sizeof(float);
 }
 

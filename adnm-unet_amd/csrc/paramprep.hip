@@ -1,0 +1,316 @@
+// Parameter-side preparation for the fused modules, one launch each way instead of the ~20-60 tiny torch ops
+// (index_select, outer products, scale folds, transposes and their autograd) they would otherwise cost per module
+// and per step.  These kernels touch PARAMETERS only (kilobytes to a few MB), never activations.
+//
+//  * ADN-SSD mixer (models/ADNssd.py of the reference): builds, from the reference-layout parameters,
+//      w_in   = in_proj.weight with rows reordered to [z | x' | B' | C' | dt]   (replaces the index_select gathers of
+//               ADNssd.py:329-341,375-386: even/odd halves become alternating heads, B'/C' = [even | odd])
+//      cw     = tap-major effective 3x3 taps of every xBC channel in that order: conv2d taps for even channels,
+//               outer(conv_31_*, conv_13_*) for the four asymmetric chains (ADNssd.py:343-346)
+//      czw    = tap-major conv2d_z taps; ln_w/ln_b = norm.weight/bias permuted like x';
+//      w_out  = alpha1 * out_proj.weight with its y-columns permuted alike (ADNssd.py:459)
+//    and the exact transpose of that map for the gradients.
+//  * WTConv2d (models/WTConv2d.py): tap-major taps with base_scale / wavelet_scale folded in (WTConv2d.py:123,146),
+//    channels zero-padded to a multiple of 4.
+#include "adnm_common.h"
+
+namespace {
+constexpr int kBlock = 256;
+constexpr int kMaxBlocks = 1024;
+
+struct AdnDims {
+  int dm, di, gn, P, nh;  // d_model, d_inner, ngroups*d_state, headdim, nheads
+};
+
+// kernel-order xBC channel -> reference xBC channel, and back
+__device__ __forceinline__ int adn_fwd_map(int ch, const AdnDims& d) {
+  const int half = d.gn >> 1;
+  if (ch < d.di) {
+    const int h = ch / d.P, p = ch - h * d.P;
+    return 2 * ((h >> 1) * d.P + p) + (h & 1);
+  }
+  int q = ch - d.di, base = d.di;
+  if (q >= d.gn) { q -= d.gn; base += d.gn; }
+  const int e = q / half, n = q - e * half;
+  return base + 2 * n + e;
+}
+__device__ __forceinline__ int adn_inv_map(int co, const AdnDims& d) {
+  const int half = d.gn >> 1;
+  if (co < d.di) {
+    const int e = co & 1, m = co >> 1, j = m / d.P, p = m - j * d.P;
+    return (2 * j + e) * d.P + p;
+  }
+  int q = co - d.di, base = d.di;
+  if (q >= d.gn) { q -= d.gn; base += d.gn; }
+  return base + (q & 1) * half + (q >> 1);
+}
+
+struct AdnParams {      // reference-layout parameters (or their gradients)
+  float *w_in, *conv2d, *c31[4], *c13[4], *conv2d_z, *ln_w, *ln_b, *w_out, *alpha1;  // chains: x1, bc1, x2, bc2
+};
+struct AdnPrepped {     // kernel-layout tensors (or their gradients)
+  float *w_in, *cw, *czw, *ln_w, *ln_b, *w_out;
+};
+
+// chain of reference xBC channel `co` (odd): which (c31,c13) pair and which row
+__device__ __forceinline__ void adn_chain_of(int co, const AdnDims& d, int& chain, int& row) {
+  const int o = (co - 1) >> 1;          // index in the odd part O
+  const int i = o >> 1;                 // index in Oe / Oo
+  const int nx = d.di >> 2;
+  const int odd = o & 1;                // 0: Oe (x1 / bc1), 1: Oo (x2 / bc2)
+  if (i < nx) { chain = odd ? 2 : 0; row = i; }
+  else { chain = odd ? 3 : 1; row = i - nx; }
+}
+
+__global__ __launch_bounds__(kBlock) void adn_prep_fwd_kernel(AdnParams p, AdnPrepped o, AdnDims d) {
+  const int cx = d.di + 2 * d.gn, dinp = 2 * d.di + 2 * d.gn + d.nh;
+  const int64_t n0 = (int64_t)dinp * d.dm, n1 = n0 + 9 * cx, n2 = n1 + 9 * d.di, n3 = n2 + 2 * d.di, n4 = n3 + (int64_t)d.dm * 2 * d.di;
+  const float a1 = *p.alpha1;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    if (i < n0) {
+      const int r = (int)(i / d.dm), c = (int)(i - (int64_t)r * d.dm);
+      int src = r;
+      if (r >= d.di && r < d.di + cx) src = d.di + adn_fwd_map(r - d.di, d);
+      o.w_in[i] = p.w_in[(int64_t)src * d.dm + c];
+    } else if (i < n1) {
+      const int j = (int)(i - n0), t = j / cx, ch = j - t * cx;
+      const int co = adn_fwd_map(ch, d);
+      float v;
+      if ((co & 1) == 0) v = p.conv2d[(co >> 1) * 9 + t];
+      else {
+        int chain, row;
+        adn_chain_of(co, d, chain, row);
+        v = p.c31[chain][row * 3 + t / 3] * p.c13[chain][row * 3 + t % 3];
+      }
+      o.cw[j] = v;
+    } else if (i < n2) {
+      const int j = (int)(i - n1), t = j / d.di, c = j - t * d.di;
+      o.czw[j] = p.conv2d_z[c * 9 + t];
+    } else if (i < n3) {
+      const int j = (int)(i - n2);
+      if (j < d.di) o.ln_w[j] = p.ln_w[adn_fwd_map(j, d)];
+      else o.ln_b[j - d.di] = p.ln_b[adn_fwd_map(j - d.di, d)];
+    } else {
+      const int64_t j = i - n3;
+      const int r = (int)(j / (2 * d.di)), k = (int)(j - (int64_t)r * 2 * d.di);
+      const int src = k < d.di ? adn_fwd_map(k, d) : k;
+      o.w_out[j] = a1 * p.w_out[(int64_t)r * 2 * d.di + src];
+    }
+  }
+}
+
+// thread per reference-parameter element: gathers its gradient from the prepped gradients.  part[blockIdx.x] =
+// this block's share of d alpha1 = sum g_w_out * out_proj.weight(permuted).
+__global__ __launch_bounds__(kBlock) void adn_prep_bwd_kernel(AdnParams p, AdnPrepped g, AdnParams dp, AdnDims d, float* __restrict__ part) {
+  __shared__ float sm[kBlock / 64];
+  const int cx = d.di + 2 * d.gn, dinp = 2 * d.di + 2 * d.gn + d.nh, ce = cx >> 1, nx = d.di >> 2, nbc = d.gn >> 1;
+  const int nchain = 2 * (nx + nbc) * 3;  // per kind (c31 / c13): x1,bc1,x2,bc2 rows x 3 taps
+  const int64_t n0 = (int64_t)dinp * d.dm, n1 = n0 + (int64_t)ce * 9, n2 = n1 + 2 * nchain, n3 = n2 + 9 * d.di, n4 = n3 + 2 * d.di,
+                n5 = n4 + (int64_t)d.dm * 2 * d.di;
+  const float a1 = *p.alpha1;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n5; i += (int64_t)gridDim.x * kBlock) {
+    if (i < n0) {
+      const int r = (int)(i / d.dm), c = (int)(i - (int64_t)r * d.dm);
+      int src = r;
+      if (r >= d.di && r < d.di + cx) src = d.di + adn_inv_map(r - d.di, d);
+      dp.w_in[i] = g.w_in[(int64_t)src * d.dm + c];
+    } else if (i < n1) {
+      const int j = (int)(i - n0), m = j / 9, t = j - m * 9;
+      dp.conv2d[j] = g.cw[t * cx + adn_inv_map(2 * m, d)];
+    } else if (i < n2) {
+      int j = (int)(i - n1);
+      const int kind = j / nchain;  // 0: conv_31 (3x1, tap a = row), 1: conv_13 (1x3, tap b = column)
+      j -= kind * nchain;
+      // layout inside a kind: [x1 (nx*3) | bc1 (nbc*3) | x2 (nx*3) | bc2 (nbc*3)]
+      int chain, row, tap;
+      if (j < nx * 3) { chain = 0; row = j / 3; tap = j % 3; }
+      else if (j < (nx + nbc) * 3) { j -= nx * 3; chain = 1; row = j / 3; tap = j % 3; }
+      else if (j < (2 * nx + nbc) * 3) { j -= (nx + nbc) * 3; chain = 2; row = j / 3; tap = j % 3; }
+      else { j -= (2 * nx + nbc) * 3; chain = 3; row = j / 3; tap = j % 3; }
+      const int idx = (chain & 1) ? nx + row : row;          // index in Oe / Oo
+      const int o_ = 2 * idx + (chain >> 1);                 // index in O
+      const int ch = adn_inv_map(2 * o_ + 1, d);
+      float s = 0.f;
+      if (kind == 0) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) s += g.cw[(tap * 3 + b) * cx + ch] * p.c13[chain][row * 3 + b];
+        dp.c31[chain][row * 3 + tap] = s;
+      } else {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) s += g.cw[(a * 3 + tap) * cx + ch] * p.c31[chain][row * 3 + a];
+        dp.c13[chain][row * 3 + tap] = s;
+      }
+    } else if (i < n3) {
+      const int j = (int)(i - n2), c = j / 9, t = j - c * 9;
+      dp.conv2d_z[j] = g.czw[t * d.di + c];
+    } else if (i < n4) {
+      const int j = (int)(i - n3);
+      if (j < d.di) dp.ln_w[j] = g.ln_w[adn_inv_map(j, d)];
+      else dp.ln_b[j - d.di] = g.ln_b[adn_inv_map(j - d.di, d)];
+    } else {
+      const int64_t j = i - n4;
+      const int r = (int)(j / (2 * d.di)), k = (int)(j - (int64_t)r * 2 * d.di);
+      const int src = k < d.di ? adn_inv_map(k, d) : k;
+      const float gv = g.w_out[(int64_t)r * 2 * d.di + src];
+      dp.w_out[j] = a1 * gv;
+      acc = fmaf(gv, p.w_out[j], acc);
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// ------------------------------------------------------------------------------------------------ WTConv2d
+struct WtPtrs {
+  float* w[5];  // [0] base conv, [1..] level convs   (reference layout (Cg, K*K), Cg = C or 4C)
+  float* s[5];  // per-channel scales
+  float* t[5];  // tap-major outputs (K*K, Cgp)
+  float *bias, *bias_t;
+};
+
+__global__ __launch_bounds__(kBlock) void wt_prep_fwd_kernel(WtPtrs p, int C, int Cp, int KK, int levels) {
+  // one thread per (group, padded channel): writes its K*K taps
+  const int per0 = Cp, perl = 4 * Cp;
+  const int total = per0 + levels * perl;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+    int g = 0, c = i;
+    if (i >= per0) { g = 1 + (i - per0) / perl; c = (i - per0) % perl; }
+    const int cg = g == 0 ? C : 4 * C, cgp = g == 0 ? Cp : 4 * Cp;
+    const bool live = c < cg;
+    const float sc = live ? p.s[g][c] : 0.f;
+    for (int t = 0; t < KK; ++t) p.t[g][t * cgp + c] = live ? p.w[g][c * KK + t] * sc : 0.f;
+    if (g == 0 && p.bias_t) p.bias_t[c] = live ? p.bias[c] * sc : 0.f;
+  }
+}
+
+// g: gradients of the tap-major tensors (same struct, fields t / bias_t); d: gradients of the parameters (w, s, bias)
+__global__ __launch_bounds__(kBlock) void wt_prep_bwd_kernel(WtPtrs p, WtPtrs g, WtPtrs d, int C, int Cp, int KK, int levels) {
+  const int per0 = C, perl = 4 * C;
+  const int total = per0 + levels * perl;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+    int gi = 0, c = i;
+    if (i >= per0) { gi = 1 + (i - per0) / perl; c = (i - per0) % perl; }
+    const int cgp = gi == 0 ? Cp : 4 * Cp;
+    const float sc = p.s[gi][c];
+    float ds = 0.f;
+    for (int t = 0; t < KK; ++t) {
+      const float gv = g.t[gi][t * cgp + c];
+      d.w[gi][c * KK + t] = gv * sc;
+      ds = fmaf(gv, p.w[gi][c * KK + t], ds);
+    }
+    if (gi == 0 && p.bias) {
+      const float gb = g.bias_t[c];
+      d.bias[c] = gb * sc;
+      ds = fmaf(gb, p.bias[c], ds);
+    }
+    d.s[gi][c] = ds;
+  }
+}
+
+int adn_check(const char* who, AdnDims d) {
+  ADNM_REQUIRE(d.dm > 0 && d.di > 0 && d.di % 8 == 0 && d.gn > 0 && d.gn % 4 == 0 && d.P > 0 && d.di % d.P == 0 && d.nh == d.di / d.P && d.nh % 2 == 0,
+               "%s: unsupported ADN-SSD dimensions dm=%d di=%d gn=%d P=%d nh=%d", who, d.dm, d.di, d.gn, d.P, d.nh);
+  return ADNM_OK;
+}
+
+unsigned grid_for(int64_t n) {
+  int64_t g = adnm_cdiv(n, kBlock);
+  return (unsigned)(g < 1 ? 1 : (g > kMaxBlocks ? kMaxBlocks : g));
+}
+
+}  // namespace
+
+// pointer tables are passed as plain arrays to keep the ABI free of structs:
+//   params[17]  = {in_proj.weight, conv2d.weight, conv_31_x1, conv_31_bc1, conv_31_x2, conv_31_bc2, conv_13_x1, conv_13_bc1,
+//                  conv_13_x2, conv_13_bc2, conv2d_z.weight, norm.weight, norm.bias, out_proj.weight, alpha1, 0, 0}
+//   prepped[6]  = {w_in, cw, czw, ln_w, ln_b, w_out}
+static AdnParams adn_params(float* const* a) {
+  AdnParams p;
+  p.w_in = a[0]; p.conv2d = a[1];
+  for (int k = 0; k < 4; ++k) { p.c31[k] = a[2 + k]; p.c13[k] = a[6 + k]; }
+  p.conv2d_z = a[10]; p.ln_w = a[11]; p.ln_b = a[12]; p.w_out = a[13]; p.alpha1 = a[14];
+  return p;
+}
+static AdnPrepped adn_prepped(float* const* a) {
+  AdnPrepped o;
+  o.w_in = a[0]; o.cw = a[1]; o.czw = a[2]; o.ln_w = a[3]; o.ln_b = a[4]; o.w_out = a[5];
+  return o;
+}
+
+extern "C" int adnm_adnprep_fwd(float* const* params, float* const* prepped, int64_t d_model, int64_t d_inner, int64_t gn, int64_t headdim,
+                                adnm_stream_t stream) {
+  ADNM_REQUIRE(params && prepped, "adnprep_fwd: null table");
+  for (int k = 0; k < 15; ++k) ADNM_REQUIRE(params[k], "adnprep_fwd: params[%d] is null", k);
+  for (int k = 0; k < 6; ++k) ADNM_REQUIRE(prepped[k], "adnprep_fwd: prepped[%d] is null", k);
+  AdnDims d{(int)d_model, (int)d_inner, (int)gn, (int)headdim, (int)(d_inner / (headdim > 0 ? headdim : 1))};
+  if (int rc = adn_check("adnprep_fwd", d)) return rc;
+  const int64_t n = (int64_t)(2 * d.di + 2 * d.gn + d.nh) * d.dm + 9 * (d.di + 2 * d.gn) + 9 * d.di + 2 * d.di + (int64_t)d.dm * 2 * d.di;
+  hipStream_t st = (hipStream_t)stream;
+  { ADNM_PROF("adn_prep_fwd", st, 8.0 * n); adn_prep_fwd_kernel<<<grid_for(n), kBlock, 0, st>>>(adn_params(params), adn_prepped(prepped), d); }
+  ADNM_CHECK_LAUNCH("adnprep_fwd");
+  return ADNM_OK;
+}
+
+extern "C" int64_t adnm_adnprep_bwd_ws_bytes(void) { return kMaxBlocks * (int64_t)sizeof(float); }
+
+extern "C" int adnm_adnprep_bwd(float* const* params, float* const* gprepped, float* const* dparams, int64_t d_model, int64_t d_inner,
+                                int64_t gn, int64_t headdim, void* ws, int64_t ws_bytes, adnm_stream_t stream) {
+  ADNM_REQUIRE(params && gprepped && dparams, "adnprep_bwd: null table");
+  for (int k = 0; k < 15; ++k) ADNM_REQUIRE(params[k] && dparams[k], "adnprep_bwd: params/dparams[%d] is null", k);
+  for (int k = 0; k < 6; ++k) ADNM_REQUIRE(gprepped[k], "adnprep_bwd: gprepped[%d] is null", k);
+  if (!ws || ws_bytes < adnm_adnprep_bwd_ws_bytes()) {
+    adnm_set_error("adnprep_bwd: workspace too small");
+    return ADNM_EWORKSPACE;
+  }
+  AdnDims d{(int)d_model, (int)d_inner, (int)gn, (int)headdim, (int)(d_inner / (headdim > 0 ? headdim : 1))};
+  if (int rc = adn_check("adnprep_bwd", d)) return rc;
+  const int cx = d.di + 2 * d.gn;
+  const int64_t n = (int64_t)(2 * d.di + 2 * d.gn + d.nh) * d.dm + (int64_t)(cx / 2) * 9 + 2 * 2 * (d.di / 4 + d.gn / 2) * 3 + 9 * d.di + 2 * d.di +
+                    (int64_t)d.dm * 2 * d.di;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = grid_for(n);
+  { ADNM_PROF("adn_prep_bwd", st, 8.0 * n); adn_prep_bwd_kernel<<<grid, kBlock, 0, st>>>(adn_params(params), adn_prepped(gprepped), adn_params(dparams), d, (float*)ws); }
+  adnm_launch_fold("adn_prep_bwd_fold", (const float*)ws, (int)grid, 1, {dparams[14], 1}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
+  ADNM_CHECK_LAUNCH("adnprep_bwd");
+  return ADNM_OK;
+}
+
+// WTConv2d tables (levels <= 4): w[1+levels], s[1+levels], t[1+levels]; bias / bias_t may be NULL together.
+static WtPtrs wt_ptrs(float* const* w, float* const* s, float* const* t, float* bias, float* bias_t, int levels) {
+  WtPtrs p;
+  for (int k = 0; k < 5; ++k) {
+    p.w[k] = (w && k <= levels) ? w[k] : nullptr;
+    p.s[k] = (s && k <= levels) ? s[k] : nullptr;
+    p.t[k] = (t && k <= levels) ? t[k] : nullptr;
+  }
+  p.bias = bias;
+  p.bias_t = bias_t;
+  return p;
+}
+
+extern "C" int adnm_wtprep_fwd(float* const* w, float* const* s, float* bias, float* const* taps, float* bias_t, int64_t C, int64_t Cp,
+                               int64_t K, int64_t levels, adnm_stream_t stream) {
+  ADNM_REQUIRE(w && s && taps && C > 0 && Cp >= C && Cp % 4 == 0 && levels >= 0 && levels <= 4 && (K == 3 || K == 5) && (!bias == !bias_t),
+               "wtprep_fwd: bad arguments (C=%lld Cp=%lld K=%lld levels=%lld)", (long long)C, (long long)Cp, (long long)K, (long long)levels);
+  for (int k = 0; k <= levels; ++k) ADNM_REQUIRE(w[k] && s[k] && taps[k], "wtprep_fwd: table entry %d is null", k);
+  hipStream_t st = (hipStream_t)stream;
+  const int total = (int)(Cp + levels * 4 * Cp);
+  { ADNM_PROF("wt_prep_fwd", st, 8.0 * total * K * K); wt_prep_fwd_kernel<<<grid_for(total), kBlock, 0, st>>>(wt_ptrs(w, s, taps, bias, bias_t, (int)levels), (int)C, (int)Cp, (int)(K * K), (int)levels); }
+  ADNM_CHECK_LAUNCH("wtprep_fwd");
+  return ADNM_OK;
+}
+
+extern "C" int adnm_wtprep_bwd(float* const* w, float* const* s, float* bias, float* const* gtaps, float* gbias_t, float* const* dw,
+                               float* const* ds, float* dbias, int64_t C, int64_t Cp, int64_t K, int64_t levels, adnm_stream_t stream) {
+  ADNM_REQUIRE(w && s && gtaps && dw && ds && C > 0 && Cp >= C && levels >= 0 && levels <= 4 && (K == 3 || K == 5), "wtprep_bwd: bad arguments");
+  ADNM_REQUIRE((!bias == !gbias_t) && (!bias == !dbias), "wtprep_bwd: bias pointers must be all set or all null");
+  for (int k = 0; k <= levels; ++k) ADNM_REQUIRE(w[k] && s[k] && gtaps[k] && dw[k] && ds[k], "wtprep_bwd: table entry %d is null", k);
+  hipStream_t st = (hipStream_t)stream;
+  const int total = (int)(C + levels * 4 * C);
+  { ADNM_PROF("wt_prep_bwd", st, 12.0 * total * K * K); wt_prep_bwd_kernel<<<grid_for(total), kBlock, 0, st>>>(wt_ptrs(w, s, nullptr, bias, nullptr, (int)levels), wt_ptrs(nullptr, nullptr, gtaps, nullptr, gbias_t, (int)levels), wt_ptrs(dw, ds, nullptr, dbias, nullptr, (int)levels), (int)C, (int)Cp, (int)(K * K), (int)levels); }
+  ADNM_CHECK_LAUNCH("wtprep_bwd");
+  return ADNM_OK;
+}

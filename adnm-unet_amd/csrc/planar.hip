@@ -86,6 +86,88 @@ __global__ __launch_bounds__(kBlock) void haar_idwt_kernel(const T* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------- max pooling
+// nn.MaxPool2d on tokens: DownSample's 2x2/stride-2 (model_untils.py:472-487) and EncoderToDecoder's stride-1
+// (1x3, 3x1, 3x3, -inf padding, model_untils.py:690-719).  Backward is a GATHER: every input pixel re-derives the
+// first arg-max (row-major scan, strict >, as ATen) of each window that contains it, so there are no atomics and no
+// saved index tensor (ATen's max_pool_backward_nhwc takes 65 us per call here).
+struct PoolGeo {
+  int kh, kw, s, ph, pw, Ho, Wo;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, PoolGeo g) {
+  const int C4 = C >> 2;
+  const int64_t total = (int64_t)B * g.Ho * g.Wo * C4;
+  const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = (int)(idx % C4);
+  int64_t t = idx / C4;
+  const int j = (int)(t % g.Wo);
+  t /= g.Wo;
+  const int i = (int)(t % g.Ho);
+  const int b = (int)(t / g.Ho);
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  for (int a = 0; a < g.kh; ++a) {
+    const int hh = i * g.s - g.ph + a;
+    if (hh < 0 || hh >= H) continue;
+    for (int c = 0; c < g.kw; ++c) {
+      const int ww = j * g.s - g.pw + c;
+      if (ww < 0 || ww >= W) continue;
+      const float4 v = Io<T>::ld4(x + (((int64_t)b * H + hh) * W + ww) * C + cg * 4);
+      m.x = v.x > m.x ? v.x : m.x; m.y = v.y > m.y ? v.y : m.y; m.z = v.z > m.z ? v.z : m.z; m.w = v.w > m.w ? v.w : m.w;
+    }
+  }
+  Io<T>::st4(y + (((int64_t)b * g.Ho + i) * g.Wo + j) * C + cg * 4, m);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void maxpool_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx, int B, int H,
+                                                             int W, int C, PoolGeo g) {
+  const int C4 = C >> 2;
+  const int64_t total = (int64_t)B * H * W * C4;
+  const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = (int)(idx % C4);
+  int64_t t = idx / C4;
+  const int w = (int)(t % W);
+  t /= W;
+  const int h = (int)(t % H);
+  const int b = (int)(t / H);
+  const T* xb = x + (int64_t)b * H * W * C + cg * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // windows (qi,qj) with qi*s - ph <= h <= qi*s - ph + kh - 1
+  int qi0 = h + g.ph - g.kh + 1;
+  qi0 = qi0 <= 0 ? 0 : (qi0 + g.s - 1) / g.s;
+  int qj0 = w + g.pw - g.kw + 1;
+  qj0 = qj0 <= 0 ? 0 : (qj0 + g.s - 1) / g.s;
+  const int qi1 = (h + g.ph) / g.s, qj1 = (w + g.pw) / g.s;
+  for (int qi = qi0; qi <= qi1 && qi < g.Ho; ++qi)
+    for (int qj = qj0; qj <= qj1 && qj < g.Wo; ++qj) {
+      float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int arg[4] = {-1, -1, -1, -1};
+      for (int a = 0; a < g.kh; ++a) {
+        const int hh = qi * g.s - g.ph + a;
+        if (hh < 0 || hh >= H) continue;
+        for (int c = 0; c < g.kw; ++c) {
+          const int ww = qj * g.s - g.pw + c;
+          if (ww < 0 || ww >= W) continue;
+          const float4 v = Io<T>::ld4(xb + ((int64_t)hh * W + ww) * C);
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (vv[k] > best[k] || arg[k] < 0) { best[k] = vv[k]; arg[k] = hh * W + ww; }
+        }
+      }
+      const float4 gq = Io<T>::ld4(dy + (((int64_t)b * g.Ho + qi) * g.Wo + qj) * C + cg * 4);
+      const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (arg[k] == h * W + w) acc[k] += gv[k];
+    }
+  Io<T>::st4(dx + (((int64_t)b * H + h) * W + w) * C + cg * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+}
+
 // ---------------------------------------------------------------------------------------------- InstanceNorm
 struct IGeo {
   int cgb, gx, nchunk, pix_per_chunk;
@@ -194,6 +276,7 @@ __global__ __launch_bounds__(kBlock) void instnorm_apply_kernel(const T* __restr
   T* yb = y + (int64_t)b * HW * C + c;
   const float4 K = Io<T>::ld4(xb);
   float4 s1 = f4zero(), s2 = f4zero();
+#pragma unroll 8
   for (int k = 0; k < nchunk; ++k) {
     const float* src = part + ((int64_t)b * nchunk + k) * 2 * C;
     const float4 a = *reinterpret_cast<const float4*>(src + c), q = *reinterpret_cast<const float4*>(src + C + c);
@@ -283,6 +366,7 @@ __global__ __launch_bounds__(kBlock) void instnorm_bwd_apply_kernel(const T* __r
   const float4 rs = *reinterpret_cast<const float4*>(rstd_in + (int64_t)b * C + c);
   const float sc = scale ? *scale : 1.f, sh = shift ? *shift : 0.f;
   float4 s1 = f4zero(), s2 = f4zero();
+#pragma unroll 8
   for (int k = 0; k < nchunk; ++k) {
     const float* src = part + ((int64_t)b * nchunk + k) * 2 * C;
     const float4 a = *reinterpret_cast<const float4*>(src + c), q = *reinterpret_cast<const float4*>(src + C + c);
@@ -368,6 +452,54 @@ extern "C" int adnm_haar_idwt(const void* s, const void* ll_add, void* y, int64_
   else
     { ADNM_PROF("haar_idwt", st, 2.0 * B * H * W * C * (ll_add ? 2.25 : 2)); haar_idwt_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)s, (const uint16_t*)ll_add, (uint16_t*)y, (int)B, (int)H, (int)W, (int)C); }
   ADNM_CHECK_LAUNCH("haar_idwt");
+  return ADNM_OK;
+}
+
+static int pool_geo(const char* who, int64_t B, int64_t H, int64_t W, int64_t C, int kh, int kw, int stride, int dtype, PoolGeo* g) {
+  ADNM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "%s: bad shape (C=%lld must be a multiple of 4)", who, (long long)C);
+  ADNM_REQUIRE(dtype == ADNM_F32 || dtype == ADNM_BF16, "%s: bad dtype %d", who, dtype);
+  if (stride == 1) {
+    ADNM_REQUIRE((kh == 1 || kh == 3) && (kw == 1 || kw == 3), "%s: stride-1 pooling supports 1x3, 3x1, 3x3 ('same' padding)", who);
+    *g = PoolGeo{kh, kw, 1, kh / 2, kw / 2, (int)H, (int)W};
+  } else {
+    ADNM_REQUIRE(stride == kh && stride == kw && stride >= 2 && stride <= 4, "%s: strided pooling needs kernel == stride in [2,4]", who);
+    *g = PoolGeo{kh, kw, stride, 0, 0, (int)(H / stride), (int)(W / stride)};
+    ADNM_REQUIRE(g->Ho > 0 && g->Wo > 0, "%s: input smaller than the window", who);
+  }
+  return ADNM_OK;
+}
+
+extern "C" int adnm_maxpool_fwd(const void* x, void* y, int64_t B, int64_t H, int64_t W, int64_t C, int kh, int kw, int stride, int dtype,
+                                adnm_stream_t stream) {
+  ADNM_REQUIRE(x && y, "maxpool_fwd: null pointer");
+  PoolGeo g;
+  if (int rc = pool_geo("maxpool_fwd", B, H, W, C, kh, kw, stride, dtype, &g)) return rc;
+  const int64_t total = B * g.Ho * g.Wo * (C / 4);
+  const unsigned grid = (unsigned)adnm_cdiv(total, kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  const double es = dtype == ADNM_F32 ? 4.0 : 2.0;
+  ADNM_PROF("maxpool_fwd", st, es * C * B * ((double)H * W + (double)g.Ho * g.Wo));
+  if (dtype == ADNM_F32) maxpool_fwd_kernel<float><<<grid, kBlock, 0, st>>>((const float*)x, (float*)y, (int)B, (int)H, (int)W, (int)C, g);
+  else maxpool_fwd_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)x, (uint16_t*)y, (int)B, (int)H, (int)W, (int)C, g);
+  ADNM_CHECK_LAUNCH("maxpool_fwd");
+  return ADNM_OK;
+}
+
+extern "C" int adnm_maxpool_bwd(const void* dy, const void* x, void* dx, int64_t B, int64_t H, int64_t W, int64_t C, int kh, int kw, int stride,
+                                int dtype, adnm_stream_t stream) {
+  ADNM_REQUIRE(dy && x && dx, "maxpool_bwd: null pointer");
+  PoolGeo g;
+  if (int rc = pool_geo("maxpool_bwd", B, H, W, C, kh, kw, stride, dtype, &g)) return rc;
+  const int64_t total = B * H * W * (C / 4);
+  const unsigned grid = (unsigned)adnm_cdiv(total, kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  const double es = dtype == ADNM_F32 ? 4.0 : 2.0;
+  ADNM_PROF("maxpool_bwd", st, es * C * B * (2.0 * H * W + (double)g.Ho * g.Wo));
+  if (dtype == ADNM_F32)
+    maxpool_bwd_kernel<float><<<grid, kBlock, 0, st>>>((const float*)dy, (const float*)x, (float*)dx, (int)B, (int)H, (int)W, (int)C, g);
+  else
+    maxpool_bwd_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)dy, (const uint16_t*)x, (uint16_t*)dx, (int)B, (int)H, (int)W, (int)C, g);
+  ADNM_CHECK_LAUNCH("maxpool_bwd");
   return ADNM_OK;
 }
 

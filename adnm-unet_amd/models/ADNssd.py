@@ -150,12 +150,11 @@ class Mamba2(nn.Module):
             raise NotImplementedError("ADN-SSD HIP path covers the reference configuration: conv_bias=False, bias=False, d_conv=3")
         if self.learnable_init_states:
             raise NotImplementedError("learnable_init_states is only meaningful on the chunked-scan branch")
-        di = self.d_inner
-        w_in = self.in_proj.weight.index_select(0, self._rows_in)
-        cw = self._effective_taps()
-        czw = ops.tap_major(self.conv2d_z.weight)
-        ln_w = self.norm.weight.index_select(0, self._perm_x)
-        ln_b = self.norm.bias.index_select(0, self._perm_x)
-        w_out = self.alpha1 * self.out_proj.weight.index_select(1, self._cols_out)  # alpha1 on both halves (:459)
+        # one HIP launch builds the kernel-layout tensors (csrc/paramprep.hip); _effective_taps()/_rows_in state the same map in torch
+        w_in, cw, czw, ln_w, ln_b, w_out = ops.adn_prep(
+            self.d_model, self.d_inner, self.ngroups * self.d_state, self.headdim,
+            [self.in_proj.weight, self.conv2d.weight, self.conv_31_x1.weight, self.conv_31_bc1.weight, self.conv_31_x2.weight,
+             self.conv_31_bc2.weight, self.conv_13_x1.weight, self.conv_13_bc1.weight, self.conv_13_x2.weight, self.conv_13_bc2.weight,
+             self.conv2d_z.weight, self.norm.weight, self.norm.bias, self.out_proj.weight, self.alpha1])
         return ops.adn_mixer(u, w_in, cw, None, czw, None, self.dt_bias, self.A_log, self.D, ln_w, ln_b, w_out, H, W,
                              self.headdim, self.ngroups * self.d_state // 2)

@@ -71,21 +71,13 @@ class WTConv2d(nn.Module):
             self.stride_filter = nn.Parameter(torch.ones(in_channels, 1, 1, 1), requires_grad=False)
 
     def _taps(self):
-        """Tap-major fp32 taps with the scales folded in; channels zero-padded to a multiple of 4
-        (the 5-frame input stage) so every kernel works on 16-byte channel quads."""
+        """Tap-major fp32 taps with base_scale / wavelet_scale folded in; channels zero-padded to a multiple of 4
+        (the 5-frame input stage) so every kernel works on 16-byte channel quads.  One HIP launch (csrc/paramprep.hip)."""
         C = self.in_channels
         Cp = (C + 3) // 4 * 4
-        bs = self.base_scale.weight.reshape(C, 1, 1, 1)
-        base = ops.tap_major(_pad_rows(self.base_conv.weight * bs, Cp))
-        bias = None
-        if self.base_conv.bias is not None:
-            bias = _pad_rows(self.base_conv.bias * bs.reshape(C), Cp).float().contiguous()
-        levels = []
-        for conv, sc in zip(self.wavelet_convs, self.wavelet_scale):
-            w = conv.weight * sc.weight.reshape(4 * C, 1, 1, 1)
-            if Cp != C:
-                w = _pad_rows(w.reshape(C, 4, *w.shape[1:]), Cp).reshape(4 * Cp, *w.shape[1:])
-            levels.append(ops.tap_major(w))
+        bias, base, levels = ops.wt_prep(C, Cp, self.kernel_size, self.wt_levels, self.base_conv.bias,
+                                         [self.base_conv.weight] + [c.weight for c in self.wavelet_convs],
+                                         [self.base_scale.weight] + [m.weight for m in self.wavelet_scale])
         return Cp, base, bias, levels
 
     def forward_tokens(self, x, H, W):

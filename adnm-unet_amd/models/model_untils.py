@@ -388,6 +388,8 @@ class DownSample(nn.Module):
     def forward(self, x):
         b, l, d = x.shape
         h, w = _hw(l)
+        if d % 4 == 0 and 2 <= self.ratio <= 4:
+            return ops.maxpool(x, h, w, self.ratio, self.ratio, self.ratio)
         return tokens_of(self.max_pool(nchw_view(x, h, w)))
 
 
@@ -509,12 +511,16 @@ class EncoderToDecoder(nn.Module):
             x = ops.instnorm(x, self.scale, self.shift, self.norm.eps, lib.ACT_NONE)
         else:
             x = self.scale * tokens_of(self.norm(nchw_view(x, h, w))) + self.shift
-        xi = nchw_view(x, h, w)
         a31, a13, a33 = self._avg_pools(x, h, w)
+        if d % 4 == 0:
+            m31, m13, m33 = (nchw_view(ops.maxpool(x, h, w, kh, kw, 1), h, w) for kh, kw in ((3, 1), (1, 3), (3, 3)))
+        else:
+            xi = nchw_view(x, h, w)
+            m31, m13, m33 = self.max_pool_31(xi), self.max_pool_13(xi), self.max_pool_33(xi)
         # the reference applies ffd13/act_func13 to both the 1x3 and the 3x1 branch (:770-777)
-        x1 = self.act_func13(self._pw(self.ffd13, x * tokens_of(self.conv13pool.act(self.conv13pool.conv(self.max_pool_31(xi) + a31)))))
-        x2 = self.act_func13(self._pw(self.ffd13, x * tokens_of(self.conv31pool.act(self.conv31pool.conv(self.max_pool_13(xi) + a13)))))
-        x3 = self.act_func33(self._pw(self.ffd33, x * tokens_of(self.conv33pool.act(self.conv33pool.conv(self.max_pool_33(xi) + a33)))))
+        x1 = self.act_func13(self._pw(self.ffd13, x * tokens_of(self.conv13pool.act(self.conv13pool.conv(m31 + a31)))))
+        x2 = self.act_func13(self._pw(self.ffd13, x * tokens_of(self.conv31pool.act(self.conv31pool.conv(m13 + a13)))))
+        x3 = self.act_func33(self._pw(self.ffd33, x * tokens_of(self.conv33pool.act(self.conv33pool.conv(m33 + a33)))))
         xp = ops.lincomb([x1, x2, x3], [self.alpha1, self.alpha2, self.alpha3], self.gamma)
         return self.mlp(self.ffd.forward_tokens(xp, h, w))
 

@@ -123,6 +123,15 @@ int adnm_haar_dwt(const void* x, int64_t ldx, int64_t cx, void* y, int64_t B, in
 int adnm_haar_idwt(const void* s, const void* ll_add, void* y, int64_t B, int64_t H, int64_t W, int64_t C,
                    int dtype, adnm_stream_t stream);
 
+/* ---------------------------------------------------------------- max pooling, NHWC (K11)
+ * nn.MaxPool2d on tokens: stride == kernel in [2,4] (DownSample, model_untils.py:472-487; floor mode) or stride 1 with
+ * kernel 1x3 / 3x1 / 3x3 and -inf 'same' padding (EncoderToDecoder, model_untils.py:690-719).  x:(B,H,W,C),
+ * y:(B,Ho,Wo,C) contiguous.  bwd recomputes the first arg-max of every window (ATen's tie rule): no index tensor. */
+int adnm_maxpool_fwd(const void* x, void* y, int64_t B, int64_t H, int64_t W, int64_t C, int kh, int kw, int stride,
+                     int dtype, adnm_stream_t stream);
+int adnm_maxpool_bwd(const void* dy, const void* x, void* dx, int64_t B, int64_t H, int64_t W, int64_t C, int kh, int kw,
+                     int stride, int dtype, adnm_stream_t stream);
+
 /* ---------------------------------------------------------------- InstanceNorm2d, NHWC (K8)
  * y = act( scale * (x - mean_{hw}) * rsqrt(var_{hw} + eps) + shift ), per (b,c) plane, no affine,
  * external scalar scale/shift (model_untils.py:90,113,155; nn.InstanceNorm2d at :284,371,741,814).
@@ -168,6 +177,28 @@ int adnm_lincomb_bwd(const void* dy, int64_t lddy, const void* x0, int64_t ld0, 
 int64_t adnm_adamw_ws_bytes(void);
 int adnm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float* state, float lr, float beta1,
                     float beta2, float eps, float weight_decay, float max_norm, void* ws, int64_t ws_bytes,
+                    adnm_stream_t stream);
+
+/* ---------------------------------------------------------------- parameter-side preparation (one launch each way)
+ * ADN-SSD mixer: reference-layout parameters -> kernel-layout tensors (row-permuted in_proj, effective 3x3 taps of
+ * the conv2d / asymmetric 1x3o3x1 chains (ADNssd.py:334,343-346) in tap-major order, permuted LayerNorm weights,
+ * alpha1 * column-permuted out_proj (ADNssd.py:459)) and the transpose of that map for the gradients.
+ *   params[15]  = {in_proj.weight, conv2d.weight, conv_31_x1, conv_31_bc1, conv_31_x2, conv_31_bc2, conv_13_x1,
+ *                  conv_13_bc1, conv_13_x2, conv_13_bc2, conv2d_z.weight, norm.weight, norm.bias, out_proj.weight, alpha1}
+ *   prepped[6]  = {w_in (d_in_proj,dm), cw (9,di+2gn), czw (9,di), ln_w (di), ln_b (di), w_out (dm,2di)}
+ * All fp32 device pointers; the tables themselves are host arrays.  gn = ngroups*d_state. */
+int adnm_adnprep_fwd(float* const* params, float* const* prepped, int64_t d_model, int64_t d_inner, int64_t gn,
+                     int64_t headdim, adnm_stream_t stream);
+int64_t adnm_adnprep_bwd_ws_bytes(void);
+int adnm_adnprep_bwd(float* const* params, float* const* gprepped, float* const* dparams, int64_t d_model,
+                     int64_t d_inner, int64_t gn, int64_t headdim, void* ws, int64_t ws_bytes, adnm_stream_t stream);
+/* WTConv2d: taps[k] (K*K, Cgp) = tap-major( w[k] (Cg,K*K) * s[k] (Cg) ), zero-padded from C to Cp channels
+ * (Cg = C for k = 0, the base conv; 4C for the level convs k = 1..levels), bias_t = bias * s[0]
+ * (WTConv2d.py:123,146).  bwd: dw, ds, dbias from the tap gradients. */
+int adnm_wtprep_fwd(float* const* w, float* const* s, float* bias, float* const* taps, float* bias_t, int64_t C,
+                    int64_t Cp, int64_t K, int64_t levels, adnm_stream_t stream);
+int adnm_wtprep_bwd(float* const* w, float* const* s, float* bias, float* const* gtaps, float* gbias_t,
+                    float* const* dw, float* const* ds, float* dbias, int64_t C, int64_t Cp, int64_t K, int64_t levels,
                     adnm_stream_t stream);
 
 #ifdef __cplusplus

@@ -302,3 +302,19 @@ def test_lincomb(M, C, K, use_gamma):
             assert_close(sg[k].grad, so[k].grad, GRAD_TOL, f"ds{k}", atol=1e-4)
     if use_gamma:
         assert_close(gg.grad, go.grad, GRAD_TOL, "dgamma", atol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,W,C,kh,kw,stride", [(2, 16, 16, 32, 2, 2, 2), (4, 128, 128, 32, 2, 2, 2), (2, 9, 7, 8, 2, 2, 2),
+                                                   (2, 8, 8, 16, 3, 1, 1), (2, 8, 8, 16, 1, 3, 1), (1, 5, 6, 12, 3, 3, 1), (2, 4, 4, 1024, 3, 3, 1)])
+def test_maxpool(B, H, W, C, kh, kw, stride):
+    x, = (T("mp.x", (B, H * W, C)),)
+    pad = (0, 0) if stride > 1 else (kh // 2, kw // 2)
+    xo = leaf(x.double())
+    yo = O.seq(F.max_pool2d(O.img(xo, H, W), (kh, kw), stride, pad))
+    cot = T("mp.c", tuple(yo.shape))
+    (yo * cot.double()).sum().backward()
+    xg = leaf(x, DEV)
+    yg = ops.maxpool(xg, H, W, kh, kw, stride)
+    (yg * cot.to(DEV)).sum().backward()
+    assert torch.equal(yg.cpu().double(), yo.detach()), "max pooling is exact"
+    assert_close(xg.grad, xo.grad, 1e-6, "dx")
