@@ -447,14 +447,14 @@ class ADNMixerFn(torch.autograd.Function):
         nh = di // P
         u2 = u.reshape(M, dm)
         u2 = u2 if u2.is_contiguous() else u2.contiguous()
-        proj = torch.mm(u2, w_in.t())  # (M, 2di+2gN+nh)   rocBLAS
+        proj = k_linear(u2, w_in, None)  # (M, 2di+2gN+nh): MFMA tall-skinny kernel at full resolution, library GEMM when tiny
         cat = torch.empty((M, 2 * di), dtype=u.dtype, device=u.device)  # [LN(y) | silu(conv_z(z))]
         k_dwconv_fwd(proj[:, :di], czw, czb, Bsz, H, W, di, 3, lib.ACT_SILU, y=cat[:, di:])
         xbc = k_dwconv_fwd(proj[:, di:di + cx], cw, cb, Bsz, H, W, cx, 3, lib.ACT_SILU)
         y, kv = k_ssd_fwd(xbc[:, :di], xbc[:, di:di + 2 * N], xbc[:, di + 2 * N:], proj[:, di + cx:], dt_bias, A_log, D,
                           Bsz, L, nh, P, N, 2)
         _, mu, rstd = k_rownorm_fwd(y, ln_w, ln_b, None, None, 1e-5, True, out=cat[:, :di])
-        out = torch.mm(cat, w_out.t())
+        out = k_linear(cat, w_out, None)
         ctx.save_for_backward(u2, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, proj, xbc, y, kv, mu, rstd, cat)
         ctx.dims = (Bsz, L, dm, H, W, P, N, di, cx, nh)
         return out.view(Bsz, L, dm)
@@ -466,8 +466,8 @@ class ADNMixerFn(torch.autograd.Function):
         M = Bsz * L
         do = dout.reshape(M, dm)
         do = do if do.is_contiguous() else do.contiguous()
-        dw_out = torch.mm(do.t(), cat)
-        dcat = torch.mm(do, w_out)  # (M, 2di)
+        dw_out, _ = k_linear_dw(do, cat, False)
+        dcat = k_linear_dx(do, w_out)  # (M, 2di)
         dy, dln_w, dln_b, _, _ = k_rownorm_bwd(dcat[:, :di], y, ln_w, ln_b, None, mu, rstd, True, True, False)
         dproj = torch.empty_like(proj)
         dxbc = torch.empty_like(xbc)
@@ -477,8 +477,8 @@ class ADNMixerFn(torch.autograd.Function):
                                    want_bias=cb is not None)
         _, dczw, dczb = k_dwconv_bwd(dcat[:, di:], proj[:, :di], czw, czb, Bsz, H, W, di, 3, lib.ACT_SILU, dx=dproj[:, :di],
                                      want_bias=czb is not None)
-        du = torch.mm(dproj, w_in)
-        dw_in = torch.mm(dproj.t(), u2)
+        du = k_linear_dx(dproj, w_in)
+        dw_in, _ = k_linear_dw(dproj, u2, False)
         return (du.view(Bsz, L, dm), dw_in, dcw, dcb, dczw, dczb, ddtb, dA, dD, dln_w, dln_b, dw_out, None, None, None, None)
 
 
@@ -653,3 +653,97 @@ class MaxPoolFn(torch.autograd.Function):
 
 def maxpool(x, H, W, kh, kw, stride):
     return MaxPoolFn.apply(x, H, W, kh, kw, stride)
+
+
+# ------------------------------------------------------------------------------------------- tall-skinny GEMMs (K6)
+TS_MIN_ROWS = 2048  # below this the library GEMM is as good (and K,N are usually > 256 there anyway)
+
+
+def ts_ok_nt(M, N, K, x):
+    return (x.is_cuda and x.dtype == torch.float32 and M >= TS_MIN_ROWS and lib.query("adnm_tsgemm_supported", M, N, K) == 1)
+
+
+def ts_ok_tn(M, N, K, x):
+    return (x.is_cuda and x.dtype == torch.float32 and M >= TS_MIN_ROWS and lib.query("adnm_tsgemm_tn_supported", M, N, K) == 1)
+
+
+def k_linear(x2, w, bias, out=None):
+    """Y = X W^T (+bias) for row views X (M,K) [stride (ld,1)], W (N,K) contiguous: MFMA tall-skinny kernel when the shape
+    fits, the library GEMM otherwise."""
+    M, K = x2.shape
+    N = w.shape[0]
+    if ts_ok_nt(M, N, K, x2) and x2.stride(0) % 4 == 0:
+        y = out if out is not None else torch.empty((M, N), dtype=x2.dtype, device=x2.device)
+        lib.call("adnm_tsgemm_nt", x2.data_ptr(), x2.stride(0), w.data_ptr(), K, 1, _p(bias), y.data_ptr(), y.stride(0), M, N, K, _stream())
+        return y
+    y = torch.mm(x2, w.t()) if bias is None else torch.addmm(bias, x2, w.t())
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def k_linear_dx(dy2, w, out=None):
+    """dX = dY W for dY (M,N) row view, W (N,K) contiguous."""
+    M, N = dy2.shape
+    K = w.shape[1]
+    if ts_ok_nt(M, K, N, dy2) and dy2.stride(0) % 4 == 0:
+        dx = out if out is not None else torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
+        lib.call("adnm_tsgemm_nt", dy2.data_ptr(), dy2.stride(0), w.data_ptr(), 1, K, None, dx.data_ptr(), dx.stride(0), M, K, N, _stream())
+        return dx
+    dx = torch.mm(dy2, w)
+    if out is not None:
+        out.copy_(dx)
+        return out
+    return dx
+
+
+def k_linear_dw(dy2, x2, want_bias):
+    """dW = dY^T X (N,K), dbias = column sums of dY."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    if ts_ok_tn(M, N, K, x2):
+        dev = x2.device
+        dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+        db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
+        nb = lib.query("adnm_tsgemm_tn_ws_bytes", M, N, K)
+        ws = _ws(nb, dev)
+        lib.call("adnm_tsgemm_tn", dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), dw.data_ptr(), _p(db), ws.data_ptr(), nb, M, N, K,
+                 _stream())
+        return dw, db
+    return torch.mm(dy2.t(), x2), (dy2.sum(0) if want_bias else None)
+
+
+class LinearFn(torch.autograd.Function):
+    """nn.Linear / 1x1 conv on tokens."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        shp = x.shape
+        K = shp[-1]
+        x2 = x.reshape(-1, K)
+        x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
+        w = w.contiguous()
+        y = k_linear(x2, w, bias)
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = bias is not None
+        ctx.shp = shp
+        return y.view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        N = w.shape[0]
+        dy2 = dy.reshape(-1, N)
+        dy2 = dy2 if dy2.stride(-1) == 1 else dy2.contiguous()
+        dx = k_linear_dx(dy2, w).view(ctx.shp) if ctx.needs_input_grad[0] else None
+        dw, db = k_linear_dw(dy2, x2, ctx.has_bias)
+        return dx, dw, db
+
+
+def linear(x, w, bias=None):
+    M = x.numel() // x.shape[-1]
+    if x.is_cuda and M >= TS_MIN_ROWS and x.dtype == torch.float32 and w.dim() == 2 and (
+            lib.query("adnm_tsgemm_supported", M, w.shape[0], w.shape[1]) == 1 or lib.query("adnm_tsgemm_tn_supported", M, w.shape[0], w.shape[1]) == 1):
+        return LinearFn.apply(x, w, bias)
+    return torch.nn.functional.linear(x, w, bias)

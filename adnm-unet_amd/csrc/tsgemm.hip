@@ -1,0 +1,258 @@
+// K6 — the 1x1 / Linear projections of the full-resolution stages as "tall-skinny" fp32 GEMMs on the matrix cores.
+//   Reference call sites: Mamba2.in_proj / out_proj (ADNssd.py:309,461), FeedForward.project_in / project_out
+//   (model_untils.py:193,196), Mlp.fc1/fc2 (:64,67), decoder6_s (ADNMUNet.py:634), OutProj's 1x1 (model_untils.py:831).
+// Shapes: M = B*H*W tokens is huge (65 536 at config 2), K and N are tiny (32..256).  Library GEMMs pick tiles for
+// square problems (measured here: 93 us for 65536x32 @ 32x208, 196 us for the 208x32 weight gradient with a 65 536-long
+// reduction under hipBLASLt); the work is 63 MB of mandatory traffic = 12 us at 5 TB/s and 0.9 GFLOP.
+//
+// Design: v_mfma_f32_16x16x4_f32 (exact fp32, bit-for-bit an fmaf chain — the parity tolerance is untouched).
+//   * nt kernel (forward and input gradient):  Y[M,N] = X[M,K] . Wp[N,K]^T (+bias).  The whole (strided) weight is
+//     staged ONCE per workgroup into LDS in B-fragment order ([col block][k step][lane]) so every B fragment is one
+//     conflict-free ds_read_b32; a wave then streams 16-row blocks of X: K/16 float4 loads per lane (the k index is
+//     permuted identically for A and B, which a dot product does not care about), NB*K/4 MFMAs, NB*4 accumulators.
+//     The input gradient dX = dY . W is the same kernel with the weight read through swapped strides.
+//   * tn kernel (weight gradient):  dW[N,K] = sum_m dY[m,N]^T X[m,K]: per-wave accumulators for the whole N x K result
+//     (<= 32 blocks of 16x16), a 64-B segment of every dY / X row per MFMA, waves folded through LDS, one fp32
+//     partial per workgroup, deterministic fold (no atomics).
+#include "adnm_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kBlock = 512;  // 8 waves share one LDS copy of the weight (nt) / fold through one LDS buffer (tn)
+constexpr int kWaves = 8;
+
+// ---------------------------------------------------------------------------------------------- nt: Y = X . Wp^T
+// Wp[n][k] is read at w[n * ws_n + k * ws_k]  (forward: ws_n=K, ws_k=1; input gradient: ws_n=1, ws_k=K_of_weight)
+template <int KQ, int NB>
+__global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                           int64_t ws_n, int64_t ws_k, const float* __restrict__ bias,
+                                                           float* __restrict__ y, int64_t ldy, int64_t M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [NB][K/4][64]
+  const int ksteps = K >> 2;
+  // stage the weight in fragment order: entry (cb, s, lane=(j,kk)) = Wp[cb*16+j][16*(s/4) + 4*kk + (s%4)]
+  for (int idx = threadIdx.x; idx < NB * ksteps * 64; idx += kBlock) {
+    const int lane = idx & 63, s = (idx >> 6) % ksteps, cb = idx / (64 * ksteps);
+    const int n = cb * 16 + (lane & 15), k = 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3);
+    wl[idx] = n < N ? w[(int64_t)n * ws_n + (int64_t)k * ws_k] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  const int64_t nrb = (M + 15) >> 4;
+  for (int64_t rb = (int64_t)blockIdx.x * kWaves + wave; rb < nrb; rb += (int64_t)gridDim.x * kWaves) {
+    const int64_t row = rb * 16 + i;
+    const bool rv = row < M;
+    float4 xa[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) xa[q] = rv ? *reinterpret_cast<const float4*>(x + row * ldx + 16 * q + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 acc[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const float ae[4] = {xa[q].x, xa[q].y, xa[q].z, xa[q].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = q * 4 + e;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], wl[(cb * ksteps + s) * 64 + lane], acc[cb], 0, 0, 0);
+      }
+    }
+    // C layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      const int n = cb * 16 + i;
+      if (n < N) {
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t orow = rb * 16 + kk * 4 + r;
+          if (orow < M) y[orow * ldy + n] = acc[cb][r] + bv;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- tn: dW = dY^T . X
+// part[blockIdx.x][n][k]; A = dY^T (16 n x 4 m), B = X (4 m x 16 k)
+template <int NBN, int NBK>
+__global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                                                           int64_t ldx, float* __restrict__ part, float* __restrict__ bpart, int64_t M,
+                                                           int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // NBN*NBK*256 + NBN*16
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  f32x4 acc[NBN][NBK];
+  float bsum[NBN];
+#pragma unroll
+  for (int a = 0; a < NBN; ++a) {
+    bsum[a] = 0.f;
+#pragma unroll
+    for (int b = 0; b < NBK; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int64_t nmb = (M + 3) >> 2;
+  for (int64_t mb = (int64_t)blockIdx.x * kWaves + wave; mb < nmb; mb += (int64_t)gridDim.x * kWaves) {
+    const int64_t m = mb * 4 + kk;
+    const bool mv = m < M;
+    float av[NBN], bv[NBK];
+#pragma unroll
+    for (int a = 0; a < NBN; ++a) {
+      const int n = a * 16 + i;
+      av[a] = (mv && n < N) ? dy[m * lddy + n] : 0.f;
+      bsum[a] += av[a];
+    }
+#pragma unroll
+    for (int b = 0; b < NBK; ++b) {
+      const int k = b * 16 + i;
+      bv[b] = (mv && k < K) ? x[m * ldx + k] : 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < NBN; ++a)
+#pragma unroll
+      for (int b = 0; b < NBK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+  }
+  // bias gradient: lanes with the same i (n) but different kk hold different m's
+#pragma unroll
+  for (int a = 0; a < NBN; ++a) bsum[a] += __shfl_xor(bsum[a], 16, 64), bsum[a] += __shfl_xor(bsum[a], 32, 64);
+  // fold the waves through ONE LDS buffer, one wave per round (keeps LDS at N*K floats -> several blocks per CU)
+  constexpr int kAcc = NBN * NBK * 256;
+  for (int wv = 1; wv < kWaves; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int a = 0; a < NBN; ++a)
+#pragma unroll
+        for (int b = 0; b < NBK; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sm[((a * NBK + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+      if (kk == 0)
+#pragma unroll
+        for (int a = 0; a < NBN; ++a) sm[kAcc + a * 16 + i] = bsum[a];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int a = 0; a < NBN; ++a) {
+#pragma unroll
+        for (int b = 0; b < NBK; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[a][b][r] += sm[((a * NBK + b) * 4 + r) * 64 + lane];
+        if (kk == 0) bsum[a] += sm[kAcc + a * 16 + i];
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    float* dst = part + (int64_t)blockIdx.x * N * K;
+#pragma unroll
+    for (int a = 0; a < NBN; ++a) {
+#pragma unroll
+      for (int b = 0; b < NBK; ++b) {
+        const int k = b * 16 + i;  // C layout: col = lane&15 -> k, row = kk*4+r -> n
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = a * 16 + kk * 4 + r;
+          if (n < N && k < K) dst[(int64_t)n * K + k] = acc[a][b][r];
+        }
+      }
+      if (bpart && kk == 0 && a * 16 + i < N) bpart[(int64_t)blockIdx.x * N + a * 16 + i] = bsum[a];
+    }
+  }
+}
+
+int nt_blocks(int64_t M) {
+  int64_t b = adnm_cdiv(adnm_cdiv(M, 16), kWaves * 2);  // ~2 row blocks per wave, >= 4 waves per SIMD in flight
+  if (b > 1024) b = 1024;
+  return (int)(b < 1 ? 1 : b);
+}
+int tn_blocks(int64_t M) {
+  int64_t b = adnm_cdiv(adnm_cdiv(M, 4), kWaves * 8);  // >= 8 MFMA rounds per wave
+  if (b > 256) b = 256;
+  return (int)(b < 1 ? 1 : b);
+}
+
+template <int KQ, int NB>
+void launch_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, float* y, int64_t ldy, int64_t M,
+               int N, int K, hipStream_t st) {
+  const size_t smem = (size_t)NB * (K / 4) * 64 * sizeof(float);
+  ADNM_PROF("tsgemm_nt", st, 4.0 * ((double)M * (K + N) + (double)N * K));
+  tsgemm_nt_kernel<KQ, NB><<<nt_blocks(M), kBlock, smem, st>>>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, N, K);
+}
+
+template <int NBN, int NBK>
+void launch_tn(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* part, float* bpart, int64_t M, int N, int K, int nblk,
+               hipStream_t st) {
+  const size_t smem = (size_t)(NBN * NBK * 256 + NBN * 16) * sizeof(float);
+  ADNM_PROF("tsgemm_tn", st, 4.0 * ((double)M * (K + N) + (double)N * K));
+  tsgemm_tn_kernel<NBN, NBK><<<nblk, kBlock, smem, st>>>(dy, lddy, x, ldx, part, bpart, M, N, K);
+}
+
+inline int pick(int v, const int* opts, int n) {
+  for (int k = 0; k < n; ++k)
+    if (v <= opts[k]) return opts[k];
+  return -1;
+}
+const int kKQ[] = {1, 2, 4, 8, 13, 16};
+const int kNB[] = {1, 2, 4, 8, 13, 16};
+
+}  // namespace
+
+extern "C" int adnm_tsgemm_supported(int64_t M, int64_t N, int64_t K) {
+  if (M < 1 || N < 1 || K < 16 || K % 16 || K > 256 || N > 256) return 0;
+  const int nb = pick((int)adnm_cdiv(N, 16), kNB, 6);
+  if (pick((int)(K / 16), kKQ, 6) != K / 16) return 0;  // K/16 must be one of the instantiated depths
+  return nb > 0 && (size_t)nb * (K / 4) * 64 * 4 <= 160 * 1024 ? 1 : 0;
+}
+
+// Y[M,N] = X[M,K] . Wp^T (+bias), Wp[n][k] = w[n*ws_n + k*ws_k].  K % 16 == 0, K <= 256, N <= 256.
+extern "C" int adnm_tsgemm_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, float* y,
+                              int64_t ldy, int64_t M, int64_t N, int64_t K, adnm_stream_t stream) {
+  ADNM_REQUIRE(x && w && y, "tsgemm_nt: null pointer");
+  ADNM_REQUIRE(adnm_tsgemm_supported(M, N, K), "tsgemm_nt: unsupported shape M=%lld N=%lld K=%lld (need K%%16==0, K<=256, N<=256)", (long long)M,
+               (long long)N, (long long)K);
+  ADNM_REQUIRE(ldx >= K && ldx % 4 == 0 && ldy >= N, "tsgemm_nt: bad row strides");
+  const int kq = pick((int)(K / 16), kKQ, 6), nb = pick((int)adnm_cdiv(N, 16), kNB, 6);
+  ADNM_REQUIRE(kq == K / 16, "tsgemm_nt: K/16=%lld not in {1,2,4,8,13,16}", (long long)(K / 16));
+  hipStream_t st = (hipStream_t)stream;
+#define NT(KQ, NB) if (kq == KQ && nb == NB) launch_nt<KQ, NB>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, (int)N, (int)K, st)
+#define NT_ROW(KQ) NT(KQ, 1); NT(KQ, 2); NT(KQ, 4); NT(KQ, 8); NT(KQ, 13); NT(KQ, 16)
+  NT_ROW(1); NT_ROW(2); NT_ROW(4); NT_ROW(8); NT_ROW(13); NT_ROW(16);
+#undef NT_ROW
+#undef NT
+  ADNM_CHECK_LAUNCH("tsgemm_nt");
+  return ADNM_OK;
+}
+
+extern "C" int adnm_tsgemm_tn_supported(int64_t M, int64_t N, int64_t K) {
+  if (M < 1 || N < 1 || K < 1 || N > 256 || K > 256) return 0;
+  const int a = pick((int)adnm_cdiv(N, 16), kNB, 6), b = pick((int)adnm_cdiv(K, 16), kNB, 6);
+  return a > 0 && b > 0 && a * b <= 32 ? 1 : 0;
+}
+extern "C" int64_t adnm_tsgemm_tn_ws_bytes(int64_t M, int64_t N, int64_t K) { return (int64_t)tn_blocks(M) * (N * K + N) * (int64_t)sizeof(float); }
+
+// dW[N,K] = dY[M,N]^T . X[M,K]  (+ dbias[N] = column sums of dY when dbias != NULL).  OVERWRITES dW / dbias.
+extern "C" int adnm_tsgemm_tn(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* dbias, void* ws, int64_t ws_bytes,
+                              int64_t M, int64_t N, int64_t K, adnm_stream_t stream) {
+  ADNM_REQUIRE(dy && x && dw, "tsgemm_tn: null pointer");
+  ADNM_REQUIRE(adnm_tsgemm_tn_supported(M, N, K), "tsgemm_tn: unsupported shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+  ADNM_REQUIRE(lddy >= N && ldx >= K, "tsgemm_tn: bad row strides");
+  if (!ws || ws_bytes < adnm_tsgemm_tn_ws_bytes(M, N, K)) {
+    adnm_set_error("tsgemm_tn: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_tsgemm_tn_ws_bytes(M, N, K));
+    return ADNM_EWORKSPACE;
+  }
+  const int a = pick((int)adnm_cdiv(N, 16), kNB, 6), b = pick((int)adnm_cdiv(K, 16), kNB, 6);
+  const int nblk = tn_blocks(M);
+  float* part = (float*)ws;
+  float* bpart = dbias ? part + (int64_t)nblk * N * K : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+#define TN(A, B) if (a == A && b == B) launch_tn<A, B>(dy, lddy, x, ldx, part, bpart, M, (int)N, (int)K, nblk, st)
+  TN(1, 1); TN(1, 2); TN(1, 4); TN(1, 8); TN(1, 13); TN(1, 16); TN(2, 1); TN(2, 2); TN(2, 4); TN(2, 8); TN(2, 13); TN(2, 16);
+  TN(4, 1); TN(4, 2); TN(4, 4); TN(4, 8); TN(8, 1); TN(8, 2); TN(8, 4); TN(13, 1); TN(13, 2); TN(16, 1); TN(16, 2);
+#undef TN
+  ADNM_CHECK_LAUNCH("tsgemm_tn");
+  adnm_launch_fold("tsgemm_tn_fold", part, nblk, (int)(N * K), {dw, (int)(N * K)}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
+  if (dbias) adnm_launch_fold("tsgemm_tn_fold", bpart, nblk, (int)N, {dbias, (int)N}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
+  ADNM_CHECK_LAUNCH("tsgemm_tn_fold");
+  return ADNM_OK;
+}

@@ -106,7 +106,8 @@ class Mlp(nn.Module):
         self.act2 = act_func()
 
     def forward(self, x):
-        return self.drop(self.fc2(self.drop(self.act1(self.fc1(x)))))
+        h = self.drop(self.act1(ops.linear(x, self.fc1.weight, self.fc1.bias)))
+        return self.drop(ops.linear(h, self.fc2.weight, self.fc2.bias))
 
 
 class Swish(nn.Module):
@@ -164,7 +165,7 @@ class Conv2dLayer(nn.Module):
         elif self._is_depthwise_same():
             x = ops.dwconv(x, self.conv.weight, self.conv.bias, h, w, lib.ACT_NONE)
         elif self._is_pointwise():
-            x = F.linear(x, self.conv.weight.reshape(self.conv.out_channels, -1), self.conv.bias)
+            x = ops.linear(x, self.conv.weight.reshape(self.conv.out_channels, -1), self.conv.bias)
         else:
             x = tokens_of(self.conv(nchw_view(x, h, w)))
         if self.norm:

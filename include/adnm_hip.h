@@ -179,6 +179,21 @@ int adnm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, flo
                     float beta2, float eps, float weight_decay, float max_norm, void* ws, int64_t ws_bytes,
                     adnm_stream_t stream);
 
+/* ---------------------------------------------------------------- tall-skinny fp32 GEMMs on MFMA (K6)
+ * The Linear / 1x1 projections of the full-resolution stages (ADNssd.py:309,461; model_untils.py:64,67,193,196,831;
+ * ADNMUNet.py:634): M = B*H*W tokens, K,N <= 256.  v_mfma_f32_16x16x4_f32: exact fp32 (an fmaf chain).
+ *   nt: Y[M,N] = X[M,K] . Wp^T (+bias[N]),  Wp[n][k] = w[n*ws_n + k*ws_k]   (forward: ws_n=K, ws_k=1;
+ *       input gradient dX = dY . W: call with X:=dY, N:=K_w, K:=N_w, ws_n=1, ws_k=K_w).  K % 16 == 0.
+ *   tn: dW[N,K] = dY[M,N]^T . X[M,K], dbias[N] = column sums of dY (NULL skips); OVERWRITTEN; ws from *_ws_bytes.
+ * *_supported() return 1 when the shape fits the kernels (callers use the library GEMM otherwise). */
+int adnm_tsgemm_supported(int64_t M, int64_t N, int64_t K);
+int adnm_tsgemm_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, float* y,
+                   int64_t ldy, int64_t M, int64_t N, int64_t K, adnm_stream_t stream);
+int adnm_tsgemm_tn_supported(int64_t M, int64_t N, int64_t K);
+int64_t adnm_tsgemm_tn_ws_bytes(int64_t M, int64_t N, int64_t K);
+int adnm_tsgemm_tn(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* dbias, void* ws,
+                   int64_t ws_bytes, int64_t M, int64_t N, int64_t K, adnm_stream_t stream);
+
 /* ---------------------------------------------------------------- parameter-side preparation (one launch each way)
  * ADN-SSD mixer: reference-layout parameters -> kernel-layout tensors (row-permuted in_proj, effective 3x3 taps of
  * the conv2d / asymmetric 1x3o3x1 chains (ADNssd.py:334,343-346) in tap-major order, permuted LayerNorm weights,

@@ -318,3 +318,39 @@ def test_maxpool(B, H, W, C, kh, kw, stride):
     (yg * cot.to(DEV)).sum().backward()
     assert torch.equal(yg.cpu().double(), yo.detach()), "max pooling is exact"
     assert_close(xg.grad, xo.grad, 1e-6, "dx")
+
+
+# ------------------------------------------------------------------------------------------- tall-skinny MFMA GEMMs (K6)
+@pytest.mark.parametrize("M,K,N,bias", [
+    (4 * 16384, 32, 208, False),   # refiner in_proj
+    (4 * 16384, 128, 32, False),   # refiner out_proj
+    (4 * 16384, 32, 128, True),    # FFN project_in
+    (4 * 16384, 64, 32, True),     # FFN project_out
+    (4 * 16384, 64, 20, False),    # OutProj 1x1 (N not a multiple of 16)
+    (16384, 128, 256, True),       # decoder5 Mlp.fc1
+    (16384, 256, 128, True),       # decoder5 Mlp.fc2 (dW falls back to the library)
+    (4099, 48, 40, True),          # ragged M, odd block counts
+])
+def test_tsgemm_linear(M, K, N, bias):
+    x, w = T("ts.x", (M, K)), T("ts.w", (N, K), 0.3)
+    b = T("ts.b", (N,), 0.2) if bias else None
+    cot = T("ts.c", (M, N))
+    xo, wo = leaf(x.double()), leaf(w.double())
+    bo = leaf(b.double()) if bias else None
+    yo = F.linear(xo, wo, bo)
+    (yo * cot.double()).sum().backward()
+    xg, wg = leaf(x, DEV), leaf(w, DEV)
+    bg = leaf(b, DEV) if bias else None
+    yg = ops.linear(xg, wg, bg)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, 1e-5, "y")
+    assert_close(xg.grad, xo.grad, 1e-5, "dx")
+    assert_close(wg.grad, wo.grad, 1e-4, "dw")
+    if bias:
+        assert_close(bg.grad, bo.grad, 1e-4, "db")
+
+
+def test_tsgemm_is_taken_for_refiner_shapes():
+    assert lib.query("adnm_tsgemm_supported", 65536, 208, 32) == 1 and lib.query("adnm_tsgemm_tn_supported", 65536, 208, 32) == 1
+    assert lib.query("adnm_tsgemm_supported", 65536, 32, 208) == 1     # dX of in_proj: K' = 208 = 13 x 16
+    assert lib.query("adnm_tsgemm_supported", 64, 4672, 1024) == 0     # deep levels stay on the library GEMM
