@@ -125,34 +125,43 @@ __global__ __launch_bounds__(64 * K) void dwconv_wgrad_kernel(const T* __restric
 #pragma unroll
   for (int k = 0; k < K; ++k) aw[k] = f4zero();
   if (cv) {
-    for (int64_t t = (int64_t)blockIdx.y * slots + slot; t < tiles; t += (int64_t)gridDim.y * slots) {
-      const int wt = (int)(t % WT);
-      const int h = (int)((t / WT) % H);
-      const int b = (int)(t / ((int64_t)WT * H));
-      const int hh = h + i - R;
-      if (hh < 0 || hh >= H) continue;
-      const int w0 = wt * TW;
-      float4 g[TW];
+    // two tiles per iteration: both tiles' loads are issued before either is consumed (memory-level parallelism)
+    const int64_t stride = (int64_t)gridDim.y * slots;
+    for (int64_t t0 = (int64_t)blockIdx.y * slots + slot; t0 < tiles; t0 += 2 * stride) {
+      float4 g[2][TW], row[2][TW + K - 1];
+      bool live[2];
 #pragma unroll
-      for (int p = 0; p < TW; ++p) {
-        const int ww = w0 + p;
-        g[p] = ww < W ? Io<T>::ld4(dpre + (((int64_t)b * H + h) * W + ww) * ldd + c) : f4zero();
+      for (int u = 0; u < 2; ++u) {
+        const int64_t t = t0 + u * stride;
+        const int wt = (int)(t % WT);
+        const int h = (int)((t / WT) % H);
+        const int b = (int)(t / ((int64_t)WT * H));
+        const int hh = h + i - R;
+        live[u] = t < tiles && hh >= 0 && hh < H;
+        const int w0 = wt * TW;
+#pragma unroll
+        for (int p = 0; p < TW; ++p) {
+          const int ww = w0 + p;
+          g[u][p] = (live[u] && ww < W) ? Io<T>::ld4(dpre + (((int64_t)b * H + h) * W + ww) * ldd + c) : f4zero();
+        }
+        const T* xr = x + ((int64_t)b * H + (live[u] ? hh : 0)) * W * ldx + c;
+#pragma unroll
+        for (int j = 0; j < TW + K - 1; ++j) {
+          const int ww = w0 + j - R;
+          row[u][j] = (live[u] && ww >= 0 && ww < W) ? Io<T>::ld4(xr + (int64_t)ww * ldx) : f4zero();
+        }
       }
-      if (i == R) {
 #pragma unroll
-        for (int p = 0; p < TW; ++p) { ab.x += g[p].x; ab.y += g[p].y; ab.z += g[p].z; ab.w += g[p].w; }
+      for (int u = 0; u < 2; ++u) {
+        if (i == R) {
+#pragma unroll
+          for (int p = 0; p < TW; ++p) { ab.x += g[u][p].x; ab.y += g[u][p].y; ab.z += g[u][p].z; ab.w += g[u][p].w; }
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+          for (int p = 0; p < TW; ++p) fma4(aw[j], g[u][p], row[u][p + j]);
       }
-      const T* xr = x + ((int64_t)b * H + hh) * W * ldx + c;
-      float4 row[TW + K - 1];
-#pragma unroll
-      for (int j = 0; j < TW + K - 1; ++j) {
-        const int ww = w0 + j - R;
-        row[j] = (ww >= 0 && ww < W) ? Io<T>::ld4(xr + (int64_t)ww * ldx) : f4zero();
-      }
-#pragma unroll
-      for (int j = 0; j < K; ++j)
-#pragma unroll
-        for (int p = 0; p < TW; ++p) fma4(aw[j], g[p], row[p + j]);
     }
   }
   float* dst = part + (int64_t)blockIdx.y * (NT + 1) * C;
