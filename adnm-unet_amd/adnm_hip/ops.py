@@ -439,7 +439,7 @@ class ADNMixerFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, u, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N):
+    def forward(ctx, u, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk=0, scan_groups=2):
         Bsz, L, dm = u.shape
         M = Bsz * L
         di = czw.shape[1]
@@ -451,18 +451,25 @@ class ADNMixerFn(torch.autograd.Function):
         cat = torch.empty((M, 2 * di), dtype=u.dtype, device=u.device)  # [LN(y) | silu(conv_z(z))]
         k_dwconv_fwd(proj[:, :di], czw, czb, Bsz, H, W, di, 3, lib.ACT_SILU, y=cat[:, di:])
         xbc = k_dwconv_fwd(proj[:, di:di + cx], cw, cb, Bsz, H, W, cx, 3, lib.ACT_SILU)
-        y, kv = k_ssd_fwd(xbc[:, :di], xbc[:, di:di + 2 * N], xbc[:, di + 2 * N:], proj[:, di + cx:], dt_bias, A_log, D,
-                          Bsz, L, nh, P, N, 2)
+        if scan_chunk == 0:   # linear_attn_duality=True: the global reduction (K1), both halves in one launch
+            y, kv = k_ssd_fwd(xbc[:, :di], xbc[:, di:di + 2 * N], xbc[:, di + 2 * N:], proj[:, di + cx:], dt_bias, A_log, D,
+                              Bsz, L, nh, P, N, 2)
+        else:                 # chunked scan (K1b): even half forward in time, odd half backward (ADNssd.py:416-439)
+            y = torch.empty((M, di), dtype=u.dtype, device=u.device)
+            Ns = N // scan_groups
+            kv = torch.stack([k_ssd_scan_fwd(xbc[:, e * P:di], 2 * P, xbc[:, di + e * N:di + (e + 1) * N], xbc[:, di + 2 * N + e * N:di + 2 * N + (e + 1) * N],
+                                             proj[:, di + cx + e:], 2, dt_bias[e:], A_log[e:], D[e:], 2, y[:, e * P:], 2 * P, Bsz, L, nh // 2, P, Ns,
+                                             scan_groups, scan_chunk, e == 1) for e in (0, 1)])
         _, mu, rstd = k_rownorm_fwd(y, ln_w, ln_b, None, None, 1e-5, True, out=cat[:, :di])
         out = k_linear(cat, w_out, None)
         ctx.save_for_backward(u2, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, proj, xbc, y, kv, mu, rstd, cat)
-        ctx.dims = (Bsz, L, dm, H, W, P, N, di, cx, nh)
+        ctx.dims = (Bsz, L, dm, H, W, P, N, di, cx, nh, scan_chunk, scan_groups)
         return out.view(Bsz, L, dm)
 
     @staticmethod
     def backward(ctx, dout):
         (u2, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, proj, xbc, y, kv, mu, rstd, cat) = ctx.saved_tensors
-        Bsz, L, dm, H, W, P, N, di, cx, nh = ctx.dims
+        Bsz, L, dm, H, W, P, N, di, cx, nh, scan_chunk, scan_groups = ctx.dims
         M = Bsz * L
         do = dout.reshape(M, dm)
         do = do if do.is_contiguous() else do.contiguous()
@@ -471,19 +478,28 @@ class ADNMixerFn(torch.autograd.Function):
         dy, dln_w, dln_b, _, _ = k_rownorm_bwd(dcat[:, :di], y, ln_w, ln_b, None, mu, rstd, True, True, False)
         dproj = torch.empty_like(proj)
         dxbc = torch.empty_like(xbc)
-        ddtb, dA, dD = k_ssd_bwd(dy, xbc[:, :di], xbc[:, di:di + 2 * N], xbc[:, di + 2 * N:], proj[:, di + cx:], dt_bias, A_log, D, kv,
-                                 dxbc[:, :di], dxbc[:, di:di + 2 * N], dxbc[:, di + 2 * N:], dproj[:, di + cx:], Bsz, L, nh, P, N, 2)
+        if scan_chunk == 0:
+            ddtb, dA, dD = k_ssd_bwd(dy, xbc[:, :di], xbc[:, di:di + 2 * N], xbc[:, di + 2 * N:], proj[:, di + cx:], dt_bias, A_log, D, kv,
+                                     dxbc[:, :di], dxbc[:, di:di + 2 * N], dxbc[:, di + 2 * N:], dproj[:, di + cx:], Bsz, L, nh, P, N, 2)
+        else:
+            Ns = N // scan_groups
+            parts = [k_ssd_scan_bwd(dy[:, e * P:], 2 * P, xbc[:, e * P:di], 2 * P, xbc[:, di + e * N:di + (e + 1) * N],
+                                    xbc[:, di + 2 * N + e * N:di + 2 * N + (e + 1) * N], proj[:, di + cx + e:], 2, dt_bias[e:], A_log[e:], D[e:], 2,
+                                    kv[e], dxbc[:, e * P:di], 2 * P, dxbc[:, di + e * N:di + (e + 1) * N],
+                                    dxbc[:, di + 2 * N + e * N:di + 2 * N + (e + 1) * N], dproj[:, di + cx + e:], 2, Bsz, L, nh // 2, P, Ns,
+                                    scan_groups, scan_chunk, e == 1) for e in (0, 1)]
+            ddtb, dA, dD = (torch.stack((parts[0][k], parts[1][k]), dim=1).reshape(nh) for k in range(3))
         _, dcw, dcb = k_dwconv_bwd(dxbc, proj[:, di:di + cx], cw, cb, Bsz, H, W, cx, 3, lib.ACT_SILU, dx=dproj[:, di:di + cx],
                                    want_bias=cb is not None)
         _, dczw, dczb = k_dwconv_bwd(dcat[:, di:], proj[:, :di], czw, czb, Bsz, H, W, di, 3, lib.ACT_SILU, dx=dproj[:, :di],
                                      want_bias=czb is not None)
         du = k_linear_dx(dproj, w_in)
         dw_in, _ = k_linear_dw(dproj, u2, False)
-        return (du.view(Bsz, L, dm), dw_in, dcw, dcb, dczw, dczb, ddtb, dA, dD, dln_w, dln_b, dw_out, None, None, None, None)
+        return (du.view(Bsz, L, dm), dw_in, dcw, dcb, dczw, dczb, ddtb, dA, dD, dln_w, dln_b, dw_out, None, None, None, None, None, None)
 
 
-def adn_mixer(u, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N):
-    return ADNMixerFn.apply(u, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N)
+def adn_mixer(u, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk=0, scan_groups=2):
+    return ADNMixerFn.apply(u, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk, scan_groups)
 
 
 class LinCombFn(torch.autograd.Function):
@@ -747,3 +763,62 @@ def linear(x, w, bias=None):
             lib.query("adnm_tsgemm_supported", M, w.shape[0], w.shape[1]) == 1 or lib.query("adnm_tsgemm_tn_supported", M, w.shape[0], w.shape[1]) == 1):
         return LinearFn.apply(x, w, bias)
     return torch.nn.functional.linear(x, w, bias)
+
+
+# ------------------------------------------------------------------------------------------- K1b chunked scan
+def k_ssd_scan_fwd(x, xhs, Bm, Cm, dt, dths, dt_bias, A_log, D, phs, y, yhs, B, L, H, P, N, G, chunk, reverse):
+    """x / y: row views whose element (row, h, p) sits at [row, h*hs + p]; Bm, Cm (M, G*N) row views; dt (M, .) row view."""
+    dev = x.device
+    NC = (L + chunk - 1) // chunk
+    S_in = torch.empty((B, H, NC, P, N), dtype=torch.float32, device=dev)
+    nb = lib.query("adnm_ssd_scan_ws_bytes", B, L, H, N, chunk, 0)
+    ws = _ws(nb, dev)
+    px, ldx = _rows(x); pb, ldb = _rows(Bm); pc, ldc = _rows(Cm); pt, ldt = _rows(dt); py, ldy = _rows(y)
+    lib.call("adnm_ssd_scan_fwd", px, ldx, xhs, pb, ldb, pc, ldc, pt, ldt, dths, _p(dt_bias), _p(A_log), _p(D), phs, py, ldy, yhs,
+             S_in.data_ptr(), ws.data_ptr(), nb, B, L, H, P, N, G, chunk, int(reverse), _dt(x), _stream())
+    return S_in
+
+
+def k_ssd_scan_bwd(dy, dyhs, x, xhs, Bm, Cm, dt, dths, dt_bias, A_log, D, phs, S_in, dx, dxhs, dBm, dCm, ddt, ddths, B, L, H, P, N, G, chunk,
+                   reverse):
+    dev = x.device
+    dbias, dA, dD = (torch.empty(H, dtype=torch.float32, device=dev) for _ in range(3))
+    nb = lib.query("adnm_ssd_scan_ws_bytes", B, L, H, N, chunk, 1)
+    ws = _ws(nb, dev)
+    pdy, lddy = _rows(dy); px, ldx = _rows(x); pb, ldb = _rows(Bm); pc, ldc = _rows(Cm); pt, ldt = _rows(dt)
+    pdx, lddx = _rows(dx); pdb, lddb = _rows(dBm); pdc, lddc = _rows(dCm); pdt, ldddt = _rows(ddt)
+    lib.call("adnm_ssd_scan_bwd", pdy, lddy, dyhs, px, ldx, xhs, pb, ldb, pc, ldc, pt, ldt, dths, _p(dt_bias), _p(A_log), _p(D), phs,
+             S_in.data_ptr(), pdx, lddx, dxhs, pdb, lddb, pdc, lddc, pdt, ldddt, ddths, dbias.data_ptr(), dA.data_ptr(), dD.data_ptr(),
+             ws.data_ptr(), nb, B, L, H, P, N, G, chunk, int(reverse), _dt(x), _stream())
+    return dbias, dA, dD
+
+
+class SSDScanFn(torch.autograd.Function):
+    """Stand-alone K1b: y = chunk_scan(x (B,L,H,P), Bm/Cm (B,L,G*N), dt_raw (B,L,H), dt_bias, A_log, D (H))."""
+
+    @staticmethod
+    def forward(ctx, x, Bm, Cm, dt_raw, dt_bias, A_log, D, G, chunk, reverse):
+        B, L, H, P = x.shape
+        N = Bm.shape[-1] // G
+        M = B * L
+        xs, bs, cs, ts = x.reshape(M, H * P).contiguous(), Bm.reshape(M, -1).contiguous(), Cm.reshape(M, -1).contiguous(), dt_raw.reshape(M, H).contiguous()
+        _need_gpu(xs)
+        y = torch.empty_like(xs)
+        S_in = k_ssd_scan_fwd(xs, P, bs, cs, ts, 1, dt_bias, A_log, D, 1, y, P, B, L, H, P, N, G, chunk, reverse)
+        ctx.save_for_backward(xs, bs, cs, ts, dt_bias, A_log, D, S_in)
+        ctx.dims = (B, L, H, P, N, G, chunk, reverse)
+        return y.view(B, L, H, P)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, bs, cs, ts, dt_bias, A_log, D, S_in = ctx.saved_tensors
+        B, L, H, P, N, G, chunk, reverse = ctx.dims
+        M = B * L
+        dy2 = dy.reshape(M, H * P).contiguous()
+        dx, dB, dC, ddt = torch.empty_like(xs), torch.empty_like(bs), torch.empty_like(cs), torch.empty_like(ts)
+        dbias, dA, dD = k_ssd_scan_bwd(dy2, P, xs, P, bs, cs, ts, 1, dt_bias, A_log, D, 1, S_in, dx, P, dB, dC, ddt, 1, B, L, H, P, N, G, chunk, reverse)
+        return dx.view(B, L, H, P), dB.view(B, L, -1), dC.view(B, L, -1), ddt.view(B, L, H), dbias, dA, dD, None, None, None
+
+
+def ssd_scan(x, Bm, Cm, dt_raw, dt_bias, A_log, D, groups=1, chunk=256, reverse=False):
+    return SSDScanFn.apply(x, Bm, Cm, dt_raw, dt_bias, A_log, D, groups, chunk, reverse)

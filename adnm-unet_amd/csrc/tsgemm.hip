@@ -30,11 +30,18 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
                                                            float* __restrict__ y, int64_t ldy, int64_t M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [NB][K/4][64]
   const int ksteps = K >> 2;
-  // stage the weight in fragment order: entry (cb, s, lane=(j,kk)) = Wp[cb*16+j][16*(s/4) + 4*kk + (s%4)]
-  for (int idx = threadIdx.x; idx < NB * ksteps * 64; idx += kBlock) {
-    const int lane = idx & 63, s = (idx >> 6) % ksteps, cb = idx / (64 * ksteps);
-    const int n = cb * 16 + (lane & 15), k = 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3);
-    wl[idx] = n < N ? w[(int64_t)n * ws_n + (int64_t)k * ws_k] : 0.f;
+  // stage the weight in fragment order: entry (cb, s, lane=(j,kk)) = Wp[cb*16+j][16*(s/4) + 4*kk + (s%4)].
+  // Global reads run along the weight's contiguous axis (k for the forward layout, n for the transposed one).
+  {
+    const int total = NB * 16 * K;
+    for (int idx = threadIdx.x; idx < total; idx += kBlock) {
+      int n, k;
+      if (ws_k == 1) { n = idx / K; k = idx - n * K; }
+      else { k = idx / (NB * 16); n = idx - k * (NB * 16); }
+      const float v = n < N ? w[(int64_t)n * ws_n + (int64_t)k * ws_k] : 0.f;
+      const int cb = n >> 4, j = n & 15, q = k >> 4, kk = (k >> 2) & 3, e = k & 3;
+      wl[(cb * ksteps + (q * 4 + e)) * 64 + kk * 16 + j] = v;
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -202,6 +209,7 @@ extern "C" int adnm_tsgemm_supported(int64_t M, int64_t N, int64_t K) {
   if (M < 1 || N < 1 || K < 16 || K % 16 || K > 256 || N > 256) return 0;
   const int nb = pick((int)adnm_cdiv(N, 16), kNB, 6);
   if (pick((int)(K / 16), kKQ, 6) != K / 16) return 0;  // K/16 must be one of the instantiated depths
+  if (N * K > 8192) return 0;  // the weight must stay a small, register/LDS-resident operand (refiner-family shapes)
   return nb > 0 && (size_t)nb * (K / 4) * 64 * 4 <= 160 * 1024 ? 1 : 0;
 }
 

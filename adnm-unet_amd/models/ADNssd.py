@@ -142,10 +142,13 @@ class Mamba2(nn.Module):
 
     def forward(self, u, H, W, seq_idx=None):
         """u: (B, L, d_model) tokens, L = H*W.  Returns the same shape (ADNssd.py:302-462 of the reference)."""
+        scan_chunk = 0
         if not self.linear_attn_duality:
-            raise NotImplementedError(
-                "linear_attn_duality=False (mamba_ssm chunked scan, ADNssd.py:413-454) is not built yet; "
-                "create_ADNMUNet never takes that branch (ADNMUNet.py:277)")
+            # chunked bidirectional scan (K1b, csrc/ssd_scan.hip).  PARITY UNPINNED: the reference delegates this branch to
+            # un-vendored mamba_ssm Triton kernels (ADNssd.py:413-454); create_ADNMUNet never takes it (ADNMUNet.py:277).
+            if not self.bimamba:
+                raise NotImplementedError("bimamba=False references undefined names in the reference (ADNssd.py:442-454)")
+            scan_chunk = int(self.chunk_size)
         if self.conv2d.bias is not None or self.in_proj.bias is not None or self.d_conv != 3:
             raise NotImplementedError("ADN-SSD HIP path covers the reference configuration: conv_bias=False, bias=False, d_conv=3")
         if self.learnable_init_states:
@@ -157,4 +160,4 @@ class Mamba2(nn.Module):
              self.conv_31_bc2.weight, self.conv_13_x1.weight, self.conv_13_bc1.weight, self.conv_13_x2.weight, self.conv_13_bc2.weight,
              self.conv2d_z.weight, self.norm.weight, self.norm.bias, self.out_proj.weight, self.alpha1])
         return ops.adn_mixer(u, w_in, cw, None, czw, None, self.dt_bias, self.A_log, self.D, ln_w, ln_b, w_out, H, W,
-                             self.headdim, self.ngroups * self.d_state // 2)
+                             self.headdim, self.ngroups * self.d_state // 2, scan_chunk, self.ngroups)

@@ -64,8 +64,6 @@ class Mamba2(nn.Module):
         self.kwargs = kwargs
 
     def forward(self, u, H, W, seq_idx=None):
-        if not self.linear_attn_duality:
-            raise NotImplementedError("linear_attn_duality=False (mamba_ssm chunked scan, Vssd.py:245-275) is not built yet")
         if self.d_conv != 3:
             raise NotImplementedError("only d_conv=3")
         b, l, _ = u.shape
@@ -74,6 +72,21 @@ class Mamba2(nn.Module):
         z, xBC, dt = proj[..., :di], proj[..., di:2 * di + 2 * gn], proj[..., 2 * di + 2 * gn:]
         xBC = ops.dwconv(xBC, self.conv2d.weight, self.conv2d.bias, H, W, lib.ACT_SILU)       # Vssd.py:232-234
         x = xBC[..., :di].reshape(b, l, nh, self.headdim)
-        y = ops.ssd_reduce(x, xBC[..., di:di + gn], xBC[..., di + gn:], dt, self.dt_bias, self.A_log, self.D, self.ngroups)
+        if self.linear_attn_duality:
+            y = ops.ssd_reduce(x, xBC[..., di:di + gn], xBC[..., di + gn:], dt, self.dt_bias, self.A_log, self.D, self.ngroups)
+        else:
+            # chunked bidirectional scan (K1b; PARITY UNPINNED — un-vendored mamba_ssm in the reference, Vssd.py:245-275):
+            # first half of the heads / groups forward in time, second half on the reversed sequence (:248-261)
+            if not self.bimamba or self.ngroups % 2 or nh % 2:
+                raise NotImplementedError("the scan branch is built for bimamba=True with an even number of groups and heads")
+            hh, g2, ds = nh // 2, self.ngroups // 2, self.d_state
+            Bm, Cm = xBC[..., di:di + gn], xBC[..., di + gn:]
+            halves = []
+            for e in (0, 1):
+                sl = slice(e * hh, (e + 1) * hh)
+                gs = slice(e * g2 * ds, (e + 1) * g2 * ds)
+                halves.append(ops.ssd_scan(x[:, :, sl], Bm[..., gs], Cm[..., gs], dt[..., sl], self.dt_bias[sl], self.A_log[sl], self.D[sl],
+                                           g2, int(self.chunk_size), e == 1))
+            y = torch.cat(halves, dim=2)
         y = ops.rownorm(y.reshape(b, l, di), self.norm.weight, self.norm.bias, None, None, self.norm.eps, True) * z  # :280-281
         return self.out_proj(y)

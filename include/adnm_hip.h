@@ -90,6 +90,28 @@ int adnm_ssd_reduce_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx
                         int64_t ws_bytes, int64_t B, int64_t L, int64_t H, int64_t P, int64_t N, int64_t G,
                         int dtype, adnm_stream_t stream);
 
+/* ---------------------------------------------------------------- SSD chunked scan (K1b) — PARITY UNPINNED
+ * The `linear_attn_duality=False` branch (ADNssd.py:413-454, Vssd.py:245-275): mamba_ssm's
+ * mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size, D, z=None) — un-vendored Triton in the reference:
+ *   d_t = exp(dt_t*A_h), S_t = d_t S_{t-1} + dt_t B_t (x) x_t, y_t = C_t.S_t + D_h x_t,  dt = softplus(dt_raw+dt_bias),
+ *   A_h = -exp(A_log[h]); head h reads K/Q group h / (H/G).  reverse=1 scans the sequence backwards (the reference
+ * flips the odd half, ADNssd.py:425-435).  x/y/dx: element (row, h, p) at ptr[row*ld + h*hstride + p];
+ * dt_raw (row, h) at ptr[row*lddt + h*dt_hstride]; dt_bias/A_log/D at [h*p_hstride].  S_in: (B,H,ceil(L/chunk),P,N)
+ * fp32 entering states, written by fwd and read by bwd.  P = 4, N in {8,16}, fp32 only. */
+int64_t adnm_ssd_scan_ws_bytes(int64_t B, int64_t L, int64_t H, int64_t N, int64_t chunk, int backward);
+int adnm_ssd_scan_fwd(const void* x, int64_t ldx, int64_t x_hstride, const void* Bm, int64_t ldb, const void* Cm,
+                      int64_t ldc, const void* dt_raw, int64_t lddt, int64_t dt_hstride, const float* dt_bias,
+                      const float* A_log, const float* D, int64_t p_hstride, void* y, int64_t ldy, int64_t y_hstride,
+                      float* S_in, void* ws, int64_t ws_bytes, int64_t B, int64_t L, int64_t H, int64_t P, int64_t N,
+                      int64_t G, int64_t chunk, int reverse, int dtype, adnm_stream_t stream);
+int adnm_ssd_scan_bwd(const void* dy, int64_t lddy, int64_t dy_hstride, const void* x, int64_t ldx, int64_t x_hstride,
+                      const void* Bm, int64_t ldb, const void* Cm, int64_t ldc, const void* dt_raw, int64_t lddt,
+                      int64_t dt_hstride, const float* dt_bias, const float* A_log, const float* D, int64_t p_hstride,
+                      const float* S_in, void* dx, int64_t lddx, int64_t dx_hstride, void* dBm, int64_t lddb, void* dCm,
+                      int64_t lddc, void* ddt_raw, int64_t ldddt, int64_t ddt_hstride, float* ddt_bias, float* dA_log,
+                      float* dD, void* ws, int64_t ws_bytes, int64_t B, int64_t L, int64_t H, int64_t P, int64_t N,
+                      int64_t G, int64_t chunk, int reverse, int dtype, adnm_stream_t stream);
+
 /* ---------------------------------------------------------------- depthwise conv, NHWC (K4, part of K3)
  * y[b,h,w,c] = act( sum_{i,j} wgt[c,i,j] * x[b,h+i-KH/2,w+j-KW/2,c] + bias[c] ) (+ addend[b,h,w,c])
  * replaces the depthwise nn.Conv2d calls at ADNssd.py:334,343-346,389, Vssd.py:233,

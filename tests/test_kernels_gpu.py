@@ -354,3 +354,39 @@ def test_tsgemm_is_taken_for_refiner_shapes():
     assert lib.query("adnm_tsgemm_supported", 65536, 208, 32) == 1 and lib.query("adnm_tsgemm_tn_supported", 65536, 208, 32) == 1
     assert lib.query("adnm_tsgemm_supported", 65536, 32, 208) == 1     # dX of in_proj: K' = 208 = 13 x 16
     assert lib.query("adnm_tsgemm_supported", 64, 4672, 1024) == 0     # deep levels stay on the library GEMM
+
+
+# ------------------------------------------------------------------------------------------- K1b chunked scan (parity unpinned)
+@pytest.mark.parametrize("B,L,H,N,G,chunk,reverse", [(2, 70, 8, 8, 2, 16, False), (2, 70, 8, 8, 2, 16, True), (1, 257, 4, 16, 1, 64, False),
+                                                     (2, 64, 32, 8, 2, 256, True), (1, 33, 2, 16, 2, 8, False)])
+def test_ssd_scan_vs_sequential_oracle(B, L, H, N, G, chunk, reverse):
+    """fp32 HIP chunked scan vs the oracle's sequential fp64 recurrence (the reference's arithmetic is un-vendored)."""
+    P = 4
+    x, Bm, Cm = T("sc.x", (B, L, H, P)), T("sc.B", (B, L, G * N)), T("sc.C", (B, L, G * N))
+    dt_raw, bias = T("sc.dt", (B, L, H), 2.0) - 2.0, T("sc.bias", (H,), 0.5)
+    A_log, D = T("sc.A", (H,), 1.0) + 1.0, 1 + 0.1 * T("sc.D", (H,))
+    cot = T("sc.cot", (B, L, H, P))
+    ins = [x, Bm, Cm, dt_raw, bias, A_log, D]
+    o = [leaf(t.double()) for t in ins]
+    dt = F.softplus(o[3] + o[4])
+    flip = (lambda t: t.flip(1)) if reverse else (lambda t: t)
+    yo = flip(O.ssd_chunk_scan(flip(o[0]), flip(dt), -torch.exp(o[5]), flip(o[1]), flip(o[2]), o[6], G))
+    (yo * cot.double()).sum().backward()
+    g = [leaf(t, DEV) for t in ins]
+    yg = ops.ssd_scan(*g, G, chunk, reverse)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, OUT_TOL, "y")
+    for name, a, b_ in zip(["dx", "dB", "dC", "ddt", "dbias", "dA_log", "dD"], g, o):
+        assert_close(a.grad, b_.grad, GRAD_TOL, name, atol=1e-6)
+
+
+def test_ssd_scan_chunk_invariance_full_size():
+    """Size-independent property at config-2 size: the result does not depend on the chunk length."""
+    B, L, H, P, N, G = 2, 16384, 8, 4, 8, 2
+    gen = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    x, Bm, Cm, dt = r(B, L, H, P), r(B, L, G * N), r(B, L, G * N), r(B, L, H) - 2
+    bias, A_log, D = torch.zeros(H, device=DEV), torch.ones(H, device=DEV), torch.ones(H, device=DEV)
+    y64 = ops.ssd_scan(x, Bm, Cm, dt, bias, A_log, D, G, 64, False)
+    y256 = ops.ssd_scan(x, Bm, Cm, dt, bias, A_log, D, G, 256, False)
+    assert_close(y64, y256, 2e-6, "chunk invariance")
