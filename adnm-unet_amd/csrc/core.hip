@@ -63,7 +63,9 @@ extern "C" int64_t adnm_prof_collect(char* buf, int64_t buflen) {
   for (auto& r : g_recs) {
     float ms = 0.f;
     if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
-      Agg& a = agg[r.name];
+      char key[160];
+      snprintf(key, sizeof(key), "%s@%.0f", r.name, r.bytes);  // one entry per (kernel, algorithmic bytes per launch) = per shape
+      Agg& a = agg[key];
       a.n += 1;
       a.ms += ms;
       a.bytes += r.bytes;

@@ -43,7 +43,12 @@ __global__ __launch_bounds__(kBlock) void dwconv_kernel(const T* __restrict__ x,
   const int C4 = C >> 2;
   const int WT = (W + TW - 1) / TW;
   const int64_t total = (int64_t)B * H * WT * C4;
-  const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  // XCD-aware block order: consecutive blockIdx round-robin over the 8 XCDs (private L2 each), but the halo rows of a
+  // stencil are shared by VERTICALLY adjacent tiles.  Give every XCD one contiguous band of tiles so that re-reads of
+  // the K-1 halo rows hit that XCD's own L2 (bijective for any grid size).
+  const unsigned nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const unsigned bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+  const int64_t idx = (int64_t)bid * kBlock + threadIdx.x;
   if (idx >= total) return;
   const int cg = (int)(idx % C4);
   int64_t t = idx / C4;
@@ -103,14 +108,19 @@ __global__ __launch_bounds__(kBlock) void dwconv_kernel(const T* __restrict__ x,
 // tile's dpre strip through L1.  lane = (channel quad, pixel slot); grid = (C4/cgb, npb).  No cross-wave reduction:
 // wave i writes taps [i*K, i*K+K) of the block's partial row; the middle wave also writes the bias gradient.
 // part[blockIdx.y, tap, c]  (tap index K*K holds dbias)
+constexpr int kWgSlices = 2;  // waves per tap row: more memory-level parallelism without more partial rows
+
 template <typename T, int K>
-__global__ __launch_bounds__(64 * K) void dwconv_wgrad_kernel(const T* __restrict__ dpre, int64_t ldd, const T* __restrict__ x,
+__global__ __launch_bounds__(64 * K * kWgSlices) void dwconv_wgrad_kernel(const T* __restrict__ dpre, int64_t ldd, const T* __restrict__ x,
                                                               int64_t ldx, float* __restrict__ part, int B, int H, int W, int C,
                                                               int cgb) {
   constexpr int R = K / 2;
   constexpr int NT = K * K;
   const int C4 = C >> 2;
-  const int i = threadIdx.x >> 6;  // tap row of this wave
+  __shared__ __attribute__((aligned(16))) float red[K][K + 1][64][4];
+  const int wv = threadIdx.x >> 6;
+  const int i = wv % K;            // tap row of this wave
+  const int sl = wv / K;           // tile slice of this wave
   const int lane = threadIdx.x & 63;
   const int cgl = lane & (cgb - 1);
   const int slot = lane / cgb;
@@ -125,9 +135,15 @@ __global__ __launch_bounds__(64 * K) void dwconv_wgrad_kernel(const T* __restric
 #pragma unroll
   for (int k = 0; k < K; ++k) aw[k] = f4zero();
   if (cv) {
-    // two tiles per iteration: both tiles' loads are issued before either is consumed (memory-level parallelism)
-    const int64_t stride = (int64_t)gridDim.y * slots;
-    for (int64_t t0 = (int64_t)blockIdx.y * slots + slot; t0 < tiles; t0 += 2 * stride) {
+    // Each block owns a CONTIGUOUS range of tiles (XCD-aware: the ranges of one XCD are adjacent, so the x / dpre rows
+    // shared by its K tap-row waves and by vertically adjacent tiles are served by that XCD's L2), and keeps two tiles
+    // in flight per lane (memory-level parallelism).
+    const unsigned nb = gridDim.y, q8 = nb >> 3, r8 = nb & 7, xcd = blockIdx.y & 7, loc = blockIdx.y >> 3;
+    const int64_t bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    const int64_t tpb = (tiles + nb - 1) / nb;
+    const int64_t tbeg = bid * tpb, tend = (tbeg + tpb < tiles) ? tbeg + tpb : tiles;
+    const int64_t stride = (int64_t)slots * kWgSlices;
+    for (int64_t t0 = tbeg + sl * slots + slot; t0 < tend; t0 += 2 * stride) {
       float4 g[2][TW], row[2][TW + K - 1];
       bool live[2];
 #pragma unroll
@@ -137,7 +153,7 @@ __global__ __launch_bounds__(64 * K) void dwconv_wgrad_kernel(const T* __restric
         const int h = (int)((t / WT) % H);
         const int b = (int)(t / ((int64_t)WT * H));
         const int hh = h + i - R;
-        live[u] = t < tiles && hh >= 0 && hh < H;
+        live[u] = t < tend && hh >= 0 && hh < H;
         const int w0 = wt * TW;
 #pragma unroll
         for (int p = 0; p < TW; ++p) {
@@ -164,14 +180,29 @@ __global__ __launch_bounds__(64 * K) void dwconv_wgrad_kernel(const T* __restric
       }
     }
   }
-  float* dst = part + (int64_t)blockIdx.y * (NT + 1) * C;
+  // fold the pixel slots of a wave, then the tile slices of the block (LDS), then write the block's partial row
 #pragma unroll
   for (int j = 0; j <= K; ++j) {
-    if (j == K && i != R) break;
     float4 v = j < K ? aw[j] : ab;
     v.x = wave_sum_from(v.x, cgb); v.y = wave_sum_from(v.y, cgb);
     v.z = wave_sum_from(v.z, cgb); v.w = wave_sum_from(v.w, cgb);
-    if (lane < cgb && cv) *reinterpret_cast<float4*>(dst + (int64_t)(j < K ? i * K + j : NT) * C + c) = v;
+    if (j < K) aw[j] = v; else ab = v;
+  }
+  if (sl == 1) {
+#pragma unroll
+    for (int j = 0; j <= K; ++j) *reinterpret_cast<float4*>(&red[i][j][lane][0]) = j < K ? aw[j] : ab;
+  }
+  __syncthreads();
+  if (sl == 0) {
+    float* dst = part + (int64_t)blockIdx.y * (NT + 1) * C;
+#pragma unroll
+    for (int j = 0; j <= K; ++j) {
+      if (j == K && i != R) break;
+      float4 v = j < K ? aw[j] : ab;
+      const float4 o = *reinterpret_cast<const float4*>(&red[i][j][lane][0]);
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      if (lane < cgb && cv) *reinterpret_cast<float4*>(dst + (int64_t)(j < K ? i * K + j : NT) * C + c) = v;
+    }
   }
 }
 
@@ -227,9 +258,9 @@ void launch_wgrad(const void* dpre, int64_t ldd, const void* x, int64_t ldx, flo
   const WGeo g = wgeo(B, H, W, C, K);
   const dim3 grid(g.gx, g.npb);
   if (K == 3)
-    { ADNM_PROF("dwconv_wgrad_k3", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 3><<<grid, 64 * 3, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb); }
+    { ADNM_PROF("dwconv_wgrad_k3", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 3><<<grid, 64 * 3 * kWgSlices, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb); }
   else
-    { ADNM_PROF("dwconv_wgrad_k5", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 5><<<grid, 64 * 5, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb); }
+    { ADNM_PROF("dwconv_wgrad_k5", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 5><<<grid, 64 * 5 * kWgSlices, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb); }
   adnm_launch_fold("dwconv_wgrad_fold", part, g.rows, (K * K + 1) * (int)C, {dwgt, K * K * (int)C}, {dbias, (int)C}, {nullptr, 0}, {nullptr, 0}, st);
 }
 

@@ -48,11 +48,20 @@ def parse():
 def collect_profile(lib):
     buf = ctypes.create_string_buffer(1 << 20)  # one call: collecting also clears the records
     lib.query("adnm_prof_collect", buf, len(buf))
-    rows = {}
+    rows = {}  # key "kernel@bytes_per_launch": one entry per kernel AND shape
     for line in buf.value.decode().splitlines():
         name, cnt, ms, nbytes = line.split("\t")
         rows[name] = {"launches": int(cnt), "ms": float(ms), "bytes": float(nbytes)}
     return rows
+
+
+def by_kernel(rows):
+    out = {}
+    for key, r in rows.items():
+        a = out.setdefault(key.split("@")[0], {"launches": 0, "ms": 0.0, "bytes": 0.0})
+        for f in ("launches", "ms", "bytes"):
+            a[f] += r[f]
+    return out
 
 
 def host_cores():
@@ -190,17 +199,19 @@ def main():
 
     if rank == 0:
         total_ms = sum(r["ms"] for r in prof.values()) or 1.0
+        # the dominant kernel = the (kernel, shape) instance with the largest share of the HIP-kernel time
         dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
         roofline = None
         kernels = {}
-        for name, r in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+        for name, r in sorted(by_kernel(prof).items(), key=lambda kv: -kv[1]["ms"]):
             kernels[name] = {"launches_per_step": r["launches"] / args.prof_steps, "ms_per_step": round(r["ms"] / args.prof_steps, 4),
                              "avg_us": round(1e3 * r["ms"] / r["launches"], 2),
                              "GBps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1) if r["ms"] > 0 else None}
         if dom:
             name, r = dom
             ach = r["bytes"] / (r["ms"] * 1e-3) / 1e9
-            roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roofline = {"kernel": name.split("@")[0], "shape_bytes": int(float(name.split("@")[1])), "launches_per_step": r["launches"] / args.prof_steps,
+                        "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                         "avg_launch_us": round(1e3 * r["ms"] / r["launches"], 2),
                         "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"]),
