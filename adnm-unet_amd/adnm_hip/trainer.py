@@ -90,7 +90,8 @@ class FlatTrainer:
         for p in self.used:
             p.grad = None
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: RCCL's watchdog thread may query events while we capture; only this thread's calls are checked
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.static_loss = self._fwd_bwd(self.sx, self.st)
             self._gather()
 

@@ -119,11 +119,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    local = local % torch.cuda.device_count()  # (a 1-GPU rehearsal box runs every rank on device 0, backend gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("ADNM_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from adnm_hip import lib, recipe
     from adnm_hip.trainer import FlatTrainer
@@ -163,7 +168,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float32)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     loss_val = float(loss.detach())
@@ -182,6 +187,10 @@ def main():
 
     # ---- instrumented steps (outside the timed region): per-kernel HIP-event timing inside libadnm_hip
     prof = {}
+    if rank != 0 and args.prof_steps > 0:
+        for _ in range(args.prof_steps):
+            eager_step()  # every rank takes part: the step contains the gradient all-reduce
+        torch.cuda.synchronize()
     if rank == 0 and args.prof_steps > 0:
         lib.query("adnm_prof_enable", 1)
         torch.cuda.synchronize()
