@@ -822,3 +822,34 @@ class SSDScanFn(torch.autograd.Function):
 
 def ssd_scan(x, Bm, Cm, dt_raw, dt_bias, A_log, D, groups=1, chunk=256, reverse=False):
     return SSDScanFn.apply(x, Bm, Cm, dt_raw, dt_bias, A_log, D, groups, chunk, reverse)
+
+
+class IGateFn(torch.autograd.Function):
+    """IntensityGate: silu(enhance * (x - threshold)) with learnable scalars, one pass each way."""
+
+    @staticmethod
+    def forward(ctx, x, enhance, threshold):
+        x = x.contiguous()
+        _need_gpu(x)
+        y = torch.empty_like(x)
+        lib.call("adnm_igate_fwd", x.data_ptr(), enhance.data_ptr(), threshold.data_ptr(), y.data_ptr(), x.numel(), _dt(x), _stream())
+        ctx.save_for_backward(x, enhance, threshold)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, enhance, threshold = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        de, dth = torch.empty_like(enhance), torch.empty_like(threshold)
+        nb = lib.query("adnm_igate_bwd_ws_bytes", x.numel())
+        ws = _ws(nb, x.device)
+        lib.call("adnm_igate_bwd", dy.data_ptr(), x.data_ptr(), enhance.data_ptr(), threshold.data_ptr(), dx.data_ptr(), de.data_ptr(),
+                 dth.data_ptr(), ws.data_ptr(), nb, x.numel(), _dt(x), _stream())
+        return dx, de, dth
+
+
+def igate(x, enhance, threshold):
+    if x.is_cuda and x.numel() % 4 == 0 and x.dtype in _DT and enhance.dtype == torch.float32:
+        return IGateFn.apply(x, enhance, threshold)
+    return torch.nn.functional.silu(enhance * (x - threshold))

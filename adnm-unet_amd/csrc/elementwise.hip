@@ -41,6 +41,48 @@ __global__ __launch_bounds__(kBlock) void gate_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// IntensityGate (model_untils.py:523-532): y = silu(enhance * (x - threshold)), both learnable scalars.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void igate_fwd_kernel(const T* __restrict__ x, const float* __restrict__ enh, const float* __restrict__ thr,
+                                                           T* __restrict__ y, int64_t n4) {
+  const float a = *enh, t = *thr;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    const float4 v = Io<T>::ld4(x + i * 4);
+    Io<T>::st4(y + i * 4, make_float4(siluf_(a * (v.x - t)), siluf_(a * (v.y - t)), siluf_(a * (v.z - t)), siluf_(a * (v.w - t))));
+  }
+}
+
+// part[blockIdx.x] = {sum g*silu'(z)*(x-t), sum g*silu'(z)}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void igate_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ enh,
+                                                           const float* __restrict__ thr, T* __restrict__ dx, float* __restrict__ part,
+                                                           int64_t n4) {
+  __shared__ float sm[2][kBlock / 64];
+  const float a = *enh, t = *thr;
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    const float4 v = Io<T>::ld4(x + i * 4), g = Io<T>::ld4(dy + i * 4);
+    const float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g.x, g.y, g.z, g.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float d = xv[k] - t, gp = gv[k] * silu_gradf_(a * d);
+      o[k] = gp * a;
+      s1 = fmaf(gp, d, s1);
+      s2 += gp;
+    }
+    Io<T>::st4(dx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = s1; sm[1][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 2] = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]);
+    part[blockIdx.x * 2 + 1] = -a * ((sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]));
+  }
+}
+
 unsigned grid_for(int64_t total) {
   int64_t g = adnm_cdiv(total, kBlock);
   return (unsigned)(g < 2048 ? (g < 1 ? 1 : g) : 2048);
@@ -71,5 +113,41 @@ extern "C" int adnm_gate_bwd(const void* dy, int64_t lddy, const void* h, int64_
   else
     { ADNM_PROF("gate_bwd", st, 2.0 * M * F * 5); gate_bwd_kernel<uint16_t><<<grid_for(M * F / 4), kBlock, 0, st>>>((const uint16_t*)dy, lddy, (const uint16_t*)h, ldh, (uint16_t*)dh, lddh, M, (int)F); }
   ADNM_CHECK_LAUNCH("gate_bwd");
+  return ADNM_OK;
+}
+
+extern "C" int64_t adnm_igate_bwd_ws_bytes(int64_t n) { return (int64_t)(n / 4 / kBlock + 1 < 512 ? n / 4 / kBlock + 1 : 512) * 2 * sizeof(float); }
+
+extern "C" int adnm_igate_fwd(const void* x, const float* enhance, const float* threshold, void* y, int64_t n, int dtype, adnm_stream_t stream) {
+  ADNM_REQUIRE(x && enhance && threshold && y, "igate_fwd: null pointer");
+  ADNM_REQUIRE(n > 0 && n % 4 == 0, "igate_fwd: element count %lld must be a positive multiple of 4", (long long)n);
+  ADNM_REQUIRE(dtype == ADNM_F32 || dtype == ADNM_BF16, "igate_fwd: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  ADNM_PROF("igate_fwd", st, (dtype == ADNM_F32 ? 8.0 : 4.0) * n);
+  if (dtype == ADNM_F32) igate_fwd_kernel<float><<<grid_for(n / 4), kBlock, 0, st>>>((const float*)x, enhance, threshold, (float*)y, n / 4);
+  else igate_fwd_kernel<uint16_t><<<grid_for(n / 4), kBlock, 0, st>>>((const uint16_t*)x, enhance, threshold, (uint16_t*)y, n / 4);
+  ADNM_CHECK_LAUNCH("igate_fwd");
+  return ADNM_OK;
+}
+
+extern "C" int adnm_igate_bwd(const void* dy, const void* x, const float* enhance, const float* threshold, void* dx, float* denhance,
+                              float* dthreshold, void* ws, int64_t ws_bytes, int64_t n, int dtype, adnm_stream_t stream) {
+  ADNM_REQUIRE(dy && x && enhance && threshold && dx && denhance && dthreshold, "igate_bwd: null pointer");
+  ADNM_REQUIRE(n > 0 && n % 4 == 0, "igate_bwd: element count %lld must be a positive multiple of 4", (long long)n);
+  ADNM_REQUIRE(dtype == ADNM_F32 || dtype == ADNM_BF16, "igate_bwd: bad dtype %d", dtype);
+  if (!ws || ws_bytes < adnm_igate_bwd_ws_bytes(n)) {
+    adnm_set_error("igate_bwd: workspace too small");
+    return ADNM_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int64_t g = n / 4 / kBlock + 1;
+  const unsigned grid = (unsigned)(g < 512 ? g : 512);
+  {
+    ADNM_PROF("igate_bwd", st, (dtype == ADNM_F32 ? 12.0 : 6.0) * n);
+    if (dtype == ADNM_F32) igate_bwd_kernel<float><<<grid, kBlock, 0, st>>>((const float*)dy, (const float*)x, enhance, threshold, (float*)dx, (float*)ws, n / 4);
+    else igate_bwd_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)dy, (const uint16_t*)x, enhance, threshold, (uint16_t*)dx, (float*)ws, n / 4);
+  }
+  adnm_launch_fold("igate_bwd_fold", (const float*)ws, (int)grid, 2, {denhance, 1}, {dthreshold, 1}, {nullptr, 0}, {nullptr, 0}, st);
+  ADNM_CHECK_LAUNCH("igate_bwd");
   return ADNM_OK;
 }

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const float* __restri
   extern __shared__ __attribute__((aligned(16))) float sm[];  // NBN*NBK*256 + NBN*16
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
+  const int nb0 = blockIdx.y * NBN * 16;  // first output row (n) of this block's tile
   f32x4 acc[NBN][NBK];
   float bsum[NBN];
 #pragma unroll
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const float* __restri
     float av[NBN], bv[NBK];
 #pragma unroll
     for (int a = 0; a < NBN; ++a) {
-      const int n = a * 16 + i;
+      const int n = nb0 + a * 16 + i;
       av[a] = (mv && n < N) ? dy[m * lddy + n] : 0.f;
       bsum[a] += av[a];
     }
@@ -159,11 +160,11 @@ __global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const float* __restri
         const int k = b * 16 + i;  // C layout: col = lane&15 -> k, row = kk*4+r -> n
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int n = a * 16 + kk * 4 + r;
+          const int n = nb0 + a * 16 + kk * 4 + r;
           if (n < N && k < K) dst[(int64_t)n * K + k] = acc[a][b][r];
         }
       }
-      if (bpart && kk == 0 && a * 16 + i < N) bpart[(int64_t)blockIdx.x * N + a * 16 + i] = bsum[a];
+      if (bpart && kk == 0 && nb0 + a * 16 + i < N) bpart[(int64_t)blockIdx.x * N + nb0 + a * 16 + i] = bsum[a];
     }
   }
 }
@@ -189,10 +190,19 @@ void launch_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_
 
 template <int NBN, int NBK>
 void launch_tn(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* part, float* bpart, int64_t M, int N, int K, int nblk,
-               hipStream_t st) {
+               int ntiles, hipStream_t st) {
   const size_t smem = (size_t)(NBN * NBK * 256 + NBN * 16) * sizeof(float);
   ADNM_PROF("tsgemm_tn", st, 4.0 * ((double)M * (K + N) + (double)N * K));
-  tsgemm_tn_kernel<NBN, NBK><<<nblk, kBlock, smem, st>>>(dy, lddy, x, ldx, part, bpart, M, N, K);
+  tsgemm_tn_kernel<NBN, NBK><<<dim3(nblk, ntiles), kBlock, smem, st>>>(dy, lddy, x, ldx, part, bpart, M, N, K);
+}
+
+// tile the N axis so that one block keeps at most 32 accumulator blocks: returns NBN (blocks of 16 rows per tile)
+inline int tn_tile(int nbn_total, int nbk) {
+  int t = 32 / nbk;
+  if (t > 16) t = 16;
+  while (t > 1 && (t & (t - 1))) --t;  // power of two -> an instantiated NBN
+  if (t >= nbn_total) return -1;        // fits without tiling
+  return t < 1 ? 1 : t;
 }
 
 inline int pick(int v, const int* opts, int n) {
@@ -233,9 +243,9 @@ extern "C" int adnm_tsgemm_nt(const float* x, int64_t ldx, const float* w, int64
 }
 
 extern "C" int adnm_tsgemm_tn_supported(int64_t M, int64_t N, int64_t K) {
-  if (M < 1 || N < 1 || K < 1 || N > 256 || K > 256) return 0;
-  const int a = pick((int)adnm_cdiv(N, 16), kNB, 6), b = pick((int)adnm_cdiv(K, 16), kNB, 6);
-  return a > 0 && b > 0 && a * b <= 32 ? 1 : 0;
+  if (M < 1 || N < 1 || K < 1 || N > 1024 || K > 256) return 0;
+  const int b = pick((int)adnm_cdiv(K, 16), kNB, 6);
+  return b > 0 ? 1 : 0;  // N is tiled over blockIdx.y when N/16 * K/16 > 32 accumulator blocks
 }
 extern "C" int64_t adnm_tsgemm_tn_ws_bytes(int64_t M, int64_t N, int64_t K) { return (int64_t)tn_blocks(M) * (N * K + N) * (int64_t)sizeof(float); }
 
@@ -249,12 +259,19 @@ extern "C" int adnm_tsgemm_tn(const float* dy, int64_t lddy, const float* x, int
     adnm_set_error("tsgemm_tn: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_tsgemm_tn_ws_bytes(M, N, K));
     return ADNM_EWORKSPACE;
   }
-  const int a = pick((int)adnm_cdiv(N, 16), kNB, 6), b = pick((int)adnm_cdiv(K, 16), kNB, 6);
+  const int b = pick((int)adnm_cdiv(K, 16), kNB, 6);
+  const int nbn_total = (int)adnm_cdiv(N, 16);
+  int a = pick(nbn_total, kNB, 6), ntiles = 1;
+  if (a < 0 || a * b > 32) {
+    a = tn_tile(nbn_total, b);
+    if (a < 0) a = 1;
+    ntiles = (int)adnm_cdiv(nbn_total, a);
+  }
   const int nblk = tn_blocks(M);
   float* part = (float*)ws;
   float* bpart = dbias ? part + (int64_t)nblk * N * K : nullptr;
   hipStream_t st = (hipStream_t)stream;
-#define TN(A, B) if (a == A && b == B) launch_tn<A, B>(dy, lddy, x, ldx, part, bpart, M, (int)N, (int)K, nblk, st)
+#define TN(A, B) if (a == A && b == B) launch_tn<A, B>(dy, lddy, x, ldx, part, bpart, M, (int)N, (int)K, nblk, ntiles, st)
   TN(1, 1); TN(1, 2); TN(1, 4); TN(1, 8); TN(1, 13); TN(1, 16); TN(2, 1); TN(2, 2); TN(2, 4); TN(2, 8); TN(2, 13); TN(2, 16);
   TN(4, 1); TN(4, 2); TN(4, 4); TN(4, 8); TN(8, 1); TN(8, 2); TN(8, 4); TN(13, 1); TN(13, 2); TN(16, 1); TN(16, 2);
 #undef TN

@@ -414,7 +414,7 @@ class IntensityGate(nn.Module):
         self.act = nn.SiLU()
 
     def forward(self, x):
-        return self.act(self.enhance * (x - self.threshold))
+        return ops.igate(x, self.enhance, self.threshold)  # fused silu(enhance*(x-threshold)) + scalar gradients
 
 
 class Channel_Att_Bridge(nn.Module):
@@ -492,10 +492,14 @@ class EncoderToDecoder(nn.Module):
         if d % 4:
             xi = nchw_view(x, h, w).contiguous()
             return self.avg_pool_31(xi), self.avg_pool_13(xi), self.avg_pool_33(xi)
-        taps = x.new_zeros((3, d, 1, 3, 3))
-        taps[0, :, 0, :, 1] = 1.0 / 3.0   # (3,1): a column
-        taps[1, :, 0, 1, :] = 1.0 / 3.0   # (1,3): a row
-        taps[2] = 1.0 / 9.0
+        key = (x.device, x.dtype)
+        taps = self.__dict__.setdefault("_pool_taps", {}).get(key)
+        if taps is None:  # constants: built once per device
+            taps = torch.zeros((3, d, 1, 3, 3), dtype=torch.float32, device=x.device)
+            taps[0, :, 0, :, 1] = 1.0 / 3.0   # (3,1): a column
+            taps[1, :, 0, 1, :] = 1.0 / 3.0   # (1,3): a row
+            taps[2] = 1.0 / 9.0
+            self.__dict__["_pool_taps"][key] = taps
         return tuple(nchw_view(ops.dwconv(x, taps[i], None, h, w, lib.ACT_NONE), h, w) for i in range(3))
 
     @staticmethod

@@ -174,6 +174,15 @@ int adnm_gate_fwd(const void* h, int64_t ldh, void* y, int64_t ldy, int64_t M, i
 int adnm_gate_bwd(const void* dy, int64_t lddy, const void* h, int64_t ldh, void* dh, int64_t lddh, int64_t M,
                   int64_t F, int dtype, adnm_stream_t stream);
 
+/* ---------------------------------------------------------------- IntensityGate (K11)
+ * y = silu(enhance * (x - threshold)) with both scalars learnable (model_untils.py:523-532; 4 per EncoderToDecoder
+ * + the bridge's gates).  n contiguous elements, n % 4 == 0.  bwd also gives d enhance, d threshold (OVERWRITTEN). */
+int adnm_igate_fwd(const void* x, const float* enhance, const float* threshold, void* y, int64_t n, int dtype,
+                   adnm_stream_t stream);
+int64_t adnm_igate_bwd_ws_bytes(int64_t n);
+int adnm_igate_bwd(const void* dy, const void* x, const float* enhance, const float* threshold, void* dx, float* denhance,
+                   float* dthreshold, void* ws, int64_t ws_bytes, int64_t n, int dtype, adnm_stream_t stream);
+
 /* ---------------------------------------------------------------- fused scalar / channel-affine mixes
  * y[m,c] = gamma[c] * ( s0*x0[m,c] + s1*x1[m,c] + s2*x2[m,c] )      x1,x2 optional (NULL), s_k NULL = 1, gamma NULL = 1
  * replaces the broadcast mul/add chains around the learnable scalars of Block.forward (ADNMUNet.py:152,158,161),

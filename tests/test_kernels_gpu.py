@@ -390,3 +390,18 @@ def test_ssd_scan_chunk_invariance_full_size():
     y64 = ops.ssd_scan(x, Bm, Cm, dt, bias, A_log, D, G, 64, False)
     y256 = ops.ssd_scan(x, Bm, Cm, dt, bias, A_log, D, G, 256, False)
     assert_close(y64, y256, 2e-6, "chunk invariance")
+
+
+def test_igate():
+    x, cot = T("ig.x", (3, 100, 64), 2.0), T("ig.c", (3, 100, 64))
+    e, t = torch.tensor(1.2), torch.tensor(0.15)
+    xo, eo, to = leaf(x.double()), leaf(e.double()), leaf(t.double())
+    yo = O.silu(eo * (xo - to))
+    (yo * cot.double()).sum().backward()
+    xg, eg, tg = leaf(x, DEV), leaf(e, DEV), leaf(t, DEV)
+    yg = ops.igate(xg, eg, tg)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, OUT_TOL, "igate")
+    assert_close(xg.grad, xo.grad, GRAD_TOL, "dx")
+    assert_close(eg.grad, eo.grad, GRAD_TOL, "denhance", atol=1e-5)
+    assert_close(tg.grad, to.grad, GRAD_TOL, "dthreshold", atol=1e-5)
