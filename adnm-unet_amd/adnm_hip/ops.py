@@ -853,3 +853,56 @@ def igate(x, enhance, threshold):
     if x.is_cuda and x.numel() % 4 == 0 and x.dtype in _DT and enhance.dtype == torch.float32:
         return IGateFn.apply(x, enhance, threshold)
     return torch.nn.functional.silu(enhance * (x - threshold))
+
+
+class SkipGateFn(torch.autograd.Function):
+    """EncoderToDecoder's three pooled, gated branches + their mix in 2 launches forward / 5-6 backward
+    (csrc/skipgate.hip).  params: the 18 tensors in the order include/adnm_hip.h documents."""
+
+    @staticmethod
+    def forward(ctx, x, h, w, *params):
+        x = x.contiguous()
+        _need_gpu(x)
+        b, l, c = x.shape
+        params = tuple(p.contiguous() for p in params)
+        pooled = torch.empty((3, b, l, c), dtype=x.dtype, device=x.device)
+        conv = torch.empty_like(pooled)
+        out = torch.empty_like(x)
+        lib.call("adnm_skipgate_fwd", x.data_ptr(), lib.ptr_table(params), pooled.data_ptr(), conv.data_ptr(), out.data_ptr(), b, h, w, c, _stream())
+        ctx.save_for_backward(x, pooled, conv, *params)
+        ctx.hw = (h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, pooled, conv, *params = ctx.saved_tensors
+        h, w = ctx.hw
+        b, l, c = x.shape
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        dp = torch.empty(int(lib.query("adnm_skipgate_grad_floats", c)), dtype=torch.float32, device=x.device)
+        nb = lib.query("adnm_skipgate_bwd_ws_bytes", b, h, w, c)
+        ws = _ws(nb, x.device)
+        lib.call("adnm_skipgate_bwd", dout.data_ptr(), x.data_ptr(), lib.ptr_table(params), pooled.data_ptr(), conv.data_ptr(), dx.data_ptr(),
+                 dp.data_ptr(), ws.data_ptr(), nb, b, h, w, c, _stream())
+        o = [0]
+
+        def take(n, like):
+            v = dp[o[0]:o[0] + n].view_as(like)
+            o[0] += n
+            return v
+        dw0, dw1, dw2 = take(12 * c, params[0]), take(12 * c, params[2]), take(36 * c, params[4])
+        dgamma = take(c, params[17])
+        dfw13, dfb13, dfw33, dfb33 = take(c, params[6]), take(c, params[7]), take(c, params[8]), take(c, params[9])
+        db0, db1, db2 = take(c, params[1]), take(c, params[3]), take(c, params[5])
+        da = [take(1, params[14 + i]) for i in range(3)]
+        de13, dt13, de33, dt33 = (take(1, params[10 + i]) for i in range(4))
+        return (dx, None, None, dw0, db0, dw1, db1, dw2, db2, dfw13, dfb13, dfw33, dfb33, de13, dt13, de33, dt33, da[0], da[1], da[2], dgamma)
+
+
+def skipgate_supported(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 256 == 0
+
+
+def skipgate(x, h, w, params):
+    return SkipGateFn.apply(x, h, w, *params)

@@ -516,6 +516,14 @@ class EncoderToDecoder(nn.Module):
             x = ops.instnorm(x, self.scale, self.shift, self.norm.eps, lib.ACT_NONE)
         else:
             x = self.scale * tokens_of(self.norm(nchw_view(x, h, w))) + self.shift
+        if ops.skipgate_supported(x):  # pools + grouped convs + gates + mix: 2 launches forward, 5-6 backward
+            f13, f33 = self.ffd13.conv, self.ffd33.conv
+            xp = ops.skipgate(x, h, w, (
+                self.conv13pool.conv.weight, self.conv13pool.conv.bias, self.conv31pool.conv.weight, self.conv31pool.conv.bias,
+                self.conv33pool.conv.weight, self.conv33pool.conv.bias, f13.weight.reshape(-1), f13.bias, f33.weight.reshape(-1), f33.bias,
+                self.act_func13.enhance, self.act_func13.threshold, self.act_func33.enhance, self.act_func33.threshold,
+                self.alpha1, self.alpha2, self.alpha3, self.gamma))
+            return self.mlp(self.ffd.forward_tokens(xp, h, w))
         a31, a13, a33 = self._avg_pools(x, h, w)
         if d % 4 == 0:
             m31, m13, m33 = (nchw_view(ops.maxpool(x, h, w, kh, kw, 1), h, w) for kh, kw in ((3, 1), (1, 3), (3, 3)))

@@ -183,6 +183,28 @@ int64_t adnm_igate_bwd_ws_bytes(int64_t n);
 int adnm_igate_bwd(const void* dy, const void* x, const float* enhance, const float* threshold, void* dx, float* denhance,
                    float* dthreshold, void* ws, int64_t ws_bytes, int64_t n, int dtype, adnm_stream_t stream);
 
+/* ---------------------------------------------------------------- EncoderToDecoder's pooled gating core (K12)
+ * model_untils.py:767-787 of the reference, x = the block's normalised tokens (B, H, W, C) fp32 contiguous, C % 256 == 0:
+ *   p_k = MaxPool_k(x) + AvgPool_k(x)      k = 0: (3,1) window, 1: (1,3), 2: (3,3); stride 1, count_include_pad
+ *   c_k = conv_k(p_k)                      conv13pool (1,3) / conv31pool (3,1) / conv33pool (3,3), groups = C/4, with bias
+ *   y_k = IntensityGate_k(ffd_k(x * GELU(c_k)))    ffd13 + act_func13 for k = 0 AND 1 (as the reference), ffd33 + act_func33 for k = 2
+ *   out = gamma * (alpha1 y_0 + alpha2 y_1 + alpha3 y_2)
+ * params: HOST array of 18 device pointers
+ *   [0..5]  conv13pool.weight (C,4,1,3), .bias, conv31pool.weight (C,4,3,1), .bias, conv33pool.weight (C,4,3,3), .bias
+ *   [6..9]  ffd13.weight (C), ffd13.bias, ffd33.weight, ffd33.bias          (1x1 depthwise = per-channel affine)
+ *   [10..13] act_func13.enhance, .threshold, act_func33.enhance, .threshold  (scalars)
+ *   [14..17] alpha1, alpha2, alpha3 (scalars), gamma (C)
+ * pooled, conv: (3, B, H, W, C) each, written by fwd and handed back to bwd.
+ * dparams (OVERWRITTEN), adnm_skipgate_grad_floats(C) floats:
+ *   [d w0 12C | d w1 12C | d w2 36C | d gamma | d ffd13.w | d ffd13.b | d ffd33.w | d ffd33.b | d b0 | d b1 | d b2 (C each) |
+ *    d alpha1..3, d enh13, d thr13, d enh33, d thr33, pad] */
+int adnm_skipgate_fwd(const float* x, const float* const* params, float* pooled, float* conv, float* out, int64_t B, int64_t H, int64_t W,
+                      int64_t C, adnm_stream_t stream);
+int64_t adnm_skipgate_grad_floats(int64_t C);
+int64_t adnm_skipgate_bwd_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t C);
+int adnm_skipgate_bwd(const float* dout, const float* x, const float* const* params, const float* pooled, const float* conv, float* dx,
+                      float* dparams, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W, int64_t C, adnm_stream_t stream);
+
 /* ---------------------------------------------------------------- fused scalar / channel-affine mixes
  * y[m,c] = gamma[c] * ( s0*x0[m,c] + s1*x1[m,c] + s2*x2[m,c] )      x1,x2 optional (NULL), s_k NULL = 1, gamma NULL = 1
  * replaces the broadcast mul/add chains around the learnable scalars of Block.forward (ADNMUNet.py:152,158,161),

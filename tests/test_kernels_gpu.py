@@ -405,3 +405,41 @@ def test_igate():
     assert_close(xg.grad, xo.grad, GRAD_TOL, "dx")
     assert_close(eg.grad, eo.grad, GRAD_TOL, "denhance", atol=1e-5)
     assert_close(tg.grad, to.grad, GRAD_TOL, "dthreshold", atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------- EncoderToDecoder core (K12)
+@pytest.mark.parametrize("B,H,W,C", [(2, 4, 4, 256), (1, 8, 8, 512), (4, 2, 2, 1024), (2, 16, 16, 256), (1, 40, 40, 256)])
+def test_skipgate(B, H, W, C):
+    """pools + grouped convs + gates + mix vs the same maths in fp64 torch ops (model_untils.py:767-787).
+    The last shape has > 1 pixel slice in the weight-gradient pass (partials + fold)."""
+    tag = f"sg{B}{H}{C}"
+    x, cot = T(tag + "x", (B, H * W, C), 1.5), T(tag + "c", (B, H * W, C))
+    shapes = [(C, 4, 1, 3), (C,), (C, 4, 3, 1), (C,), (C, 4, 3, 3), (C,), (C,), (C,), (C,), (C,)]
+    params = [T(f"{tag}p{i}", s, 0.5 if len(s) > 1 else 0.3) for i, s in enumerate(shapes)]
+    params[6], params[8] = 1 + params[6], 1 + params[8]
+    params += [torch.tensor(v) for v in (1.3, 0.1, 0.8, -0.05, 0.33, 0.4, 0.27)] + [1 + 0.2 * T(tag + "g", (C,))]
+
+    def ref(x, p):
+        xi = x.reshape(B, H, W, C).permute(0, 3, 1, 2)
+        ys = []
+        for k, (win, pad, cpad) in enumerate((((3, 1), (1, 0), (0, 1)), ((1, 3), (0, 1), (1, 0)), ((3, 3), (1, 1), (1, 1)))):
+            pool = F.max_pool2d(xi, win, 1, pad) + F.avg_pool2d(xi, win, 1, pad)
+            c = F.conv2d(pool, p[2 * k], p[2 * k + 1], 1, cpad, 1, C // 4)
+            f = k >> 1
+            z = xi * F.gelu(c) * p[6 + 2 * f].view(1, -1, 1, 1) + p[7 + 2 * f].view(1, -1, 1, 1)
+            ys.append(F.silu(p[10 + 2 * f] * (z - p[11 + 2 * f])))
+        out = (p[14] * ys[0] + p[15] * ys[1] + p[16] * ys[2]) * p[17].view(1, -1, 1, 1)
+        return out.permute(0, 2, 3, 1).reshape(B, H * W, C)
+
+    xo, po = leaf(x.double()), [leaf(t.double()) for t in params]
+    yo = ref(xo, po)
+    (yo * cot.double()).sum().backward()
+    xg, pg = leaf(x, DEV), [leaf(t, DEV) for t in params]
+    yg = ops.skipgate(xg, H, W, pg)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, OUT_TOL, "skipgate out")
+    assert_close(xg.grad, xo.grad, GRAD_TOL, "dx")
+    names = ["w13", "b13", "w31", "b31", "w33", "b33", "ffd13.w", "ffd13.b", "ffd33.w", "ffd33.b", "enh13", "thr13", "enh33", "thr33",
+             "alpha1", "alpha2", "alpha3", "gamma"]
+    for n, a, b in zip(names, pg, po):
+        assert_close(a.grad, b.grad, GRAD_TOL, "d" + n, atol=1e-5)

@@ -5,7 +5,7 @@ once-per-step marker kernel.   tools/kstats.py <dir> [top_n] [frac]"""
 import csv, glob, sys
 d = sys.argv[1]
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-f = glob.glob(d + '/*/*_kernel_trace.csv')[0]
+f = (glob.glob(d + '/*/*_kernel_trace.csv') + glob.glob(d + '/*_kernel_trace.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 marks = sorted(int(r['Start_Timestamp']) for r in rows if 'ssd_apply_kernel' in r['Kernel_Name'])  # 10 launches per step
