@@ -66,7 +66,7 @@ def k_rownorm_fwd(x2, w, b, scale, shift, eps, mean, out=None):
     return y, mu, rstd
 
 
-def k_rownorm_bwd(dy2, x2, w, b, scale, mu, rstd, mean, want_b, want_affine, dx_out=None):
+def k_rownorm_bwd(dy2, x2, w, b, scale, mu, rstd, mean, want_b, want_affine, dx_out=None, dres=None):
     M, d = x2.shape
     dev = x2.device
     dx = dx_out if dx_out is not None else torch.empty((M, d), dtype=x2.dtype, device=dev)
@@ -79,8 +79,9 @@ def k_rownorm_bwd(dy2, x2, w, b, scale, mu, rstd, mean, want_b, want_affine, dx_
     pdy, lddy = _rows(dy2)
     px, ldx = _rows(x2)
     pdx, lddx = _rows(dx)
+    pres, ldres = _rows(dres) if dres is not None else (None, 0)
     lib.call("adnm_rownorm_bwd", pdy, lddy, px, ldx, _p(w), _p(b), _p(scale), mu.data_ptr(), rstd.data_ptr(), pdx, lddx,
-             dw.data_ptr(), _p(db), _p(dsc), _p(dsh), ws.data_ptr(), nb, M, d, int(mean), _dt(x2), _stream())
+             dw.data_ptr(), _p(db), _p(dsc), _p(dsh), pres, ldres, ws.data_ptr(), nb, M, d, int(mean), _dt(x2), _stream())
     return dx, dw, db, dsc, dsh
 
 
@@ -250,6 +251,95 @@ class RowNormFn(torch.autograd.Function):
 
 def rownorm(x, w, b=None, scale=None, shift=None, eps=1e-5, mean=True):
     return RowNormFn.apply(x, w, b, scale, shift, eps, mean)
+
+
+class RowNormTapFn(torch.autograd.Function):
+    """(norm(x), x): the head of a pre-norm residual block (ADNMUNet.py:149-152).  Handing x back as a second output lets
+    backward add the residual path's gradient inside the row-norm kernel instead of in a separate autograd add."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, scale, shift, eps, mean):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        y, mu, rstd = k_rownorm_fwd(x2, w, b, scale, shift, eps, mean)
+        ctx.save_for_backward(x2, w, b, scale, mu, rstd)
+        ctx.mean, ctx.shp, ctx.has_shift = mean, shp, shift is not None
+        return y.view(shp), x
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x2, w, b, scale, mu, rstd = ctx.saved_tensors
+        d = ctx.shp[-1]
+        if dy is None:
+            return (dres, None, None, None, None, None, None)
+        dy2 = dy.reshape(-1, d)
+        if dy2.stride(-1) != 1:
+            dy2 = dy2.contiguous()
+        if dres is not None:
+            dres = dres.reshape(-1, d)
+            if dres.stride(-1) != 1:
+                dres = dres.contiguous()
+        dx, dw, db, dsc, dsh = k_rownorm_bwd(dy2, x2, w, b, scale, mu, rstd, ctx.mean, b is not None,
+                                            scale is not None or ctx.has_shift, dres=dres)
+        return (dx.view(ctx.shp), dw, db, dsc if scale is not None else None, dsh if ctx.has_shift else None, None, None)
+
+
+def rownorm_tap(x, w, b=None, scale=None, shift=None, eps=1e-5, mean=True):
+    return RowNormTapFn.apply(x, w, b, scale, shift, eps, mean)
+
+
+class CatMixFn(torch.autograd.Function):
+    """cat((a1*x, a2*r), -1) [+ cat((a3*f, a4*f), -1)] in one pass each way (csrc/elementwise.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, r, f, a1, a2, a3, a4):
+        shp = x.shape
+        d = shp[-1]
+        rows = lambda t: t.reshape(-1, d) if t.reshape(-1, d).stride(-1) == 1 else t.reshape(-1, d).contiguous()
+        x2, r2 = rows(x), rows(r)
+        f2 = rows(f) if f is not None else None
+        _need_gpu(x2)
+        M = x2.shape[0]
+        y = torch.empty((M, 2 * d), dtype=x.dtype, device=x.device)
+        (px, ldx), (pr, ldr) = _rows(x2), _rows(r2)
+        pf, ldf = _rows(f2) if f2 is not None else (None, 0)
+        lib.call("adnm_catmix_fwd", px, ldx, pr, ldr, pf, ldf, _p(a1), _p(a2), _p(a3), _p(a4), y.data_ptr(), M, d, _dt(y), _stream())
+        ctx.save_for_backward(x2, r2, f2, a1, a2, a3, a4)
+        ctx.shp = shp
+        return y.view(*shp[:-1], 2 * d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, r2, f2, a1, a2, a3, a4 = ctx.saved_tensors
+        M, d = x2.shape
+        g = dy.reshape(M, 2 * d)
+        g = g if g.stride(-1) == 1 else g.contiguous()
+        need = ctx.needs_input_grad
+        mk = lambda on: torch.empty((M, d), dtype=x2.dtype, device=x2.device) if on else None
+        dx, dr, df = mk(need[0]), mk(need[1]), mk(need[2] and f2 is not None)
+        da = torch.empty(4, dtype=torch.float32, device=x2.device)
+        nb = lib.query("adnm_catmix_bwd_ws_bytes", M, d)
+        ws = _ws(nb, x2.device)
+        (pg, ldg), (px, ldx), (pr, ldr) = _rows(g), _rows(x2), _rows(r2)
+        pf, ldf = _rows(f2) if f2 is not None else (None, 0)
+        lib.call("adnm_catmix_bwd", pg, ldg, px, ldx, pr, ldr, pf, ldf, _p(a1), _p(a2), _p(a3), _p(a4), _p(dx), _p(dr), _p(df), da.data_ptr(),
+                 ws.data_ptr(), nb, M, d, _dt(g), _stream())
+        v = lambda t: t.view(ctx.shp) if t is not None else None
+        s = lambda a, i: da[i].view_as(a) if a is not None else None
+        return v(dx), v(dr), v(df), s(a1, 0), s(a2, 1), s(a3 if f2 is not None else None, 2), s(a4 if f2 is not None else None, 3)
+
+
+def catmix(x, r, f, a1, a2, a3=None, a4=None):
+    """Head merge of Block / Attention / WTLayer; falls back to the plain expression for shapes the kernel does not take."""
+    d = x.shape[-1]
+    ok = (x.is_cuda and r.shape == x.shape and (f is None or f.shape == x.shape) and d % 4 == 0 and x.dtype in _DT
+          and all(a is None or a.numel() == 1 for a in (a1, a2, a3, a4)))
+    if not ok:
+        y = torch.cat((a1 * x, a2 * r), dim=-1)
+        return y if f is None else y + torch.cat((a3 * f, a4 * f), dim=-1)
+    return CatMixFn.apply(x, r, f, a1, a2, a3, a4)
 
 
 class SSDReduceFn(torch.autograd.Function):

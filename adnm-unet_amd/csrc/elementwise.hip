@@ -83,6 +83,68 @@ __global__ __launch_bounds__(kBlock) void igate_bwd_kernel(const T* __restrict__
   }
 }
 
+// Head merge of Block / Attention / WTLayer (ADNMUNet.py:124-131, :214-221; model_untils.py:398-400):
+//   y = cat((a1*x, a2*r), -1) [+ cat((a3*f, a4*f), -1)]      x, r, f: (M,d) -> y: (M,2d)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void catmix_fwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ r, int64_t ldr,
+                                                            const T* __restrict__ f, int64_t ldf, const float* __restrict__ a1,
+                                                            const float* __restrict__ a2, const float* __restrict__ a3,
+                                                            const float* __restrict__ a4, T* __restrict__ y, int64_t M, int d) {
+  const int d4 = d >> 2;
+  const float s1 = a1 ? *a1 : 1.f, s2 = a2 ? *a2 : 1.f, s3 = (f && a3) ? *a3 : 1.f, s4 = (f && a4) ? *a4 : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < M * d4; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t m = i / d4;
+    const int c = (int)(i % d4) * 4;
+    const float4 xv = Io<T>::ld4(x + m * ldx + c), rv = Io<T>::ld4(r + m * ldr + c);
+    float4 l = make_float4(s1 * xv.x, s1 * xv.y, s1 * xv.z, s1 * xv.w), q = make_float4(s2 * rv.x, s2 * rv.y, s2 * rv.z, s2 * rv.w);
+    if (f) {
+      const float4 fv = Io<T>::ld4(f + m * ldf + c);
+      l = make_float4(fmaf(s3, fv.x, l.x), fmaf(s3, fv.y, l.y), fmaf(s3, fv.z, l.z), fmaf(s3, fv.w, l.w));
+      q = make_float4(fmaf(s4, fv.x, q.x), fmaf(s4, fv.y, q.y), fmaf(s4, fv.z, q.z), fmaf(s4, fv.w, q.w));
+    }
+    Io<T>::st4(y + m * 2 * d + c, l);
+    Io<T>::st4(y + m * 2 * d + d + c, q);
+  }
+}
+
+// part[block] = {sum dyL*x, sum dyR*r, sum dyL*f, sum dyR*f}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void catmix_bwd_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x, int64_t ldx,
+                                                            const T* __restrict__ r, int64_t ldr, const T* __restrict__ f, int64_t ldf,
+                                                            const float* __restrict__ a1, const float* __restrict__ a2,
+                                                            const float* __restrict__ a3, const float* __restrict__ a4, T* __restrict__ dx,
+                                                            T* __restrict__ dr, T* __restrict__ df, float* __restrict__ part, int64_t M, int d) {
+  __shared__ float sm[4][kBlock / 64];
+  const int d4 = d >> 2;
+  const float s1 = a1 ? *a1 : 1.f, s2 = a2 ? *a2 : 1.f, s3 = (f && a3) ? *a3 : 1.f, s4 = (f && a4) ? *a4 : 1.f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < M * d4; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t m = i / d4;
+    const int c = (int)(i % d4) * 4;
+    const float4 gl = Io<T>::ld4(dy + m * lddy + c), gr = Io<T>::ld4(dy + m * lddy + d + c);
+    const float4 xv = Io<T>::ld4(x + m * ldx + c), rv = Io<T>::ld4(r + m * ldr + c);
+    acc[0] += gl.x * xv.x + gl.y * xv.y + gl.z * xv.z + gl.w * xv.w;
+    acc[1] += gr.x * rv.x + gr.y * rv.y + gr.z * rv.z + gr.w * rv.w;
+    if (dx) Io<T>::st4(dx + m * d + c, make_float4(s1 * gl.x, s1 * gl.y, s1 * gl.z, s1 * gl.w));
+    if (dr) Io<T>::st4(dr + m * d + c, make_float4(s2 * gr.x, s2 * gr.y, s2 * gr.z, s2 * gr.w));
+    if (f) {
+      const float4 fv = Io<T>::ld4(f + m * ldf + c);
+      acc[2] += gl.x * fv.x + gl.y * fv.y + gl.z * fv.z + gl.w * fv.w;
+      acc[3] += gr.x * fv.x + gr.y * fv.y + gr.z * fv.z + gr.w * fv.w;
+      if (df)
+        Io<T>::st4(df + m * d + c, make_float4(fmaf(s3, gl.x, s4 * gr.x), fmaf(s3, gl.y, s4 * gr.y), fmaf(s3, gl.z, s4 * gr.z),
+                                               fmaf(s3, gl.w, s4 * gr.w)));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    acc[k] = wave_sum(acc[k]);
+    if ((threadIdx.x & 63) == 0) sm[k][threadIdx.x >> 6] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) part[blockIdx.x * 4 + threadIdx.x] = (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]);
+}
+
 unsigned grid_for(int64_t total) {
   int64_t g = adnm_cdiv(total, kBlock);
   return (unsigned)(g < 2048 ? (g < 1 ? 1 : g) : 2048);
@@ -149,5 +211,65 @@ extern "C" int adnm_igate_bwd(const void* dy, const void* x, const float* enhanc
   }
   adnm_launch_fold("igate_bwd_fold", (const float*)ws, (int)grid, 2, {denhance, 1}, {dthreshold, 1}, {nullptr, 0}, {nullptr, 0}, st);
   ADNM_CHECK_LAUNCH("igate_bwd");
+  return ADNM_OK;
+}
+
+namespace {
+unsigned catmix_blocks(int64_t M, int64_t d) {
+  const int64_t g = adnm_cdiv(M * (d / 4), kBlock);
+  return (unsigned)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
+}
+int catmix_check(const char* who, const void* x, int64_t ldx, const void* r, int64_t ldr, const void* f, int64_t ldf, int64_t M, int64_t d, int dtype) {
+  ADNM_REQUIRE(x && r, "%s: null pointer", who);
+  ADNM_REQUIRE(M > 0 && d >= 4 && d % 4 == 0, "%s: d=%lld must be a positive multiple of 4", who, (long long)d);
+  ADNM_REQUIRE(ldx >= d && ldr >= d && ldx % 4 == 0 && ldr % 4 == 0 && (!f || (ldf >= d && ldf % 4 == 0)), "%s: bad row stride", who);
+  ADNM_REQUIRE(dtype == ADNM_F32 || dtype == ADNM_BF16, "%s: bad dtype %d", who, dtype);
+  return ADNM_OK;
+}
+}  // namespace
+
+extern "C" int adnm_catmix_fwd(const void* x, int64_t ldx, const void* r, int64_t ldr, const void* f, int64_t ldf, const float* a1, const float* a2,
+                               const float* a3, const float* a4, void* y, int64_t M, int64_t d, int dtype, adnm_stream_t stream) {
+  if (int rc = catmix_check("catmix_fwd", x, ldx, r, ldr, f, ldf, M, d, dtype)) return rc;
+  ADNM_REQUIRE(y, "catmix_fwd: null output");
+  hipStream_t st = (hipStream_t)stream;
+  const double es = dtype == ADNM_F32 ? 4.0 : 2.0;
+  ADNM_PROF("catmix_fwd", st, es * M * d * (f ? 5 : 4));
+  if (dtype == ADNM_F32)
+    catmix_fwd_kernel<float><<<grid_for(M * (d / 4)), kBlock, 0, st>>>((const float*)x, ldx, (const float*)r, ldr, (const float*)f, ldf, a1, a2, a3, a4,
+                                                                       (float*)y, M, (int)d);
+  else
+    catmix_fwd_kernel<uint16_t><<<grid_for(M * (d / 4)), kBlock, 0, st>>>((const uint16_t*)x, ldx, (const uint16_t*)r, ldr, (const uint16_t*)f, ldf,
+                                                                          a1, a2, a3, a4, (uint16_t*)y, M, (int)d);
+  ADNM_CHECK_LAUNCH("catmix_fwd");
+  return ADNM_OK;
+}
+
+extern "C" int64_t adnm_catmix_bwd_ws_bytes(int64_t M, int64_t d) { return (int64_t)catmix_blocks(M, d) * 4 * sizeof(float); }
+
+extern "C" int adnm_catmix_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* r, int64_t ldr, const void* f, int64_t ldf,
+                               const float* a1, const float* a2, const float* a3, const float* a4, void* dx, void* dr, void* df, float* da,
+                               void* ws, int64_t ws_bytes, int64_t M, int64_t d, int dtype, adnm_stream_t stream) {
+  if (int rc = catmix_check("catmix_bwd", x, ldx, r, ldr, f, ldf, M, d, dtype)) return rc;
+  ADNM_REQUIRE(dy && da && lddy >= 2 * d && lddy % 4 == 0, "catmix_bwd: dy must be (M, 2d) with a row stride that is a multiple of 4");
+  if (!ws || ws_bytes < adnm_catmix_bwd_ws_bytes(M, d)) {
+    adnm_set_error("catmix_bwd: workspace too small");
+    return ADNM_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = catmix_blocks(M, d);
+  const double es = dtype == ADNM_F32 ? 4.0 : 2.0;
+  {
+    ADNM_PROF("catmix_bwd", st, es * M * d * (f ? 8 : 6));
+    if (dtype == ADNM_F32)
+      catmix_bwd_kernel<float><<<grid, kBlock, 0, st>>>((const float*)dy, lddy, (const float*)x, ldx, (const float*)r, ldr, (const float*)f, ldf, a1, a2,
+                                                        a3, a4, (float*)dx, (float*)dr, (float*)df, (float*)ws, M, (int)d);
+    else
+      catmix_bwd_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)dy, lddy, (const uint16_t*)x, ldx, (const uint16_t*)r, ldr,
+                                                           (const uint16_t*)f, ldf, a1, a2, a3, a4, (uint16_t*)dx, (uint16_t*)dr, (uint16_t*)df,
+                                                           (float*)ws, M, (int)d);
+  }
+  adnm_launch_fold("catmix_bwd_fold", (const float*)ws, (int)grid, 4, {da, 4}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
+  ADNM_CHECK_LAUNCH("catmix_bwd");
   return ADNM_OK;
 }

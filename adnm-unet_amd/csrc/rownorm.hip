@@ -88,8 +88,8 @@ template <typename T, bool MEAN, int IT>
 __global__ __launch_bounds__(kBlock) void rownorm_bwd_kernel(
     const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x, int64_t ldx, const float* __restrict__ w,
     const float* __restrict__ b, const float* __restrict__ scale, const float* __restrict__ mu_in,
-    const float* __restrict__ rstd_in, T* __restrict__ dx, int64_t lddx, float* __restrict__ part, int64_t M, int d,
-    int lpr) {
+    const float* __restrict__ rstd_in, T* __restrict__ dx, int64_t lddx, const T* __restrict__ dres, int64_t lddres,
+    float* __restrict__ part, int64_t M, int d, int lpr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // (waves) x (2d+4)
   const int lane_in_row = threadIdx.x & (lpr - 1);
   const int rows_per_block = kBlock / lpr;
@@ -141,6 +141,10 @@ __global__ __launch_bounds__(kBlock) void rownorm_bwd_kernel(
         o.y = rstd * (g[i].y - s1 - xh[i].y * s2);
         o.z = rstd * (g[i].z - s1 - xh[i].z * s2);
         o.w = rstd * (g[i].w - s1 - xh[i].w * s2);
+        if (dres) {  // gradient arriving through the residual path of the pre-norm block
+          const float4 e = Io<T>::ld4(dres + row * lddres + c);
+          o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+        }
         Io<T>::st4(dx + row * lddx + c, o);
       }
     }
@@ -205,16 +209,16 @@ int launch_fwd(const void* x, int64_t ldx, const float* w, const float* b, const
 template <typename T, bool MEAN>
 int launch_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* w, const float* b,
                const float* scale, const float* mu, const float* rstd, void* dx, int64_t lddx, float* dw, float* db,
-               float* dscale, float* dshift, float* part, int64_t M, int64_t d, hipStream_t st) {
+               float* dscale, float* dshift, const void* dres, int64_t lddres, float* part, int64_t M, int64_t d, hipStream_t st) {
   const int lpr = lanes_per_row(d);
   const int it = (int)adnm_cdiv(d, (int64_t)lpr * 4);
   const int nblk = bwd_blocks(M, d);
   const size_t smem = (size_t)(kBlock / 64) * (2 * d + 4) * sizeof(float);
 #define BWD(IT)                                                                                                  \
   rownorm_bwd_kernel<T, MEAN, IT><<<nblk, kBlock, smem, st>>>((const T*)dy, lddy, (const T*)x, ldx, w, b, scale, mu, \
-                                                              rstd, (T*)dx, lddx, part, M, (int)d, lpr)
+                                                              rstd, (T*)dx, lddx, (const T*)dres, lddres, part, M, (int)d, lpr)
   {
-  ADNM_PROF("rownorm_bwd", st, (double)sizeof(T) * M * d * 3);
+  ADNM_PROF("rownorm_bwd", st, (double)sizeof(T) * M * d * (dres ? 4 : 3));
   if (it <= 1) BWD(1);
   else if (it <= 2) BWD(2);
   else if (it <= 4) BWD(4);
@@ -254,15 +258,16 @@ extern "C" int64_t adnm_rownorm_bwd_ws_bytes(int64_t M, int64_t d) {
 
 extern "C" int adnm_rownorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* w,
                                 const float* b, const float* scale, const float* mu, const float* rstd, void* dx,
-                                int64_t lddx, float* dw, float* db, float* dscale, float* dshift, void* ws,
-                                int64_t ws_bytes, int64_t M, int64_t d, int subtract_mean, int dtype,
-                                adnm_stream_t stream) {
+                                int64_t lddx, float* dw, float* db, float* dscale, float* dshift, const void* dres,
+                                int64_t lddres, void* ws, int64_t ws_bytes, int64_t M, int64_t d, int subtract_mean,
+                                int dtype, adnm_stream_t stream) {
   ADNM_REQUIRE(dy && x && w && rstd && dx && dw, "rownorm_bwd: null pointer");
   ADNM_REQUIRE(!subtract_mean || mu, "rownorm_bwd: mu required when subtract_mean");
   ADNM_REQUIRE(M > 0 && d >= 4 && d % 4 == 0 && d <= 4096, "rownorm_bwd: d=%lld must be a multiple of 4 in [4,4096]", (long long)d);
   ADNM_REQUIRE(ldx >= d && lddy >= d && lddx >= d && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0,
                "rownorm_bwd: row strides must be >= d and multiples of 4");
   ADNM_REQUIRE(dtype == ADNM_F32 || dtype == ADNM_BF16, "rownorm_bwd: bad dtype %d", dtype);
+  ADNM_REQUIRE(!dres || (lddres >= d && lddres % 4 == 0), "rownorm_bwd: bad residual-gradient stride");
   if (ws_bytes < adnm_rownorm_bwd_ws_bytes(M, d) || !ws) {
     adnm_set_error("rownorm_bwd: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_rownorm_bwd_ws_bytes(M, d));
     return ADNM_EWORKSPACE;
@@ -270,8 +275,8 @@ extern "C" int adnm_rownorm_bwd(const void* dy, int64_t lddy, const void* x, int
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)ws;
   if (dtype == ADNM_F32)
-    return subtract_mean ? launch_bwd<float, true>(dy, lddy, x, ldx, w, b, scale, mu, rstd, dx, lddx, dw, db, dscale, dshift, part, M, d, st)
-                         : launch_bwd<float, false>(dy, lddy, x, ldx, w, b, scale, mu, rstd, dx, lddx, dw, db, dscale, dshift, part, M, d, st);
-  return subtract_mean ? launch_bwd<uint16_t, true>(dy, lddy, x, ldx, w, b, scale, mu, rstd, dx, lddx, dw, db, dscale, dshift, part, M, d, st)
-                       : launch_bwd<uint16_t, false>(dy, lddy, x, ldx, w, b, scale, mu, rstd, dx, lddx, dw, db, dscale, dshift, part, M, d, st);
+    return subtract_mean ? launch_bwd<float, true>(dy, lddy, x, ldx, w, b, scale, mu, rstd, dx, lddx, dw, db, dscale, dshift, dres, lddres, part, M, d, st)
+                         : launch_bwd<float, false>(dy, lddy, x, ldx, w, b, scale, mu, rstd, dx, lddx, dw, db, dscale, dshift, dres, lddres, part, M, d, st);
+  return subtract_mean ? launch_bwd<uint16_t, true>(dy, lddy, x, ldx, w, b, scale, mu, rstd, dx, lddx, dw, db, dscale, dshift, dres, lddres, part, M, d, st)
+                       : launch_bwd<uint16_t, false>(dy, lddy, x, ldx, w, b, scale, mu, rstd, dx, lddx, dw, db, dscale, dshift, dres, lddres, part, M, d, st);
 }

@@ -29,18 +29,18 @@ from .model_untils import (BiasFree_LayerNorm, RMSNorm, Mlp, Swish, FeedForward,
 def _merge(mod, x, residual, features):
     """Skip / feature merge at the head of Block and Attention (ADNMUNet.py:124-131, :214-221)."""
     if residual is not None:
-        x = torch.cat((mod.alpha1 * x, mod.alpha2 * residual), dim=-1)
-        if features is not None:
-            x = x + torch.cat((mod.alpha3 * features, mod.alpha4 * features), dim=-1)
+        x = ops.catmix(x, residual, features, mod.alpha1, mod.alpha2, mod.alpha3, mod.alpha4)
     elif features is not None:
         x = ops.lincomb([x, features], [None, mod.alpha3])
     return x
 
 
 def _normed(norm, x, scale, shift):
+    """-> (scale*norm(x)+shift, x).  With the HIP row-norms the second value is an autograd alias of x whose gradient is
+    added inside the norm's backward kernel (the residual path of the pre-norm block)."""
     if isinstance(norm, (RMSNorm, BiasFree_LayerNorm)):
-        return norm(x, scale, shift)  # scalar affine fused into the HIP row-norm
-    return scale * norm(x) + shift
+        return norm.tap(x, scale, shift)  # scalar affine fused into the HIP row-norm
+    return scale * norm(x) + shift, x
 
 
 class Block(nn.Module):
@@ -79,9 +79,9 @@ class Block(nn.Module):
         for i in range(self.num_layers):
             # beta3/beta4 alias beta1/beta2 in the reference (:145-146)
             beta1, beta2 = (self.beta1, self.beta2) if self.num_layers == 1 else (self.beta1[i:i + 1], self.beta2[i:i + 1])
-            xn = _normed(self.norm1_layers[i], x, self.scale1[i], self.shift1[i])
+            xn, x = _normed(self.norm1_layers[i], x, self.scale1[i], self.shift1[i])
             x = ops.lincomb([x, self.drop_path_layers[i](self.mixer_layers[i](xn, h, w))], [beta1, beta2])
-            xn = _normed(self.norm2_layers[i], x, self.scale2[i], self.shift2[i])
+            xn, x = _normed(self.norm2_layers[i], x, self.scale2[i], self.shift2[i])
             x = ops.lincomb([x, self.ffns[i].forward_tokens(xn, h, w)], [beta1, beta2])
         x = ops.lincomb([x], [None], self.gamma)
         if self.dim != self.out_dim:
@@ -112,9 +112,9 @@ class Attention(nn.Module):
         x = _merge(self, hidden_states, residual, features)
         b, l, d = x.shape
         h, w = _hw(l)
-        xn = self.attn_norm1(x, self.attn_scale1, self.attn_shift1)
+        xn, x = self.attn_norm1.tap(x, self.attn_scale1, self.attn_shift1)
         x = ops.lincomb([x, self.attn_layer(xn, h, w)], [self.beta1, self.beta2])
-        xn = self.attn_norm2(x, self.attn_scale2, self.attn_shift2)
+        xn, x = self.attn_norm2.tap(x, self.attn_scale2, self.attn_shift2)
         x = ops.lincomb([x, self.attn_mlp(xn)], [self.beta3, self.beta4])
         x = ops.lincomb([x], [None], self.gamma)
         if self.dim != self.out_dim:

@@ -79,6 +79,9 @@ class BiasFree_LayerNorm(nn.Module):
     def forward(self, x, scale=None, shift=None):
         return ops.rownorm(x, self.weight, None, scale, shift, 1e-5, True)
 
+    def tap(self, x, scale=None, shift=None):
+        return ops.rownorm_tap(x, self.weight, None, scale, shift, 1e-5, True)
+
 
 class RMSNorm(nn.Module):
     """Stands in for mamba_ssm.ops.triton.layer_norm.RMSNorm (bound at ADNMUNet.py:278 of the reference):
@@ -92,6 +95,9 @@ class RMSNorm(nn.Module):
 
     def forward(self, x, scale=None, shift=None):
         return ops.rownorm(x, self.weight, None, scale, shift, self.eps, False)
+
+    def tap(self, x, scale=None, shift=None):
+        return ops.rownorm_tap(x, self.weight, None, scale, shift, self.eps, False)
 
 
 class Mlp(nn.Module):
@@ -367,7 +373,7 @@ class WTLayer(nn.Module):
         """(model_untils.py:402-426 of the reference).  With a residual the reference builds the feature
         concat and discards it (:408), so `features` does not enter the result on that branch."""
         if residual is not None:
-            x = torch.cat((self.gama1 * x, self.gama2 * residual), dim=-1)
+            x = ops.catmix(x, residual, None, self.gama1, self.gama2)
         elif features is not None:
             x = x + self.gama3 * features
         b, l, d = x.shape

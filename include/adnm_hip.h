@@ -58,12 +58,14 @@ int adnm_rownorm_fwd(const void* x, int64_t ldx, const float* w, const float* b,
                      const float* shift, void* y, int64_t ldy, float* mu, float* rstd, int64_t M, int64_t d,
                      float eps, int subtract_mean, int dtype, adnm_stream_t stream);
 /* dx:(M,d) stride lddx; dw,db:(d); dscale,dshift:(1) — any of db/dscale/dshift may be NULL.
+ * dres (optional, (M,d) stride lddres): the gradient reaching x through the residual path of a pre-norm block
+ * (ADNMUNet.py:152,158: x' = beta1*x + beta2*f(norm(x))) — added into dx in the same pass, so autograd's separate add disappears.
  * ws: fp32 workspace of adnm_rownorm_bwd_ws_bytes(M,d) bytes. Parameter grads are OVERWRITTEN. */
 int64_t adnm_rownorm_bwd_ws_bytes(int64_t M, int64_t d);
 int adnm_rownorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* w, const float* b,
                      const float* scale, const float* mu, const float* rstd, void* dx, int64_t lddx, float* dw,
-                     float* db, float* dscale, float* dshift, void* ws, int64_t ws_bytes, int64_t M, int64_t d,
-                     int subtract_mean, int dtype, adnm_stream_t stream);
+                     float* db, float* dscale, float* dshift, const void* dres, int64_t lddres, void* ws, int64_t ws_bytes,
+                     int64_t M, int64_t d, int subtract_mean, int dtype, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- SSD reduction form (K1)
  * non_casual_linear_attn (ADNssd.py:252-299, Vssd.py:161-208):
@@ -204,6 +206,17 @@ int64_t adnm_skipgate_grad_floats(int64_t C);
 int64_t adnm_skipgate_bwd_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t C);
 int adnm_skipgate_bwd(const float* dout, const float* x, const float* const* params, const float* pooled, const float* conv, float* dx,
                       float* dparams, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W, int64_t C, adnm_stream_t stream);
+
+/* ---------------------------------------------------------------- head merge (K13)
+ * y = cat((a1*x, a2*r), -1) [+ cat((a3*f, a4*f), -1)] — Block / Attention merge (ADNMUNet.py:124-131, :214-221) and WTLayer's
+ * (model_untils.py:398-400).  x, r, f: (M,d) with row strides; f may be NULL; a_k: device scalars (NULL = 1); y: (M,2d)
+ * contiguous.  bwd: dx, dr, df (M,d) contiguous (NULL skips), da[4] OVERWRITTEN (da[2..3] = 0 without f). */
+int adnm_catmix_fwd(const void* x, int64_t ldx, const void* r, int64_t ldr, const void* f, int64_t ldf, const float* a1, const float* a2,
+                    const float* a3, const float* a4, void* y, int64_t M, int64_t d, int dtype, adnm_stream_t stream);
+int64_t adnm_catmix_bwd_ws_bytes(int64_t M, int64_t d);
+int adnm_catmix_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* r, int64_t ldr, const void* f, int64_t ldf,
+                    const float* a1, const float* a2, const float* a3, const float* a4, void* dx, void* dr, void* df, float* da, void* ws,
+                    int64_t ws_bytes, int64_t M, int64_t d, int dtype, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- fused scalar / channel-affine mixes
  * y[m,c] = gamma[c] * ( s0*x0[m,c] + s1*x1[m,c] + s2*x2[m,c] )      x1,x2 optional (NULL), s_k NULL = 1, gamma NULL = 1

@@ -443,3 +443,48 @@ def test_skipgate(B, H, W, C):
              "alpha1", "alpha2", "alpha3", "gamma"]
     for n, a, b in zip(names, pg, po):
         assert_close(a.grad, b.grad, GRAD_TOL, "d" + n, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,d,with_f", [(4 * 1024, 128, True), (300, 64, False), (64, 512, True)])
+def test_catmix(M, d, with_f):
+    x, r, f, cot = (T(f"cm.{n}{M}", (2, M // 2, d)) for n in "xrfc")
+    cot = T(f"cm.cot{M}", (2, M // 2, 2 * d))
+    al = [torch.tensor(v) for v in (1.1, 0.9, 0.7, -0.4)]
+
+    def run(x, r, f, al, fn):
+        y = fn(x, r, f if with_f else None, al[0], al[1], al[2] if with_f else None, al[3] if with_f else None)
+        (y * cot.to(y)).sum().backward()
+        return y
+
+    def ref(x, r, f, a1, a2, a3, a4):
+        y = torch.cat((a1 * x, a2 * r), -1)
+        return y if f is None else y + torch.cat((a3 * f, a4 * f), -1)
+    xo, ro, fo, ao = leaf(x.double()), leaf(r.double()), leaf(f.double()), [leaf(a.double()) for a in al]
+    yo = run(xo, ro, fo, ao, ref)
+    xg, rg, fg, ag = leaf(x, DEV), leaf(r, DEV), leaf(f, DEV), [leaf(a, DEV) for a in al]
+    yg = run(xg, rg, fg, ag, ops.catmix)
+    assert_close(yg, yo, OUT_TOL, "catmix")
+    assert_close(xg.grad, xo.grad, GRAD_TOL, "dx")
+    assert_close(rg.grad, ro.grad, GRAD_TOL, "dr")
+    if with_f:
+        assert_close(fg.grad, fo.grad, GRAD_TOL, "df")
+    for i in range(4 if with_f else 2):
+        assert_close(ag[i].grad, ao[i].grad, GRAD_TOL, f"da{i + 1}", atol=1e-5)
+
+
+@pytest.mark.parametrize("mean", [False, True])
+def test_rownorm_tap(mean):
+    """pre-norm residual head: (norm(x), x) with the residual gradient added inside the norm's backward kernel."""
+    M, d = 1000, 64
+    x, w, c1, c2 = T("rt.x", (M, d), 2.0), 1 + 0.2 * T("rt.w", (d,)), T("rt.c1", (M, d)), T("rt.c2", (M, d))
+    sc, sh = torch.tensor(1.3), torch.tensor(-0.2)
+    xo, wo, so, ho = leaf(x.double()), leaf(w.double()), leaf(sc.double()), leaf(sh.double())
+    yo = O.biasfree_layernorm(xo, wo) if mean else O.rmsnorm(xo, wo, 1e-5)
+    ((so * yo + ho) * c1.double()).sum().backward(retain_graph=True)
+    (xo * c2.double()).sum().backward()
+    xg, wg, sg, hg = leaf(x, DEV), leaf(w, DEV), leaf(sc, DEV), leaf(sh, DEV)
+    yn, xr = ops.rownorm_tap(xg, wg, None, sg, hg, 1e-5, mean)
+    ((yn * c1.to(DEV)).sum() + (xr * c2.to(DEV)).sum()).backward()
+    assert_close(xg.grad, xo.grad, GRAD_TOL, "dx (norm + residual)")
+    assert_close(wg.grad, wo.grad, GRAD_TOL, "dw")
+    assert_close(sg.grad, so.grad, GRAD_TOL, "dscale")

@@ -37,3 +37,14 @@ print(f"window: {steps} steps, wall {wall/steps:.2f} ms/step, kernel time {tot/s
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0]): print(f"  {k:20s} {v[0]/steps:7.2f} ms/step {v[1]/steps:7.0f} launches")
 for n, v in sorted(per.items(), key=lambda kv: -kv[1][0])[:top]:
     print(f"{v[0]/steps:8.3f} ms/step {v[1]/steps:7.1f} calls {1e3*v[0]/v[1]:8.1f} us  {n[:130]}")
+# ---- per (family, grid size): where in the pyramid the time goes; `real` subtracts ~2 us/launch of trace overhead
+import re
+fam = {}
+for r in rows:
+    n = re.sub(r"^void ", "", r['Kernel_Name']); n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = n.split("(")[0][:70]
+    k = (n, int(r.get('Grid_Size', 0) or 0))
+    a = fam.setdefault(k, [0, 0]); a[0] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6; a[1] += 1
+print("\n(kernel, grid) by time:")
+for (n, g), v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:int(sys.argv[4]) if len(sys.argv) > 4 else 90]:
+    print(f"{v[0]/steps:8.3f} ms/step {v[1]/steps:6.1f} calls {1e3*v[0]/v[1]:8.1f} us grid={g:9d}  {n}")
