@@ -996,3 +996,30 @@ def skipgate_supported(x):
 
 def skipgate(x, h, w, params):
     return SkipGateFn.apply(x, h, w, *params)
+
+
+class RainLossFn(torch.autograd.Function):
+    """enRainfallLoss value + d/dpred in one pass; backward is a single scale of the stored gradient."""
+
+    @staticmethod
+    def forward(ctx, pred, target, omega_t, alpha, gamma):
+        p, t = pred.contiguous(), target.contiguous()
+        _need_gpu(p)
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        grad = torch.empty_like(p)
+        nb = lib.query("adnm_rainloss_ws_bytes", p.numel())
+        ws = _ws(nb, p.device)
+        lib.call("adnm_rainloss", p.data_ptr(), t.data_ptr(), loss.data_ptr(), grad.data_ptr(), ws.data_ptr(), nb, p.numel(), float(omega_t),
+                 float(alpha), float(gamma), _stream())
+        ctx.save_for_backward(grad)
+        ctx.shp = pred.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, dl):
+        (grad,) = ctx.saved_tensors
+        return (grad * dl).view(ctx.shp), None, None, None, None
+
+
+def rainloss(pred, target, omega_t, alpha, gamma):
+    return RainLossFn.apply(pred, target, omega_t, alpha, gamma)

@@ -145,6 +145,34 @@ __global__ __launch_bounds__(kBlock) void catmix_bwd_kernel(const T* __restrict_
   if (threadIdx.x < 4) part[blockIdx.x * 4 + threadIdx.x] = (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]);
 }
 
+// enRainfallLoss (models/loss.py:30-57 of the reference), value and d/dpred in one pass.
+//   e = w(pred>=t) * |pred-t| * (1 + [t>=0.7] alpha exp(t))  +  [t>=0.7 and pred<t] gamma (exp(alpha (t-pred)) - 1);  loss = sum e / n
+__global__ __launch_bounds__(kBlock) void rainloss_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, float* __restrict__ grad,
+                                                          float* __restrict__ part, int64_t n, float omega, float alpha, float gamma) {
+  __shared__ float sm[kBlock / 64];
+  const float inv_n = 1.0f / (float)n;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const float p = pred[i], t = tgt[i], diff = p - t;
+    const bool over = p >= t, heavy = t >= 0.7f;
+    const float w = over ? 1.0f - omega : omega;
+    const float wi = heavy ? alpha * __expf(t) : 0.f;
+    float e = w * fabsf(diff) * (1.0f + wi);
+    float g = w * (1.0f + wi) * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
+    if (gamma != 0.f && heavy && !over) {
+      const float ex = __expf(alpha * (t - p));
+      e += gamma * (ex - 1.0f);
+      g -= gamma * alpha * ex;
+    }
+    acc += e;
+    grad[i] = g * inv_n;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) * inv_n;
+}
+
 unsigned grid_for(int64_t total) {
   int64_t g = adnm_cdiv(total, kBlock);
   return (unsigned)(g < 2048 ? (g < 1 ? 1 : g) : 2048);
@@ -271,5 +299,32 @@ extern "C" int adnm_catmix_bwd(const void* dy, int64_t lddy, const void* x, int6
   }
   adnm_launch_fold("catmix_bwd_fold", (const float*)ws, (int)grid, 4, {da, 4}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
   ADNM_CHECK_LAUNCH("catmix_bwd");
+  return ADNM_OK;
+}
+
+namespace {
+unsigned rainloss_blocks(int64_t n) {
+  const int64_t g = adnm_cdiv(n, kBlock * 4);
+  return (unsigned)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
+}
+}  // namespace
+extern "C" int64_t adnm_rainloss_ws_bytes(int64_t n) { return (int64_t)rainloss_blocks(n) * sizeof(float); }
+
+extern "C" int adnm_rainloss(const float* pred, const float* target, float* loss, float* grad, void* ws, int64_t ws_bytes, int64_t n,
+                             float omega_t, float alpha, float gamma, adnm_stream_t stream) {
+  ADNM_REQUIRE(pred && target && loss && grad, "rainloss: null pointer");
+  ADNM_REQUIRE(n > 0, "rainloss: empty input");
+  if (!ws || ws_bytes < adnm_rainloss_ws_bytes(n)) {
+    adnm_set_error("rainloss: workspace too small");
+    return ADNM_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = rainloss_blocks(n);
+  {
+    ADNM_PROF("rainloss", st, 12.0 * n);
+    rainloss_kernel<<<grid, kBlock, 0, st>>>(pred, target, grad, (float*)ws, n, omega_t, alpha, gamma);
+  }
+  adnm_launch_fold("rainloss_fold", (const float*)ws, (int)grid, 1, {loss, 1}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
+  ADNM_CHECK_LAUNCH("rainloss");
   return ADNM_OK;
 }

@@ -307,19 +307,42 @@ __device__ __forceinline__ void dgrad4(const float* __restrict__ dc, const float
   }
 }
 
+// Weight gradient of branch K for 16 groups: a wave = 16 pixel sub-slices x 4 groups, every lane keeps its group's
+// whole 4x4xT tap matrix in registers (coalesced float4 loads of d c and p), the 16 sub-slices are summed with
+// in-row lane shuffles, and the lane of sub-slice 0 writes the group's 16T floats in PyTorch's (o, i, t) order.
 template <int K>
-__device__ __forceinline__ float wgrad_elem(const float* __restrict__ dc, const float* __restrict__ p, const Geo& g, int n, int slice, int SW) {
+__device__ __forceinline__ void wgrad_block(const float* __restrict__ dc, const float* __restrict__ p, float* __restrict__ dw, const Geo& g,
+                                            int gchunk, int outer, int SW) {
   constexpr int T = Taps<K>::T;
-  const int cg = n / (16 * T), r = n % (16 * T), o = r / (4 * T), i = (r / T) % 4, t = r % T;
-  const int di = Taps<K>::di(t), dj = Taps<K>::dj(t);
-  float acc = 0.f;
-  for (int64_t pix = slice; pix < g.npix; pix += SW) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & 15, cg = gchunk * 16 + wave * 4 + (lane >> 4);
+  float acc[16 * T];
+#pragma unroll
+  for (int e = 0; e < 16 * T; ++e) acc[e] = 0.f;
+  for (int64_t pix = sub + 16 * (int64_t)outer; pix < g.npix; pix += 16 * (int64_t)SW) {
     const int w = (int)(pix % g.W), h = (int)((pix / g.W) % g.H);
-    const int hh = h + di, ww = w + dj;
-    if (hh < 0 || hh >= g.H || ww < 0 || ww >= g.W) continue;
-    acc = fmaf(dc[pix * g.C + cg * 4 + o], p[(pix + (int64_t)di * g.W + dj) * g.C + cg * 4 + i], acc);
+    float dv[4];
+    f4(ld4(dc + pix * g.C + cg * 4), dv);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int di = Taps<K>::di(t), dj = Taps<K>::dj(t);
+      const int hh = h + di, ww = w + dj;
+      if (hh < 0 || hh >= g.H || ww < 0 || ww >= g.W) continue;
+      float pv[4];
+      f4(ld4(p + (pix + (int64_t)di * g.W + dj) * g.C + cg * 4), pv);
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[(o * 4 + i) * T + t] = fmaf(dv[o], pv[i], acc[(o * 4 + i) * T + t]);
+    }
   }
-  return acc;
+#pragma unroll
+  for (int e = 0; e < 16 * T; ++e) acc[e] = group_sum(acc[e], 16);
+  if (sub == 0) {
+    float* out = dw + (int64_t)cg * 16 * T;
+#pragma unroll
+    for (int e = 0; e < 16 * T; e += 4) *reinterpret_cast<float4*>(out + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void skip_conv_bwd_kernel(const float* __restrict__ dc0, const float* __restrict__ dc1,
@@ -341,16 +364,16 @@ __global__ __launch_bounds__(kBlock) void skip_conv_bwd_kernel(const float* __re
     st4(g2 + idx * 4, o);
     return;
   }
-  const int nw = g.C * kWeightsPerChannel;
-  const int64_t e = (int64_t)(blockIdx.x - ndg) * kBlock + threadIdx.x;
-  if (e >= (int64_t)nw * SW) return;
-  const int n = (int)(e % nw), slice = (int)(e / nw);
-  const int n1 = g.C * 12, n2 = g.C * 24;
-  float acc;
-  if (n < n1) acc = wgrad_elem<0>(dc0, p0, g, n, slice, SW);
-  else if (n < n2) acc = wgrad_elem<1>(dc1, p1, g, n - n1, slice, SW);
-  else acc = wgrad_elem<2>(dc2, p2, g, n - n2, slice, SW);
-  dw[(int64_t)slice * nw + n] = acc;
+  // weight-gradient role: block -> (branch, chunk of 16 groups, outer pixel slice); partial row `outer` of (SW, 60 C)
+  const int nchunk = g.C4 / 16;
+  int r = (int)blockIdx.x - ndg;
+  const int k = r / (nchunk * SW);
+  r -= k * nchunk * SW;
+  const int outer = r / nchunk, gchunk = r % nchunk;
+  float* row = dw + (int64_t)outer * g.C * kWeightsPerChannel;
+  if (k == 0) wgrad_block<0>(dc0, p0, row, g, gchunk, outer, SW);
+  else if (k == 1) wgrad_block<1>(dc1, p1, row + (int64_t)g.C * 12, g, gchunk, outer, SW);
+  else wgrad_block<2>(dc2, p2, row + (int64_t)g.C * 24, g, gchunk, outer, SW);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -373,7 +396,7 @@ int load_params(const char* who, const float* const* params, Params* P) {
   return ADNM_OK;
 }
 int slices_pointwise(const Geo& g) { return (int)(g.npix < 4 ? 1 : (g.npix / 4 > 512 ? 512 : g.npix / 4)); }
-int slices_wgrad(const Geo& g) { return (int)(adnm_cdiv(g.npix, 128) > 64 ? 64 : adnm_cdiv(g.npix, 128)); }
+int slices_wgrad(const Geo& g) { return (int)(g.npix / 64 < 1 ? 1 : (g.npix / 64 > 16 ? 16 : g.npix / 64)); }   // x 16 in-wave sub-slices
 struct WsLayout {
   int64_t tensors, vpart, spart, wpart, total;   // float offsets
 };
@@ -451,7 +474,7 @@ extern "C" int adnm_skipgate_bwd(const float* dout, const float* x, const float*
   const int ndg = (int)adnm_cdiv(g.npix * g.C4, kBlock);
   {
     ADNM_PROF("skip_conv_bwd", st, 4.0 * (9 * n + 2.0 * nwt));
-    skip_conv_bwd_kernel<<<(unsigned)(ndg + adnm_cdiv((int64_t)nwt * SW, kBlock)), kBlock, 0, st>>>(
+    skip_conv_bwd_kernel<<<(unsigned)(ndg + 3 * (g.C4 / 16) * SW), kBlock, 0, st>>>(
         dc0, dc1, dc2, pooled, pooled + n, pooled + 2 * n, P, g0, g1, g2, SW > 1 ? wpart : dwgt, ndg, SW, g);
   }
   if (SW > 1) adnm_launch_fold("skip_wgrad_fold", wpart, SW, nwt, {dwgt, nwt}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);

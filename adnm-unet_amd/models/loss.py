@@ -1,7 +1,9 @@
 """enRainfallLoss (DQWL) — same class / constructor as the reference's models/loss.py:30-57.
-Element stream + one reduction per step ("next" row §8f): plain device ops for now."""
+One fused HIP pass on the GPU (value and d/dpred together)."""
 import torch
 import torch.nn as nn
+
+from adnm_hip import ops
 
 
 class enRainfallLoss(nn.Module):
@@ -10,6 +12,12 @@ class enRainfallLoss(nn.Module):
         self.omega_t, self.alpha, self.gamma = omega_t, alpha, gamma
 
     def forward(self, pred, target):
+        if pred.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.float32 and pred.shape == target.shape:
+            return ops.rainloss(pred, target, self.omega_t, self.alpha, self.gamma)  # value + gradient in one HIP pass
+        return self.forward_torch(pred, target)
+
+    def forward_torch(self, pred, target):
+        """The same expression in device-agnostic torch ops (CPU tensors, odd dtypes)."""
         err = (pred - target).abs()
         over = pred >= target
         w = torch.where(over, 1.0 - self.omega_t, self.omega_t)                # asymmetric L1 (loss.py:40-41)

@@ -207,6 +207,13 @@ int64_t adnm_skipgate_bwd_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t C);
 int adnm_skipgate_bwd(const float* dout, const float* x, const float* const* params, const float* pooled, const float* conv, float* dx,
                       float* dparams, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W, int64_t C, adnm_stream_t stream);
 
+/* ---------------------------------------------------------------- enRainfallLoss (K14)
+ * models/loss.py:30-57 of the reference (train_untils.py:43 builds it with omega_t 0.57, alpha 0.25, gamma 0):
+ * loss (1 float) and grad = d loss / d pred (n floats) in one pass over contiguous fp32 pred / target. */
+int64_t adnm_rainloss_ws_bytes(int64_t n);
+int adnm_rainloss(const float* pred, const float* target, float* loss, float* grad, void* ws, int64_t ws_bytes, int64_t n, float omega_t,
+                  float alpha, float gamma, adnm_stream_t stream);
+
 /* ---------------------------------------------------------------- head merge (K13)
  * y = cat((a1*x, a2*r), -1) [+ cat((a3*f, a4*f), -1)] — Block / Attention merge (ADNMUNet.py:124-131, :214-221) and WTLayer's
  * (model_untils.py:398-400).  x, r, f: (M,d) with row strides; f may be NULL; a_k: device scalars (NULL = 1); y: (M,2d)
