@@ -10,8 +10,9 @@
 // (~2.3 FMA per byte).  Mapping: one lane per (token, head); the HB = min(64, pow2(H)) lanes of a token are
 // adjacent, so a token row is read as one contiguous 16*HB-byte segment and the shared Bm/Cm row is a
 // same-address broadcast.  Each lane keeps the N x P state of ITS head in registers (64 VGPRs at N=16, P=4)
-// for all the tokens it visits; no LDS in the inner loops.  Cross-lane sums (over the tokens of a wave in
-// pass 1, over the heads of a token for dBm/dCm in backward) are xor-shuffles; cross-block sums go through
+// for all the tokens it visits; no LDS in the forward inner loops.  Cross-lane sums over the tokens of a wave in
+// pass 1 are xor-shuffles; the backward pass keeps the states in LDS instead and gives a lane one (token, group), so
+// its sums over heads stay in registers (see ssd_bwd_kernel); cross-block sums go through
 // fp32 partials in the caller's workspace and a small deterministic second kernel — never atomics, so the
 // result is bitwise reproducible run to run.
 #include "adnm_common.h"
@@ -36,6 +37,21 @@ struct Geo {
   int tok2;       // tokens per block, streaming passes
   int nblk2;      // blocks along L, streaming passes
 };
+
+struct BwdGeo {
+  int nhb, tok, nblk;   // head blocks of kBwdHeadsHost heads, tokens per block, blocks along L
+};
+constexpr int kBwdHeadsHost = 16;
+inline BwdGeo make_bwd_geo(int64_t B, int64_t L, int64_t H, int64_t G) {
+  BwdGeo g;
+  g.nhb = (int)adnm_cdiv(H, kBwdHeadsHost);
+  const int64_t slots = kBlock / G;
+  int64_t per_lane = (B * L * g.nhb) / (slots * 1024);   // aim at ~1024 blocks, 1..8 tokens per lane
+  per_lane = per_lane < 1 ? 1 : (per_lane > 8 ? 8 : per_lane);
+  g.tok = (int)(slots * per_lane);
+  g.nblk = (int)adnm_cdiv(L, g.tok);
+  return g;
+}
 
 inline Geo make_geo(int64_t L, int64_t H) {
   Geo g;
@@ -209,76 +225,93 @@ __global__ __launch_bounds__(kBlock) void ssd_apply_kernel(const T* __restrict__
 //   dw     = sum_p t[p] x[p]                ddt_raw = dw * a * sigmoid(dt_raw + bias)
 //   dCm[n] = sum_{h in g} sum_p dy[p] KV[n][p]        dBm[n] = sum_{h in g} w sum_p dKV[n][p] x[p]
 //   dD += sum_p dy x ;  ddt_bias += ddt_raw ;  dA_log += dw * w
-// hpart: per (b, l-block, wave) partial of [dD | ddt_bias | dA_log] per head; bcpart: per head-block partial of
-// [dBm | dCm] rows when H spans several head blocks (otherwise written straight to dBm/dCm).
-template <typename T, int P, int N>
+// Mapping: a block owns kBwdHeads heads of one batch item; their KV / dKV states sit in LDS (every lane of a group reads
+// the same address: a broadcast).  A lane owns one (token, group) and walks the heads of its group, so the sums over heads
+// that dBm / dCm need are plain register accumulations — the earlier (token, head)-per-lane version spent its time in the
+// 96 cross-lane shuffles per token that this removes.  hpart: per (b, token block) partial of [dD | ddt_bias | dA_log];
+// bcpart: per head-block partial of [dBm | dCm] rows when H spans several head blocks (else written straight out).
+constexpr int kBwdHeads = 16;
+
+template <typename T, int P, int N, int G>
 __global__ __launch_bounds__(kBlock) void ssd_bwd_kernel(
     const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x, int64_t ldx, const T* __restrict__ Bm, int64_t ldb,
-    const T* __restrict__ Cm, int64_t ldc, const T* __restrict__ dt_raw, int64_t lddt, int64_t dt_hs,
-    const float* __restrict__ dt_bias, const float* __restrict__ A_log, const float* __restrict__ D, int64_t p_hs,
-    const float* __restrict__ kv, const float* __restrict__ dkv, T* __restrict__ dx, int64_t lddx, T* __restrict__ dBm,
-    int64_t lddb, T* __restrict__ dCm, int64_t lddc, T* __restrict__ ddt_raw, int64_t ldddt,
-    float* __restrict__ hpart, float* __restrict__ bcpart, int64_t L, int H, int G, int hb, int tok_per_block,
-    int nblk, int nhb) {
-  const int hl = threadIdx.x & (hb - 1);
-  const int slot = threadIdx.x / hb;
-  const int slots = kBlock / hb;
-  const int h = blockIdx.y * hb + hl;
-  const bool hv = h < H;
-  const int hh = hv ? h : 0;
-  const int b = blockIdx.z;
+    const T* __restrict__ dt_raw, int64_t lddt, int64_t dt_hs, const float* __restrict__ dt_bias, const float* __restrict__ A_log,
+    const float* __restrict__ D, int64_t p_hs, const float* __restrict__ kv, const float* __restrict__ dkv, T* __restrict__ dx,
+    int64_t lddx, T* __restrict__ dBm, int64_t lddb, T* __restrict__ dCm, int64_t lddc, T* __restrict__ ddt_raw, int64_t ldddt,
+    float* __restrict__ hpart, float* __restrict__ bcpart, int64_t L, int H, int tok_per_block, int nblk, int nhb) {
+  constexpr int HPL = kBwdHeads / G;      // heads per lane
+  constexpr int SST = N * P + 4;          // LDS floats per head: +4 keeps float4 alignment and staggers the banks of the G groups
+  __shared__ __attribute__((aligned(16))) float sS[kBwdHeads * SST];
+  __shared__ __attribute__((aligned(16))) float sD[kBwdHeads * SST];
+  __shared__ float sc[kBwdHeads][3];                  // exp(A_log), dt_bias, D
+  __shared__ float sred[kWaves][kBwdHeads * 3];
+  __shared__ float sacc[HPL * 3][kBlock];             // per-thread [dD, ddt_bias, dA_log] of each of its heads (column = thread: no conflicts)
+  const int b = blockIdx.z, h0 = blockIdx.y * kBwdHeads;
+  for (int i = threadIdx.x; i < kBwdHeads * N * P / 4; i += kBlock) {
+    const int hd = i / (N * P / 4), r = i % (N * P / 4);
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
+    if (h0 + hd < H) {
+      u = *reinterpret_cast<const float4*>(kv + ((int64_t)b * H + h0 + hd) * (N * P) + r * 4);
+      v = *reinterpret_cast<const float4*>(dkv + ((int64_t)b * H + h0 + hd) * (N * P) + r * 4);
+    }
+    *reinterpret_cast<float4*>(sS + hd * SST + r * 4) = u;
+    *reinterpret_cast<float4*>(sD + hd * SST + r * 4) = v;
+  }
+  if (threadIdx.x < kBwdHeads) {
+    const int h = h0 + threadIdx.x;
+    const bool ok = h < H;
+    sc[threadIdx.x][0] = ok ? __expf(A_log[h * p_hs]) : 0.f;
+    sc[threadIdx.x][1] = ok ? dt_bias[h * p_hs] : 0.f;
+    sc[threadIdx.x][2] = ok ? D[h * p_hs] : 0.f;
+  }
+  __syncthreads();
+  const int g = threadIdx.x & (G - 1), slot = threadIdx.x / G;
+  constexpr int slots = kBlock / G;
   const int64_t l0 = (int64_t)blockIdx.x * tok_per_block;
   const int64_t l1 = (l0 + tok_per_block < L) ? l0 + tok_per_block : L;
-  float s[N][P], ds[N][P];
-  {
-    const float* s0 = kv + ((int64_t)b * H + hh) * (N * P);
-    const float* s1 = dkv + ((int64_t)b * H + hh) * (N * P);
 #pragma unroll
-    for (int n = 0; n < N; ++n)
-#pragma unroll
-      for (int p = 0; p < P; p += 4) {
-        float4 t = *reinterpret_cast<const float4*>(s0 + n * P + p);
-        float4 u = *reinterpret_cast<const float4*>(s1 + n * P + p);
-        if (!hv) t = u = make_float4(0.f, 0.f, 0.f, 0.f);
-        s[n][p] = t.x; s[n][p + 1] = t.y; s[n][p + 2] = t.z; s[n][p + 3] = t.w;
-        ds[n][p] = u.x; ds[n][p + 1] = u.y; ds[n][p + 2] = u.z; ds[n][p + 3] = u.w;
-      }
-  }
-  const float Dh = D[hh * p_hs];
-  const float a = __expf(A_log[hh * p_hs]);
-  const float bias = dt_bias[hh * p_hs];
-  const int g = hh % G;
-  float accD = 0.f, accB = 0.f, accA = 0.f;
-  // all lanes of a token take part in the head reduction, so the loop bound is per-slot (uniform per token)
+  for (int j = 0; j < HPL * 3; ++j) sacc[j][threadIdx.x] = 0.f;
   for (int64_t l = l0 + slot; l < l1; l += slots) {
     const int64_t row = (int64_t)b * L + l;
-    float dBv[N], dCv[N];
-    if (hv) {
-      float v[P], gy[P], kb[N], t[P], o[P];
+    float kb[N], dBv[N], dCv[N];
+    load_vec<T, N>(Bm + row * ldb + g * N, kb);
+#pragma unroll
+    for (int n = 0; n < N; ++n) dBv[n] = dCv[n] = 0.f;
+#pragma unroll 1
+    for (int j = 0; j < HPL; ++j) {   // not unrolled: keeps the live state at one head (the accumulators above live in LDS for that)
+      const int hl = g + G * j, h = h0 + hl;
+      if (h >= H) continue;
+      float v[P], gy[P], t[P], o[P];
       load_vec<T, P>(x + row * ldx + (int64_t)h * P, v);
       load_vec<T, P>(dy + row * lddy + (int64_t)h * P, gy);
-      load_vec<T, N>(Bm + row * ldb + g * N, kb);
-      const float z = Io<T>::ld(dt_raw + row * lddt + h * dt_hs) + bias;
-      const float dt = softplusf_(z);
-      const float w = dt * a;
+      const float a = sc[hl][0], z = Io<T>::ld(dt_raw + row * lddt + h * dt_hs) + sc[hl][1], Dh = sc[hl][2];
+      const float w = softplusf_(z) * a;
+      const float* S = sS + hl * SST;
+      const float* Dk = sD + hl * SST;
       float dd = 0.f, dw = 0.f;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         t[p] = 0.f;
         dd = fmaf(gy[p], v[p], dd);
       }
-      accD += dd;
 #pragma unroll
       for (int n = 0; n < N; ++n) {
+        float sv[P], dv[P];
+#pragma unroll
+        for (int p = 0; p < P; p += 4) {
+          const float4 s4 = *reinterpret_cast<const float4*>(S + n * P + p), d4 = *reinterpret_cast<const float4*>(Dk + n * P + p);
+          sv[p] = s4.x; sv[p + 1] = s4.y; sv[p + 2] = s4.z; sv[p + 3] = s4.w;
+          dv[p] = d4.x; dv[p + 1] = d4.y; dv[p + 2] = d4.z; dv[p + 3] = d4.w;
+        }
         float cb = 0.f, cc = 0.f;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-          t[p] = fmaf(kb[n], ds[n][p], t[p]);
-          cb = fmaf(ds[n][p], v[p], cb);
-          cc = fmaf(gy[p], s[n][p], cc);
+          t[p] = fmaf(kb[n], dv[p], t[p]);
+          cb = fmaf(dv[p], v[p], cb);
+          cc = fmaf(gy[p], sv[p], cc);
         }
-        dBv[n] = cb * w;
-        dCv[n] = cc;
+        dBv[n] = fmaf(cb, w, dBv[n]);
+        dCv[n] += cc;
       }
 #pragma unroll
       for (int p = 0; p < P; ++p) {
@@ -288,46 +321,34 @@ __global__ __launch_bounds__(kBlock) void ssd_bwd_kernel(
       store_vec<T, P>(dx + row * lddx + (int64_t)h * P, o);
       const float dz = dw * a * sigmoidf_(z);
       Io<T>::st(ddt_raw + row * ldddt + h * dt_hs, dz);
-      accB += dz;
-      accA = fmaf(dw, w, accA);
+      sacc[j * 3][threadIdx.x] += dd;
+      sacc[j * 3 + 1][threadIdx.x] += dz;
+      sacc[j * 3 + 2][threadIdx.x] += dw * w;
+    }
+    if (nhb == 1) {
+      store_vec<T, N>(dBm + row * lddb + g * N, dBv);
+      store_vec<T, N>(dCm + row * lddc + g * N, dCv);
     } else {
+      float* dst = bcpart + (((int64_t)blockIdx.y * gridDim.z + b) * L + l) * (2 * G * N);
 #pragma unroll
-      for (int n = 0; n < N; ++n) dBv[n] = dCv[n] = 0.f;
-    }
-    // sum over the heads of this token that share the K/Q group: lanes whose hl differs in bits >= log2(G)
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) {
-        if (o < hb && o >= G) {
-          dBv[n] += __shfl_xor(dBv[n], o, 64);
-          dCv[n] += __shfl_xor(dCv[n], o, 64);
-        }
-      }
-    }
-    if (hl < G) {
-      if (nhb == 1) {
-        store_vec<T, N>(dBm + row * lddb + hl * N, dBv);
-        store_vec<T, N>(dCm + row * lddc + hl * N, dCv);
-      } else {
-        float* dst = bcpart + (((int64_t)blockIdx.y * gridDim.z + b) * L + l) * (2 * G * N);
-#pragma unroll
-        for (int n = 0; n < N; n += 4) {
-          *reinterpret_cast<float4*>(dst + hl * N + n) = make_float4(dBv[n], dBv[n + 1], dBv[n + 2], dBv[n + 3]);
-          *reinterpret_cast<float4*>(dst + G * N + hl * N + n) = make_float4(dCv[n], dCv[n + 1], dCv[n + 2], dCv[n + 3]);
-        }
+      for (int n = 0; n < N; n += 4) {
+        *reinterpret_cast<float4*>(dst + g * N + n) = make_float4(dBv[n], dBv[n + 1], dBv[n + 2], dBv[n + 3]);
+        *reinterpret_cast<float4*>(dst + G * N + g * N + n) = make_float4(dCv[n], dCv[n + 1], dCv[n + 2], dCv[n + 3]);
       }
     }
   }
-  accD = wave_sum_from(accD, hb);
-  accB = wave_sum_from(accB, hb);
-  accA = wave_sum_from(accA, hb);
+  // per-head statistics: sum over the token slots of the wave (lanes of equal g), then over the waves through LDS
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane < hb && hv) {
-    float* dst = hpart + ((((int64_t)b * nblk + blockIdx.x) * kWaves + wave) * 3) * H + h;
-    dst[0] = accD;
-    dst[H] = accB;
-    dst[2 * H] = accA;
+  for (int j = 0; j < HPL; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float v = wave_sum_from(sacc[j * 3 + k][threadIdx.x], G);
+      if (lane < G) sred[wave][(g + G * j) * 3 + k] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < kBwdHeads * 3) {
+    const int hl = threadIdx.x / 3, k = threadIdx.x % 3, h = h0 + hl;
+    if (h < H) hpart[(((int64_t)b * nblk + blockIdx.x) * 3 + k) * H + h] = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
   }
 }
 
@@ -361,8 +382,9 @@ Ws carve(void* ws, int64_t B, int64_t L, int64_t H, int64_t P, int64_t N, int64_
   };
   w.part = take(B * g.nchunk * H * N * P);
   w.dkv = take(B * H * N * P);
-  w.hpart = take(B * g.nblk2 * kWaves * 3 * H);
-  w.bcpart = take(g.nhb > 1 ? (int64_t)g.nhb * B * L * 2 * G * N : 0);
+  const BwdGeo bg = make_bwd_geo(B, L, H, G);
+  w.hpart = take(B * bg.nblk * 3 * H);
+  w.bcpart = take(bg.nhb > 1 ? (int64_t)bg.nhb * B * L * 2 * G * N : 0);
   w.bytes = off;
   return w;
 }
@@ -418,17 +440,27 @@ void run_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const voi
              int64_t p_hs, const float* kv, const float* dkv, void* dx, int64_t lddx, void* dBm, int64_t lddb, void* dCm,
              int64_t lddc, void* ddt_raw, int64_t ldddt, float* hpart, float* bcpart, float* ddt_bias, float* dA_log, float* dD,
              int64_t B, int64_t L, int64_t H, int64_t G, hipStream_t st) {
-  const Geo g = make_geo(L, H);
-  { ADNM_PROF("ssd_bwd", st, (double)sizeof(T) * B * L * (3 * H * P + 4 * G * N + 2 * H)); ssd_bwd_kernel<T, P, N><<<dim3(g.nblk2, g.nhb, (unsigned)B), kBlock, 0, st>>>(
-      (const T*)dy, lddy, (const T*)x, ldx, (const T*)Bm, ldb, (const T*)Cm, ldc, (const T*)dt_raw, lddt, dt_hs, dt_bias, A_log, D,
-      p_hs, kv, dkv, (T*)dx, lddx, (T*)dBm, lddb, (T*)dCm, lddc, (T*)ddt_raw, ldddt, hpart, bcpart, L, (int)H, (int)G, g.hb,
-      g.tok2, g.nblk2, g.nhb); }
+  (void)Cm;
+  (void)ldc;
+  const BwdGeo g = make_bwd_geo(B, L, H, G);
+  const dim3 grid(g.nblk, g.nhb, (unsigned)B);
+#define ADNM_SSD_BWD(GG)                                                                                                              \
+  ssd_bwd_kernel<T, P, N, GG><<<grid, kBlock, 0, st>>>((const T*)dy, lddy, (const T*)x, ldx, (const T*)Bm, ldb, (const T*)dt_raw, lddt, \
+                                                       dt_hs, dt_bias, A_log, D, p_hs, kv, dkv, (T*)dx, lddx, (T*)dBm, lddb, (T*)dCm,   \
+                                                       lddc, (T*)ddt_raw, ldddt, hpart, bcpart, L, (int)H, g.tok, g.nblk, g.nhb)
+  {
+    ADNM_PROF("ssd_bwd", st, (double)sizeof(T) * B * L * (3 * H * P + 4 * G * N + 2 * H));
+    if (G == 1) ADNM_SSD_BWD(1);
+    else if (G == 2) ADNM_SSD_BWD(2);
+    else ADNM_SSD_BWD(4);
+  }
+#undef ADNM_SSD_BWD
   if (g.nhb > 1) {
     const int64_t tot = B * L * 2 * G * N;
     { ADNM_PROF("ssd_bc_fold", st, 4.0 * tot * g.nhb); ssd_bc_fold_kernel<T><<<(unsigned)adnm_cdiv(tot, 256), 256, 0, st>>>(bcpart, g.nhb, B * L, (int)(G * N), (T*)dBm, lddb, (T*)dCm,
                                                                          lddc); }
   }
-  adnm_launch_fold("ssd_head_fold", hpart, (int)(B * g.nblk2 * kWaves), 3 * (int)H, {dD, (int)H}, {ddt_bias, (int)H}, {dA_log, (int)H}, {nullptr, 0}, st);
+  adnm_launch_fold("ssd_head_fold", hpart, (int)(B * g.nblk), 3 * (int)H, {dD, (int)H}, {ddt_bias, (int)H}, {dA_log, (int)H}, {nullptr, 0}, st);
 }
 
 }  // namespace

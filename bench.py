@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--prof-steps", type=int, default=3)
+    ap.add_argument("--dump-prof", default="", help="write the per-(kernel, shape) HIP-event table of the instrumented steps to this file")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): replay fwd+bwd as a captured hipGraph; 0: eager launches")
     ap.add_argument("--blas", default="hipblas", choices=["default", "hipblas", "hipblaslt"],
                     help="library used for the plain GEMMs (default rocBLAS: its long-reduction weight-grad GEMMs are 6x faster here)")
@@ -208,6 +209,12 @@ def main():
 
     if rank == 0:
         total_ms = sum(r["ms"] for r in prof.values()) or 1.0
+        if args.dump_prof:
+            with open(args.dump_prof, "w") as f:
+                f.write("kernel@bytes_per_launch\tlaunches_per_step\tavg_us\tms_per_step\tGB/s\n")
+                for key, r in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+                    f.write(f"{key}\t{r['launches'] / args.prof_steps:.1f}\t{1e3 * r['ms'] / r['launches']:.2f}\t{r['ms'] / args.prof_steps:.4f}\t"
+                            f"{r['bytes'] / max(r['ms'], 1e-9) / 1e6:.1f}\n")
         # the dominant kernel = the (kernel, shape) instance with the largest share of the HIP-kernel time
         dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
         roofline = None
