@@ -56,6 +56,23 @@ def collect_profile(lib):
     return rows
 
 
+# profiler scope name -> device kernel name, for the kernels whose every launch has ONE shape (so the per-kernel PMC
+# average of profiles/r01_pmc_traffic.json IS the per-launch traffic of that shape)
+PMC_KERNEL = {"adamw_update": "adamw_kernel", "grad_sumsq": "sumsq_partial_kernel"}
+
+
+def pmc_traffic(scope_name):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.py) of this
+    same command; None when that kernel runs several shapes or no PMC pass is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    dev = PMC_KERNEL.get(scope_name)
+    if dev is None or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rec = json.load(f).get(dev)
+    return round(rec["hbm_bytes_per_launch"]) if rec else None
+
+
 def by_kernel(rows):
     out = {}
     for key, r in rows.items():
@@ -228,7 +245,7 @@ def main():
             ach = r["bytes"] / (r["ms"] * 1e-3) / 1e9
             roofline = {"kernel": name.split("@")[0], "shape_bytes": int(float(name.split("@")[1])), "launches_per_step": r["launches"] / args.prof_steps,
                         "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name.split("@")[0]),
                         "avg_launch_us": round(1e3 * r["ms"] / r["launches"], 2),
                         "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"]),
                         "hip_kernels_ms_per_step": round(total_ms / args.prof_steps, 3),
