@@ -34,25 +34,48 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
   // Global reads run along the weight's contiguous axis (k for the forward layout, n for the transposed one).
   {
     const int total = NB * 16 * K;
-    for (int idx = threadIdx.x; idx < total; idx += kBlock) {
-      int n, k;
-      if (ws_k == 1) { n = idx / K; k = idx - n * K; }
-      else { k = idx / (NB * 16); n = idx - k * (NB * 16); }
-      const float v = n < N ? w[(int64_t)n * ws_n + (int64_t)k * ws_k] : 0.f;
-      const int cb = n >> 4, j = n & 15, q = k >> 4, kk = (k >> 2) & 3, e = k & 3;
-      wl[(cb * ksteps + (q * 4 + e)) * 64 + kk * 16 + j] = v;
+    constexpr int kU = 8;   // loads issued back to back before the first LDS write: one HBM round trip per 4096 elements
+    for (int base = 0; base < total; base += kBlock * kU) {
+      float v[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int idx = base + u * kBlock + threadIdx.x;
+        int n, k;
+        if (ws_k == 1) { n = idx / K; k = idx - n * K; }
+        else { k = idx / (NB * 16); n = idx - k * (NB * 16); }
+        v[u] = (idx < total && n < N) ? w[(int64_t)n * ws_n + (int64_t)k * ws_k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int idx = base + u * kBlock + threadIdx.x;
+        if (idx >= total) continue;
+        int n, k;
+        if (ws_k == 1) { n = idx / K; k = idx - n * K; }
+        else { k = idx / (NB * 16); n = idx - k * (NB * 16); }
+        const int cb = n >> 4, j = n & 15, q = k >> 4, kk = (k >> 2) & 3, e = k & 3;
+        wl[(cb * ksteps + (q * 4 + e)) * 64 + kk * 16 + j] = v[u];
+      }
     }
   }
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
   const int64_t nrb = (M + 15) >> 4;
-  for (int64_t rb = (int64_t)blockIdx.x * kWaves + wave; rb < nrb; rb += (int64_t)gridDim.x * kWaves) {
-    const int64_t row = rb * 16 + i;
-    const bool rv = row < M;
-    float4 xa[KQ];
+  const int64_t stride = (int64_t)gridDim.x * kWaves;
+  int64_t rb = (int64_t)blockIdx.x * kWaves + wave;
+  // the first row block's loads are in flight while the weight is being staged; inside the loop the NEXT block's
+  // loads are issued before the current block's MFMAs, so a wave never waits for HBM with an idle matrix pipe
+  float4 xa[KQ], xn[KQ];
+  auto fetch = [&](int64_t b, float4 (&dst)[KQ]) {
+    const int64_t row = b * 16 + i;
+    const bool rv = b < nrb && row < M;
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) xa[q] = rv ? *reinterpret_cast<const float4*>(x + row * ldx + 16 * q + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < KQ; ++q) dst[q] = rv ? *reinterpret_cast<const float4*>(x + row * ldx + 16 * q + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  constexpr bool kPrefetch = KQ < 16 && NB < 16;   // the widest variants have no registers to spare for a second row block
+  fetch(rb, xa);
+  __syncthreads();
+  for (; rb < nrb; rb += stride) {
+    if (kPrefetch) fetch(rb + stride, xn);
     f32x4 acc[NB];
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -79,6 +102,12 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
         }
       }
     }
+    if (kPrefetch) {
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) xa[q] = xn[q];
+    } else {
+      fetch(rb + stride, xa);
+    }
   }
 }
 
@@ -88,7 +117,7 @@ template <int NBN, int NBK>
 __global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                                                            int64_t ldx, float* __restrict__ part, float* __restrict__ bpart, int64_t M,
                                                            int N, int K) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // NBN*NBK*256 + NBN*16
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // 4 x (NBN*NBK*256 + NBN*16)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
   const int nb0 = blockIdx.y * NBN * 16;  // first output row (n) of this block's tile
@@ -101,52 +130,66 @@ __global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const float* __restri
     for (int b = 0; b < NBK; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int64_t nmb = (M + 3) >> 2;
-  for (int64_t mb = (int64_t)blockIdx.x * kWaves + wave; mb < nmb; mb += (int64_t)gridDim.x * kWaves) {
+  const int64_t stride = (int64_t)gridDim.x * kWaves;
+  float av[NBN], bv[NBK], an[NBN], bn[NBK];
+  auto fetch = [&](int64_t mb, float (&a_)[NBN], float (&b_)[NBK]) {
     const int64_t m = mb * 4 + kk;
-    const bool mv = m < M;
-    float av[NBN], bv[NBK];
+    const bool mv = mb < nmb && m < M;
 #pragma unroll
     for (int a = 0; a < NBN; ++a) {
       const int n = nb0 + a * 16 + i;
-      av[a] = (mv && n < N) ? dy[m * lddy + n] : 0.f;
-      bsum[a] += av[a];
+      a_[a] = (mv && n < N) ? dy[m * lddy + n] : 0.f;
     }
 #pragma unroll
     for (int b = 0; b < NBK; ++b) {
       const int k = b * 16 + i;
-      bv[b] = (mv && k < K) ? x[m * ldx + k] : 0.f;
+      b_[b] = (mv && k < K) ? x[m * ldx + k] : 0.f;
     }
+  };
+  int64_t mb = (int64_t)blockIdx.x * kWaves + wave;
+  fetch(mb, av, bv);
+  for (; mb < nmb; mb += stride) {
+    fetch(mb + stride, an, bn);   // next round's loads fly under this round's MFMAs
+#pragma unroll
+    for (int a = 0; a < NBN; ++a) bsum[a] += av[a];
 #pragma unroll
     for (int a = 0; a < NBN; ++a)
 #pragma unroll
       for (int b = 0; b < NBK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < NBN; ++a) av[a] = an[a];
+#pragma unroll
+    for (int b = 0; b < NBK; ++b) bv[b] = bn[b];
   }
   // bias gradient: lanes with the same i (n) but different kk hold different m's
 #pragma unroll
   for (int a = 0; a < NBN; ++a) bsum[a] += __shfl_xor(bsum[a], 16, 64), bsum[a] += __shfl_xor(bsum[a], 32, 64);
-  // fold the waves through ONE LDS buffer, one wave per round (keeps LDS at N*K floats -> several blocks per CU)
-  constexpr int kAcc = NBN * NBK * 256;
-  for (int wv = 1; wv < kWaves; ++wv) {
-    if (wave == wv) {
+  // fold the 8 waves as a tree through 4 LDS buffers (3 rounds; upper half writes, lower half adds) — deterministic order
+  constexpr int kAcc = NBN * NBK * 256, kBuf = kAcc + NBN * 16;
+#pragma unroll
+  for (int half = kWaves / 2; half >= 1; half >>= 1) {
+    if (wave >= half && wave < 2 * half) {
+      float* buf = sm + (wave - half) * kBuf;
 #pragma unroll
       for (int a = 0; a < NBN; ++a)
 #pragma unroll
         for (int b = 0; b < NBK; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sm[((a * NBK + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+          for (int r = 0; r < 4; ++r) buf[((a * NBK + b) * 4 + r) * 64 + lane] = acc[a][b][r];
       if (kk == 0)
 #pragma unroll
-        for (int a = 0; a < NBN; ++a) sm[kAcc + a * 16 + i] = bsum[a];
+        for (int a = 0; a < NBN; ++a) buf[kAcc + a * 16 + i] = bsum[a];
     }
     __syncthreads();
-    if (wave == 0) {
+    if (wave < half) {
+      const float* buf = sm + wave * kBuf;
 #pragma unroll
       for (int a = 0; a < NBN; ++a) {
 #pragma unroll
         for (int b = 0; b < NBK; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[a][b][r] += sm[((a * NBK + b) * 4 + r) * 64 + lane];
-        if (kk == 0) bsum[a] += sm[kAcc + a * 16 + i];
+          for (int r = 0; r < 4; ++r) acc[a][b][r] += buf[((a * NBK + b) * 4 + r) * 64 + lane];
+        if (kk == 0) bsum[a] += buf[kAcc + a * 16 + i];
       }
     }
     __syncthreads();
@@ -191,14 +234,20 @@ void launch_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_
 template <int NBN, int NBK>
 void launch_tn(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* part, float* bpart, int64_t M, int N, int K, int nblk,
                int ntiles, hipStream_t st) {
-  const size_t smem = (size_t)(NBN * NBK * 256 + NBN * 16) * sizeof(float);
+  const size_t smem = (size_t)(kWaves / 2) * (NBN * NBK * 256 + NBN * 16) * sizeof(float);
+  static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in (host-side attribute, not a stream operation)
+  if (!attr_set && smem > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)tsgemm_tn_kernel<NBN, NBK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
   ADNM_PROF("tsgemm_tn", st, 4.0 * ((double)M * (K + N) + (double)N * K));
   tsgemm_tn_kernel<NBN, NBK><<<dim3(nblk, ntiles), kBlock, smem, st>>>(dy, lddy, x, ldx, part, bpart, M, N, K);
 }
 
 // tile the N axis so that one block keeps at most 32 accumulator blocks: returns NBN (blocks of 16 rows per tile)
+// (<= 16 blocks = 64 accumulator VGPRs, 26 for the 13-wide in_proj case: the 32-block variants spill to scratch)
 inline int tn_tile(int nbn_total, int nbk) {
-  int t = 32 / nbk;
+  int t = nbk == 13 ? 2 : 16 / nbk;
   if (t > 16) t = 16;
   while (t > 1 && (t & (t - 1))) --t;  // power of two -> an instantiated NBN
   if (t >= nbn_total) return -1;        // fits without tiling
@@ -245,7 +294,7 @@ extern "C" int adnm_tsgemm_nt(const float* x, int64_t ldx, const float* w, int64
 extern "C" int adnm_tsgemm_tn_supported(int64_t M, int64_t N, int64_t K) {
   if (M < 1 || N < 1 || K < 1 || N > 1024 || K > 256) return 0;
   const int b = pick((int)adnm_cdiv(K, 16), kNB, 6);
-  return b > 0 ? 1 : 0;  // N is tiled over blockIdx.y when N/16 * K/16 > 32 accumulator blocks
+  return b > 0 ? 1 : 0;  // N is tiled over blockIdx.y when N/16 * K/16 > 26 accumulator blocks
 }
 extern "C" int64_t adnm_tsgemm_tn_ws_bytes(int64_t M, int64_t N, int64_t K) { return (int64_t)tn_blocks(M) * (N * K + N) * (int64_t)sizeof(float); }
 
@@ -262,7 +311,7 @@ extern "C" int adnm_tsgemm_tn(const float* dy, int64_t lddy, const float* x, int
   const int b = pick((int)adnm_cdiv(K, 16), kNB, 6);
   const int nbn_total = (int)adnm_cdiv(N, 16);
   int a = pick(nbn_total, kNB, 6), ntiles = 1;
-  if (a < 0 || a * b > 32) {
+  if (a < 0 || a * b > 26) {
     a = tn_tile(nbn_total, b);
     if (a < 0) a = 1;
     ntiles = (int)adnm_cdiv(nbn_total, a);
@@ -272,8 +321,8 @@ extern "C" int adnm_tsgemm_tn(const float* dy, int64_t lddy, const float* x, int
   float* bpart = dbias ? part + (int64_t)nblk * N * K : nullptr;
   hipStream_t st = (hipStream_t)stream;
 #define TN(A, B) if (a == A && b == B) launch_tn<A, B>(dy, lddy, x, ldx, part, bpart, M, (int)N, (int)K, nblk, ntiles, st)
-  TN(1, 1); TN(1, 2); TN(1, 4); TN(1, 8); TN(1, 13); TN(1, 16); TN(2, 1); TN(2, 2); TN(2, 4); TN(2, 8); TN(2, 13); TN(2, 16);
-  TN(4, 1); TN(4, 2); TN(4, 4); TN(4, 8); TN(8, 1); TN(8, 2); TN(8, 4); TN(13, 1); TN(13, 2); TN(16, 1); TN(16, 2);
+  TN(1, 1); TN(1, 2); TN(1, 4); TN(1, 8); TN(1, 13); TN(1, 16); TN(2, 1); TN(2, 2); TN(2, 4); TN(2, 8); TN(2, 13);
+  TN(4, 1); TN(4, 2); TN(4, 4); TN(8, 1); TN(8, 2); TN(13, 1); TN(13, 2); TN(16, 1);
 #undef TN
   ADNM_CHECK_LAUNCH("tsgemm_tn");
   adnm_launch_fold("tsgemm_tn_fold", part, nblk, (int)(N * K), {dw, (int)(N * K)}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
