@@ -773,6 +773,25 @@ def ts_ok_tn(M, N, K, x):
     return (x.is_cuda and x.dtype == torch.float32 and M >= TS_MIN_ROWS and lib.query("adnm_tsgemm_tn_supported", M, N, K) == 1)
 
 
+SK_NT, SK_NN, SK_TN = 0, 1, 2
+SK_MAX_ROWS = 16   # measured on MI355X: the kernel wins where the library collapses (Channel_Att_Bridge: 4 rows x 2144 features,
+#                    12 us vs 40-120 us); from 64 rows up rocBLAS is as fast or faster, so those shapes stay with the library
+
+
+def sk_ok(op, M, N, K, *tensors):
+    """Short-GEMM kernel (csrc/skgemm.hip): every fp32 Linear the tall-skinny kernel does not take, up to SK_MAX_ROWS rows."""
+    return (M <= SK_MAX_ROWS and all(t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1 and t.stride(0) % 4 == 0
+                                     and t.data_ptr() % 16 == 0 for t in tensors)
+            and lib.query("adnm_skgemm_supported", op, M, N, K) == 1)
+
+
+def _skgemm(op, a, b, bias, c, dbias, M, N, K):
+    nb = lib.query("adnm_skgemm_ws_bytes", op, M, N, K)
+    ws = _ws(nb, a.device)
+    lib.call("adnm_skgemm", op, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _p(bias), c.data_ptr(), c.stride(0), _p(dbias),
+             ws.data_ptr(), nb, M, N, K, _stream())
+
+
 def k_linear(x2, w, bias, out=None):
     """Y = X W^T (+bias) for row views X (M,K) [stride (ld,1)], W (N,K) contiguous: MFMA tall-skinny kernel when the shape
     fits, the library GEMM otherwise."""
@@ -781,6 +800,10 @@ def k_linear(x2, w, bias, out=None):
     if ts_ok_nt(M, N, K, x2) and x2.stride(0) % 4 == 0:
         y = out if out is not None else torch.empty((M, N), dtype=x2.dtype, device=x2.device)
         lib.call("adnm_tsgemm_nt", x2.data_ptr(), x2.stride(0), w.data_ptr(), K, 1, _p(bias), y.data_ptr(), y.stride(0), M, N, K, _stream())
+        return y
+    if sk_ok(SK_NT, M, N, K, x2, w) and (out is None or (out.stride(-1) == 1 and out.stride(0) % 4 == 0)) and N % 4 == 0:
+        y = out if out is not None else torch.empty((M, N), dtype=x2.dtype, device=x2.device)
+        _skgemm(SK_NT, x2, w, bias, y, None, M, N, K)
         return y
     y = torch.mm(x2, w.t()) if bias is None else torch.addmm(bias, x2, w.t())
     if out is not None:
@@ -796,6 +819,10 @@ def k_linear_dx(dy2, w, out=None):
     if ts_ok_nt(M, K, N, dy2) and dy2.stride(0) % 4 == 0:
         dx = out if out is not None else torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
         lib.call("adnm_tsgemm_nt", dy2.data_ptr(), dy2.stride(0), w.data_ptr(), 1, K, None, dx.data_ptr(), dx.stride(0), M, K, N, _stream())
+        return dx
+    if sk_ok(SK_NN, M, N, K, dy2, w) and (out is None or (out.stride(-1) == 1 and out.stride(0) % 4 == 0)):
+        dx = out if out is not None else torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
+        _skgemm(SK_NN, dy2, w, None, dx, None, M, N, K)
         return dx
     dx = torch.mm(dy2, w)
     if out is not None:
@@ -816,6 +843,11 @@ def k_linear_dw(dy2, x2, want_bias):
         ws = _ws(nb, dev)
         lib.call("adnm_tsgemm_tn", dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), dw.data_ptr(), _p(db), ws.data_ptr(), nb, M, N, K,
                  _stream())
+        return dw, db
+    if sk_ok(SK_TN, M, N, K, dy2, x2):
+        dw = torch.empty((N, K), dtype=torch.float32, device=x2.device)
+        db = torch.empty(N, dtype=torch.float32, device=x2.device) if want_bias else None
+        _skgemm(SK_TN, dy2, x2, None, dw, db, M, N, K)
         return dw, db
     return torch.mm(dy2.t(), x2), (dy2.sum(0) if want_bias else None)
 
@@ -848,9 +880,8 @@ class LinearFn(torch.autograd.Function):
 
 
 def linear(x, w, bias=None):
-    M = x.numel() // x.shape[-1]
-    if x.is_cuda and M >= TS_MIN_ROWS and x.dtype == torch.float32 and w.dim() == 2 and (
-            lib.query("adnm_tsgemm_supported", M, w.shape[0], w.shape[1]) == 1 or lib.query("adnm_tsgemm_tn_supported", M, w.shape[0], w.shape[1]) == 1):
+    """nn.Linear on tokens: MFMA kernels (tall-skinny / short GEMM) where a shape fits, the library GEMM otherwise."""
+    if x.is_cuda and x.dtype == torch.float32 and w.dim() == 2:
         return LinearFn.apply(x, w, bias)
     return torch.nn.functional.linear(x, w, bias)
 

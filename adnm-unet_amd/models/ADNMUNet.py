@@ -85,7 +85,7 @@ class Block(nn.Module):
             x = ops.lincomb([x, self.ffns[i].forward_tokens(xn, h, w)], [beta1, beta2])
         x = ops.lincomb([x], [None], self.gamma)
         if self.dim != self.out_dim:
-            x = self.out_proj(x)
+            x = ops.linear(x, self.out_proj.weight, self.out_proj.bias)
         return x
 
 
@@ -118,7 +118,7 @@ class Attention(nn.Module):
         x = ops.lincomb([x, self.attn_mlp(xn)], [self.beta3, self.beta4])
         x = ops.lincomb([x], [None], self.gamma)
         if self.dim != self.out_dim:
-            x = self.out_proj(x)
+            x = ops.linear(x, self.out_proj.weight, self.out_proj.bias)
         return x
 
 

@@ -37,11 +37,11 @@ class StandardAttention(nn.Module):
 
     def forward(self, x, H, W):
         b, n, _ = x.shape
-        q, k, v = self.to_qkv(x).chunk(3, dim=-1)
+        q, k, v = ops.linear(x, self.to_qkv.weight, None).chunk(3, dim=-1)
         sp = lambda t: t.reshape(b, n, self.heads, -1).transpose(1, 2)
         att = self.dropout(torch.softmax(torch.matmul(sp(q), sp(k).transpose(-1, -2)) * self.scale, dim=-1))
         out = torch.matmul(att, sp(v)).transpose(1, 2).reshape(b, n, self.inner_dim)
-        return self.to_out(out)
+        return ops.linear(out, self.to_out.weight, self.to_out.bias)
 
 
 def _dw(channels, k, pad, bias):

@@ -309,13 +309,13 @@ class ConvFFD(nn.Module):
     def forward(self, x):
         b, l, d = x.shape
         h, w = _hw(l)
-        x = self.in_proj(x)
+        x = ops.linear(x, self.in_proj.weight, self.in_proj.bias)
         c = self.dw_conv.conv
         if x.shape[-1] % 4 == 0:
             x = ops.dwconv(x, c.weight, c.bias, h, w, lib.ACT_GELU)  # conv + GELU (model_untils.py:219-220)
         else:
             x = self.act(self.dw_conv.forward_tokens(x, h, w))
-        return self.out_proj(x)
+        return ops.linear(x, self.out_proj.weight, self.out_proj.bias)
 
 
 class PatchEmbed(nn.Module):
@@ -449,7 +449,8 @@ class Channel_Att_Bridge(nn.Module):
         for i in range(7):
             if live is not None and i not in live:
                 continue
-            out[i] = self.sigmoid1(getattr(self, f"att{i + 1}")(att))
+            lin = getattr(self, f"att{i + 1}")
+            out[i] = self.sigmoid1(ops.linear(att, lin.weight, lin.bias))
         return out
 
 

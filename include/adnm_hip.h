@@ -207,6 +207,22 @@ int64_t adnm_skipgate_bwd_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t C);
 int adnm_skipgate_bwd(const float* dout, const float* x, const float* const* params, const float* pooled, const float* conv, float* dx,
                       float* dparams, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W, int64_t C, adnm_stream_t stream);
 
+/* ---------------------------------------------------------------- short GEMMs of the deep stages (K6b, MFMA)
+ * nn.Linear with M <= 65536 token rows and up to 16384 features: Mamba2.in_proj/out_proj (ADNssd.py:309,461),
+ * FeedForward.project_in/out (model_untils.py:193,196), Mlp (:64,67), ConvFFD (:217,221), Block.out_proj (ADNMUNet.py:163),
+ * StandardAttention.to_qkv/to_out (ADNssd.py:33-34), Channel_Att_Bridge.att* (model_untils.py:744-750).  fp32, row-major:
+ *   ADNM_SKGEMM_NT: c[M,N] = a[M,K] . b[N,K]^T (+ bias[N])           forward          K % 16 == 0
+ *   ADNM_SKGEMM_NN: c[M,K] = a[M,N] . b[N,K]                         input gradient   N % 16 == 0, K % 4 == 0
+ *   ADNM_SKGEMM_TN: c[N,K] = a[M,N]^T . b[M,K]; dbias[N] = sum_m a   weight gradient  N % 4 == 0, K % 4 == 0
+ * lda / ldb / ldc: row strides in elements (multiples of 4); bias only with NT, dbias only with TN; c / dbias OVERWRITTEN. */
+#define ADNM_SKGEMM_NT 0
+#define ADNM_SKGEMM_NN 1
+#define ADNM_SKGEMM_TN 2
+int adnm_skgemm_supported(int op, int64_t M, int64_t N, int64_t K);
+int64_t adnm_skgemm_ws_bytes(int op, int64_t M, int64_t N, int64_t K);
+int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, float* dbias,
+                void* ws, int64_t ws_bytes, int64_t M, int64_t N, int64_t K, adnm_stream_t stream);
+
 /* ---------------------------------------------------------------- enRainfallLoss (K14)
  * models/loss.py:30-57 of the reference (train_untils.py:43 builds it with omega_t 0.57, alpha 0.25, gamma 0):
  * loss (1 float) and grad = d loss / d pred (n floats) in one pass over contiguous fp32 pred / target. */

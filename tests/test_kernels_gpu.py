@@ -488,3 +488,43 @@ def test_rownorm_tap(mean):
     assert_close(xg.grad, xo.grad, GRAD_TOL, "dx (norm + residual)")
     assert_close(wg.grad, wo.grad, GRAD_TOL, "dw")
     assert_close(sg.grad, so.grad, GRAD_TOL, "dscale")
+
+
+# ------------------------------------------------------------------------------------------- short GEMMs (K6b)
+@pytest.mark.parametrize("M,K,N,bias", [
+    (64, 2048, 1024, True),     # deepest Mamba2.out_proj: slices through partials + fold
+    (64, 1024, 4672, False),    # deepest in_proj
+    (256, 512, 2368, False),
+    (1024, 256, 1216, True),    # no split: direct stores
+    (4, 2144, 256, True),       # Channel_Att_Bridge.att*: 4 rows
+    (100, 48, 36, True),        # ragged tiles
+    (4096, 128, 544, False),
+])
+def test_skgemm_linear(M, K, N, bias, monkeypatch):
+    monkeypatch.setattr(ops, "SK_MAX_ROWS", 65536)   # exercise the kernel on every shape, not only where the product routes to it
+    x, w, cot = T(f"sk.x{M}{K}", (M, K)), T(f"sk.w{N}{K}", (N, K), 0.05), T(f"sk.c{M}{N}", (M, N))
+    b = T(f"sk.b{N}", (N,)) if bias else None
+    xo, wo, bo = leaf(x.double()), leaf(w.double()), (leaf(b.double()) if bias else None)
+    yo = F.linear(xo, wo, bo)
+    (yo * cot.double()).sum().backward()
+    assert lib.query("adnm_skgemm_supported", 0, M, N, K) == 1
+    xg, wg, bg = leaf(x, DEV), leaf(w, DEV), (leaf(b, DEV) if bias else None)
+    yg = ops.linear(xg, wg, bg)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, OUT_TOL, "y")
+    assert_close(xg.grad, xo.grad, GRAD_TOL, "dx")
+    assert_close(wg.grad, wo.grad, GRAD_TOL, "dw")
+    if bias:
+        assert_close(bg.grad, bo.grad, GRAD_TOL, "db")
+
+
+def test_skgemm_strided_operands(monkeypatch):
+    monkeypatch.setattr(ops, "SK_MAX_ROWS", 65536)
+    """column slices of wider buffers as input and output (how the mixer calls it): no partials for the strided output."""
+    M, K, N = 256, 512, 128
+    big_in, big_out = T("sks.in", (M, K + 64)).to(DEV), torch.zeros((M, N + 32), device=DEV)
+    w = T("sks.w", (N, K), 0.05).to(DEV)
+    y = ops.k_linear(big_in[:, 32:32 + K], w, None, out=big_out[:, 16:16 + N])
+    ref = big_in[:, 32:32 + K].double() @ w.double().t()
+    assert_close(y, ref, OUT_TOL, "strided y")
+    assert float(big_out[:, :16].abs().max()) == 0.0 and float(big_out[:, 16 + N:].abs().max()) == 0.0
