@@ -774,15 +774,42 @@ def ts_ok_tn(M, N, K, x):
 
 
 SK_NT, SK_NN, SK_TN = 0, 1, 2
-SK_MAX_ROWS = 16   # measured on MI355X: the kernel wins where the library collapses (Channel_Att_Bridge: 4 rows x 2144 features,
-#                    12 us vs 40-120 us); from 64 rows up rocBLAS is as fast or faster, so those shapes stay with the library
+SK_MAX_ROWS = 4096
+SK_FORCE = False      # tests: always take the kernel where the shape is supported
+_SK_CHOICE = {}       # (op, M, N, K, bias) -> True: skgemm, False: library — measured on first eager use
 
 
 def sk_ok(op, M, N, K, *tensors):
-    """Short-GEMM kernel (csrc/skgemm.hip): every fp32 Linear the tall-skinny kernel does not take, up to SK_MAX_ROWS rows."""
-    return (M <= SK_MAX_ROWS and all(t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1 and t.stride(0) % 4 == 0
-                                     and t.data_ptr() % 16 == 0 for t in tensors)
+    """Short-GEMM kernel (csrc/skgemm.hip) candidate: an fp32 Linear the tall-skinny kernel does not take."""
+    return ((SK_FORCE or M <= SK_MAX_ROWS) and all(t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1 and t.stride(0) % 4 == 0
+                                                   and t.data_ptr() % 16 == 0 for t in tensors)
             and lib.query("adnm_skgemm_supported", op, M, N, K) == 1)
+
+
+def sk_pick(key, run_sk, run_lib):
+    """Measure, don't guess: rocBLAS / hipBLASLt pick excellent kernels for most of these shapes and pathological ones for a
+    few (one 256x256 macro tile for a 256x512x256 Linear: 123 us, ours 15).  The first EAGER use of a shape times both
+    (FlatTrainer's dry-run steps do that before the graph is captured); under capture an unseen shape goes to the library."""
+    if SK_FORCE:
+        return True
+    c = _SK_CHOICE.get(key)
+    if c is not None:
+        return c
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    best = []
+    for fn in (run_sk, run_lib):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        e1.synchronize()
+        best.append(e0.elapsed_time(e1))
+    _SK_CHOICE[key] = best[0] < 0.9 * best[1]   # the kernel has to win clearly
+    return _SK_CHOICE[key]
 
 
 def _skgemm(op, a, b, bias, c, dbias, M, N, K):
@@ -801,11 +828,13 @@ def k_linear(x2, w, bias, out=None):
         y = out if out is not None else torch.empty((M, N), dtype=x2.dtype, device=x2.device)
         lib.call("adnm_tsgemm_nt", x2.data_ptr(), x2.stride(0), w.data_ptr(), K, 1, _p(bias), y.data_ptr(), y.stride(0), M, N, K, _stream())
         return y
+    lib_nt = lambda: torch.mm(x2, w.t()) if bias is None else torch.addmm(bias, x2, w.t())
     if sk_ok(SK_NT, M, N, K, x2, w) and (out is None or (out.stride(-1) == 1 and out.stride(0) % 4 == 0)) and N % 4 == 0:
         y = out if out is not None else torch.empty((M, N), dtype=x2.dtype, device=x2.device)
-        _skgemm(SK_NT, x2, w, bias, y, None, M, N, K)
-        return y
-    y = torch.mm(x2, w.t()) if bias is None else torch.addmm(bias, x2, w.t())
+        if sk_pick((SK_NT, M, N, K, bias is not None), lambda: _skgemm(SK_NT, x2, w, bias, y, None, M, N, K), lib_nt):
+            _skgemm(SK_NT, x2, w, bias, y, None, M, N, K)
+            return y
+    y = lib_nt()
     if out is not None:
         out.copy_(y)
         return out
@@ -822,8 +851,9 @@ def k_linear_dx(dy2, w, out=None):
         return dx
     if sk_ok(SK_NN, M, N, K, dy2, w) and (out is None or (out.stride(-1) == 1 and out.stride(0) % 4 == 0)):
         dx = out if out is not None else torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
-        _skgemm(SK_NN, dy2, w, None, dx, None, M, N, K)
-        return dx
+        if sk_pick((SK_NN, M, N, K, False), lambda: _skgemm(SK_NN, dy2, w, None, dx, None, M, N, K), lambda: torch.mm(dy2, w)):
+            _skgemm(SK_NN, dy2, w, None, dx, None, M, N, K)
+            return dx
     dx = torch.mm(dy2, w)
     if out is not None:
         out.copy_(dx)
@@ -847,8 +877,10 @@ def k_linear_dw(dy2, x2, want_bias):
     if sk_ok(SK_TN, M, N, K, dy2, x2):
         dw = torch.empty((N, K), dtype=torch.float32, device=x2.device)
         db = torch.empty(N, dtype=torch.float32, device=x2.device) if want_bias else None
-        _skgemm(SK_TN, dy2, x2, None, dw, db, M, N, K)
-        return dw, db
+        if sk_pick((SK_TN, M, N, K, want_bias), lambda: _skgemm(SK_TN, dy2, x2, None, dw, db, M, N, K),
+                   lambda: (torch.mm(dy2.t(), x2), dy2.sum(0) if want_bias else None)):
+            _skgemm(SK_TN, dy2, x2, None, dw, db, M, N, K)
+            return dw, db
     return torch.mm(dy2.t(), x2), (dy2.sum(0) if want_bias else None)
 
 

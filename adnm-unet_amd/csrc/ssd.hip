@@ -53,12 +53,16 @@ inline BwdGeo make_bwd_geo(int64_t B, int64_t L, int64_t H, int64_t G) {
   return g;
 }
 
-inline Geo make_geo(int64_t L, int64_t H) {
+inline Geo make_geo(int64_t L, int64_t H, int64_t B = 4) {
   Geo g;
   g.hb = heads_per_block(H);
   g.slots = kBlock / g.hb;
   g.nhb = (int)adnm_cdiv(H, g.hb);
-  g.tok1 = g.slots * 16;
+  // tokens a lane walks in the reduction passes: 16 on the big maps; on the deep 4x4 .. 16x16 maps fewer, so that the grid
+  // still has ~256 workgroups (a 16-step dependent load chain on 16 workgroups cost 18 us for a 64-token reduction)
+  int64_t per_lane = (B * L * g.nhb) / ((int64_t)g.slots * 256);
+  per_lane = per_lane < 2 ? 2 : (per_lane > 16 ? 16 : per_lane);
+  g.tok1 = g.slots * (int)per_lane;
   g.nchunk = (int)adnm_cdiv(L, g.tok1);
   g.tok2 = g.slots * 8;
   g.nblk2 = (int)adnm_cdiv(L, g.tok2);
@@ -372,7 +376,7 @@ struct Ws {
 };
 
 Ws carve(void* ws, int64_t B, int64_t L, int64_t H, int64_t P, int64_t N, int64_t G) {
-  const Geo g = make_geo(L, H);
+  const Geo g = make_geo(L, H, B);
   Ws w;
   int64_t off = 0;
   auto take = [&](int64_t nfloat) {
@@ -411,7 +415,7 @@ template <typename T, int P, int N>
 void run_outer(bool weighted, const void* V, int64_t ldv, const void* K, int64_t ldk, const void* dt_raw, int64_t lddt,
                int64_t dt_hs, const float* dt_bias, const float* A_log, int64_t p_hs, float* part, float* out, int64_t B,
                int64_t L, int64_t H, int64_t G, hipStream_t st) {
-  const Geo g = make_geo(L, H);
+  const Geo g = make_geo(L, H, B);
   const dim3 grid(g.nchunk, g.nhb, (unsigned)B);
   const size_t smem = (size_t)g.hb * N * P * sizeof(float);
   if (weighted)
@@ -429,7 +433,7 @@ void run_outer(bool weighted, const void* V, int64_t ldv, const void* K, int64_t
 template <typename T, int P, int N>
 void run_apply(const void* x, int64_t ldx, const void* Cm, int64_t ldc, const float* D, int64_t p_hs, const float* kv, void* y,
                int64_t ldy, int64_t B, int64_t L, int64_t H, int64_t G, hipStream_t st) {
-  const Geo g = make_geo(L, H);
+  const Geo g = make_geo(L, H, B);
   { ADNM_PROF("ssd_apply", st, (double)sizeof(T) * B * L * (2 * H * P + G * N)); ssd_apply_kernel<T, P, N><<<dim3(g.nblk2, g.nhb, (unsigned)B), kBlock, 0, st>>>((const T*)x, ldx, (const T*)Cm, ldc, D, p_hs, kv,
                                                                                   (T*)y, ldy, L, (int)H, (int)G, g.hb, g.tok2); }
 }

@@ -82,8 +82,8 @@ class Block(nn.Module):
             xn, x = _normed(self.norm1_layers[i], x, self.scale1[i], self.shift1[i])
             x = ops.lincomb([x, self.drop_path_layers[i](self.mixer_layers[i](xn, h, w))], [beta1, beta2])
             xn, x = _normed(self.norm2_layers[i], x, self.scale2[i], self.shift2[i])
-            x = ops.lincomb([x, self.ffns[i].forward_tokens(xn, h, w)], [beta1, beta2])
-        x = ops.lincomb([x], [None], self.gamma)
+            # the block's closing per-channel gamma (:161) rides on the last residual mix: one launch instead of two
+            x = ops.lincomb([x, self.ffns[i].forward_tokens(xn, h, w)], [beta1, beta2], self.gamma if i == self.num_layers - 1 else None)
         if self.dim != self.out_dim:
             x = ops.linear(x, self.out_proj.weight, self.out_proj.bias)
         return x
@@ -115,8 +115,7 @@ class Attention(nn.Module):
         xn, x = self.attn_norm1.tap(x, self.attn_scale1, self.attn_shift1)
         x = ops.lincomb([x, self.attn_layer(xn, h, w)], [self.beta1, self.beta2])
         xn, x = self.attn_norm2.tap(x, self.attn_scale2, self.attn_shift2)
-        x = ops.lincomb([x, self.attn_mlp(xn)], [self.beta3, self.beta4])
-        x = ops.lincomb([x], [None], self.gamma)
+        x = ops.lincomb([x, self.attn_mlp(xn)], [self.beta3, self.beta4], self.gamma)
         if self.dim != self.out_dim:
             x = ops.linear(x, self.out_proj.weight, self.out_proj.bias)
         return x

@@ -501,7 +501,7 @@ def test_rownorm_tap(mean):
     (4096, 128, 544, False),
 ])
 def test_skgemm_linear(M, K, N, bias, monkeypatch):
-    monkeypatch.setattr(ops, "SK_MAX_ROWS", 65536)   # exercise the kernel on every shape, not only where the product routes to it
+    monkeypatch.setattr(ops, "SK_FORCE", True)   # exercise the kernel on every shape, not only where the timing routes to it
     x, w, cot = T(f"sk.x{M}{K}", (M, K)), T(f"sk.w{N}{K}", (N, K), 0.05), T(f"sk.c{M}{N}", (M, N))
     b = T(f"sk.b{N}", (N,)) if bias else None
     xo, wo, bo = leaf(x.double()), leaf(w.double()), (leaf(b.double()) if bias else None)
@@ -519,7 +519,7 @@ def test_skgemm_linear(M, K, N, bias, monkeypatch):
 
 
 def test_skgemm_strided_operands(monkeypatch):
-    monkeypatch.setattr(ops, "SK_MAX_ROWS", 65536)
+    monkeypatch.setattr(ops, "SK_FORCE", True)
     """column slices of wider buffers as input and output (how the mixer calls it): no partials for the strided output."""
     M, K, N = 256, 512, 128
     big_in, big_out = T("sks.in", (M, K + 64)).to(DEV), torch.zeros((M, N + 32), device=DEV)
