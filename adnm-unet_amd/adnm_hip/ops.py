@@ -124,23 +124,23 @@ def k_ssd_bwd(dy, x, Bm, Cm, dt_raw, dt_bias, A_log, D, kv, dx, dBm, dCm, ddt, B
     return dbias, dA, dD
 
 
-def k_dwconv_fwd(x, wt, bias, B, H, W, C, K, act, y=None, addend=None):
-    """x (M,C) row view (M=B*H*W); wt tap-major (K*K, C) fp32."""
+def k_dwconv_fwd(x, wt, bias, B, H, W, C, K, act, y=None, addend=None, chan_major=False):
+    """x (M,C) row view (M=B*H*W); wt tap-major (K*K, C) fp32, or nn.Conv2d's (C, K*K) with chan_major."""
     _need_gpu(x)
     if y is None:
         y = torch.empty((B * H * W, C), dtype=x.dtype, device=x.device)
     px, ldx = _rows(x)
     py, ldy = _rows(y)
     pa, lda = _rows(addend) if addend is not None else (None, 0)
-    lib.call("adnm_dwconv_fwd", px, ldx, _p(_f32(wt)), _p(_f32(bias)), pa, lda, py, ldy, B, H, W, C, K, K, act, _dt(x), _stream())
+    lib.call("adnm_dwconv_fwd", px, ldx, _p(_f32(wt)), _p(_f32(bias)), pa, lda, py, ldy, B, H, W, C, K, K, act, int(chan_major), _dt(x), _stream())
     return y
 
 
-def k_dwconv_bwd(dy, x, wt, bias, B, H, W, C, K, act, dx=None, want_bias=False, want_w=True):
+def k_dwconv_bwd(dy, x, wt, bias, B, H, W, C, K, act, dx=None, want_bias=False, want_w=True, chan_major=False):
     dev = x.device
     if dx is None:
         dx = torch.empty((B * H * W, C), dtype=x.dtype, device=dev)
-    dwt = torch.empty((K * K, C), dtype=torch.float32, device=dev) if want_w else None
+    dwt = torch.empty((C, K * K) if chan_major else (K * K, C), dtype=torch.float32, device=dev) if want_w else None
     db = torch.empty(C, dtype=torch.float32, device=dev) if want_bias else None
     dpre = torch.empty((B * H * W, C), dtype=x.dtype, device=dev) if act != lib.ACT_NONE else None
     nb = lib.query("adnm_dwconv_bwd_ws_bytes", B, H, W, C, K, K)
@@ -149,7 +149,7 @@ def k_dwconv_bwd(dy, x, wt, bias, B, H, W, C, K, act, dx=None, want_bias=False, 
     px, ldx = _rows(x)
     pdx, lddx = _rows(dx)
     lib.call("adnm_dwconv_bwd", pdy, lddy, px, ldx, _p(wt), _p(bias), _p(dpre), pdx, lddx, _p(dwt), _p(db), ws.data_ptr(),
-             nb, B, H, W, C, K, K, act, _dt(x), _stream())
+             nb, B, H, W, C, K, K, act, int(chan_major), _dt(x), _stream())
     return dx, dwt, db
 
 
@@ -382,8 +382,10 @@ class DWConvFn(torch.autograd.Function):
         K = w.shape[-1]
         x2 = x.reshape(B * L, C)
         x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
-        wt = tap_major(w)
-        y = k_dwconv_fwd(x2, wt, bias, B, H, W, C, K, act)
+        wt = w.reshape(C, K * K)   # nn.Conv2d's own layout: the kernels read it as is (no tap-major copy either way)
+        if wt.dtype != torch.float32 or not wt.is_contiguous():
+            wt = wt.contiguous().float()
+        y = k_dwconv_fwd(x2, wt, bias, B, H, W, C, K, act, chan_major=True)
         ctx.save_for_backward(x2, wt, bias)
         ctx.dims = (B, H, W, C, K, act, w.shape)
         return y.view(B, L, C)
@@ -395,8 +397,8 @@ class DWConvFn(torch.autograd.Function):
         dy2 = dy.reshape(B * H * W, C)
         dy2 = dy2 if dy2.stride(-1) == 1 else dy2.contiguous()
         want_w = ctx.needs_input_grad[1]
-        dx, dwt, db = k_dwconv_bwd(dy2, x2, wt, bias, B, H, W, C, K, act, want_bias=bias is not None, want_w=want_w)
-        return dx.view(B, H * W, C), dwt.t().reshape(wshape) if want_w else None, db, None, None, None
+        dx, dwt, db = k_dwconv_bwd(dy2, x2, wt, bias, B, H, W, C, K, act, want_bias=bias is not None, want_w=want_w, chan_major=True)
+        return dx.view(B, H * W, C), dwt.view(wshape) if want_w else None, db, None, None, None
 
 
 def dwconv(x, w, bias, H, W, act=lib.ACT_NONE):
@@ -861,6 +863,15 @@ def k_linear_dx(dy2, w, out=None):
     return dx
 
 
+def colsum(t):
+    """sum over the rows of a 2-D fp32 matrix (bias gradient) with the deterministic fold kernel."""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous()):
+        return t.sum(0)
+    out = torch.empty(t.shape[1], dtype=torch.float32, device=t.device)
+    lib.call("adnm_colsum", t.data_ptr(), out.data_ptr(), t.shape[0], t.shape[1], _stream())
+    return out
+
+
 def k_linear_dw(dy2, x2, want_bias):
     """dW = dY^T X (N,K), dbias = column sums of dY."""
     M, N = dy2.shape
@@ -878,10 +889,10 @@ def k_linear_dw(dy2, x2, want_bias):
         dw = torch.empty((N, K), dtype=torch.float32, device=x2.device)
         db = torch.empty(N, dtype=torch.float32, device=x2.device) if want_bias else None
         if sk_pick((SK_TN, M, N, K, want_bias), lambda: _skgemm(SK_TN, dy2, x2, None, dw, db, M, N, K),
-                   lambda: (torch.mm(dy2.t(), x2), dy2.sum(0) if want_bias else None)):
+                   lambda: (torch.mm(dy2.t(), x2), colsum(dy2) if want_bias else None)):
             _skgemm(SK_TN, dy2, x2, None, dw, db, M, N, K)
             return dw, db
-    return torch.mm(dy2.t(), x2), (dy2.sum(0) if want_bias else None)
+    return torch.mm(dy2.t(), x2), (colsum(dy2) if want_bias else None)
 
 
 class LinearFn(torch.autograd.Function):

@@ -34,7 +34,7 @@ __device__ __forceinline__ float4 apply_act_grad(float4 v, int act) {
 // MODE 0: y = act(conv(x) + bias) (+ addend)         [forward]
 // MODE 1: y = dy * act'(conv(x) + bias)              [backward step (a); `aux` = dy with pixel stride ldaux]
 // MODE 2: y = conv_flipped(x)                        [backward step (b); x = dpre]
-template <typename T, int K, int MODE>
+template <typename T, int K, int MODE, bool WCM>
 __global__ __launch_bounds__(kBlock) void dwconv_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ wgt,
                                                         const float* __restrict__ bias, const T* __restrict__ aux,
                                                         int64_t ldaux, T* __restrict__ y, int64_t ldy, int B, int H, int W,
@@ -58,6 +58,14 @@ __global__ __launch_bounds__(kBlock) void dwconv_kernel(const T* __restrict__ x,
   const int b = (int)(t / H);
   const int c = cg * 4;
   const int w0 = wt * TW;
+  float wcmv[WCM ? 4 * K * K : 1];
+  if (WCM) {
+#pragma unroll
+    for (int q = 0; q < K * K; ++q) {
+      const float4 t4 = *reinterpret_cast<const float4*>(wgt + (int64_t)c * (K * K) + 4 * q);
+      wcmv[4 * q] = t4.x; wcmv[4 * q + 1] = t4.y; wcmv[4 * q + 2] = t4.z; wcmv[4 * q + 3] = t4.w;
+    }
+  }
   float4 acc[TW];
 #pragma unroll
   for (int i = 0; i < TW; ++i) acc[i] = f4zero();
@@ -75,7 +83,10 @@ __global__ __launch_bounds__(kBlock) void dwconv_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       const int tap = (MODE == 2) ? ((K - 1 - i) * K + (K - 1 - j)) : (i * K + j);
-      const float4 wv = *reinterpret_cast<const float4*>(wgt + (int64_t)tap * C + c);
+      // weights: tap-major (K*K, C): one float4 per tap; or, wcm, nn.Conv2d's own channel-major (C, K*K): the lane's 4 channels
+      // are 4*K*K consecutive floats, fetched once as K*K float4s (wcmv) and picked apart at compile-time indices
+      const float4 wv = WCM ? make_float4(wcmv[tap], wcmv[(WCM ? K * K : 0) + tap * WCM], wcmv[(WCM ? 2 * K * K : 0) + tap * WCM], wcmv[(WCM ? 3 * K * K : 0) + tap * WCM])
+                            : *reinterpret_cast<const float4*>(wgt + (int64_t)tap * C + c);
 #pragma unroll
       for (int p = 0; p < TW; ++p) fma4(acc[p], wv, row[p + j]);
     }
@@ -113,7 +124,7 @@ constexpr int kWgSlices = 2;  // waves per tap row: more memory-level parallelis
 template <typename T, int K>
 __global__ __launch_bounds__(64 * K * kWgSlices) void dwconv_wgrad_kernel(const T* __restrict__ dpre, int64_t ldd, const T* __restrict__ x,
                                                               int64_t ldx, float* __restrict__ part, int B, int H, int W, int C,
-                                                              int cgb) {
+                                                              int cgb, int wcm) {
   constexpr int R = K / 2;
   constexpr int NT = K * K;
   const int C4 = C >> 2;
@@ -201,7 +212,14 @@ __global__ __launch_bounds__(64 * K * kWgSlices) void dwconv_wgrad_kernel(const 
       float4 v = j < K ? aw[j] : ab;
       const float4 o = *reinterpret_cast<const float4*>(&red[i][j][lane][0]);
       v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-      if (lane < cgb && cv) *reinterpret_cast<float4*>(dst + (int64_t)(j < K ? i * K + j : NT) * C + c) = v;
+      if (lane < cgb && cv) {
+        if (wcm && j < K) {   // channel-major partial row: column c*K*K + tap, so the fold emits nn.Conv2d's (C, K*K) layout
+          float* q = dst + (int64_t)c * NT + i * K + j;
+          q[0] = v.x; q[NT] = v.y; q[2 * NT] = v.z; q[3 * NT] = v.w;
+        } else {
+          *reinterpret_cast<float4*>(dst + (int64_t)(j < K ? i * K + j : NT) * C + c) = v;
+        }
+      }
     }
   }
 }
@@ -241,41 +259,48 @@ int check(const char* who, const void* x, int64_t B, int64_t H, int64_t W, int64
 
 template <typename T, int MODE>
 void launch_conv(const void* x, int64_t ldx, const float* wgt, const float* bias, const void* aux, int64_t ldaux, void* y, int64_t ldy,
-                 int64_t B, int64_t H, int64_t W, int64_t C, int K, int act, hipStream_t st) {
+                 int64_t B, int64_t H, int64_t W, int64_t C, int K, int act, int wcm, hipStream_t st) {
   const int64_t total = B * H * adnm_cdiv(W, TW) * (C / 4);
   const unsigned grid = (unsigned)adnm_cdiv(total, kBlock);
-  if (K == 3)
-    { ADNM_PROF("dwconv_k3", st, (double)sizeof(T) * B * H * W * C * (MODE == 1 ? 3 : (aux ? 3 : 2))); dwconv_kernel<T, 3, MODE><<<grid, kBlock, 0, st>>>((const T*)x, ldx, wgt, bias, (const T*)aux, ldaux, (T*)y, ldy, (int)B, (int)H,
-                                                       (int)W, (int)C, act); }
-  else
-    { ADNM_PROF("dwconv_k5", st, (double)sizeof(T) * B * H * W * C * (MODE == 1 ? 3 : (aux ? 3 : 2))); dwconv_kernel<T, 5, MODE><<<grid, kBlock, 0, st>>>((const T*)x, ldx, wgt, bias, (const T*)aux, ldaux, (T*)y, ldy, (int)B, (int)H,
-                                                       (int)W, (int)C, act); }
+#define ADNM_DWCONV(KK, WCMV)                                                                                                       \
+  dwconv_kernel<T, KK, MODE, WCMV><<<grid, kBlock, 0, st>>>((const T*)x, ldx, wgt, bias, (const T*)aux, ldaux, (T*)y, ldy, (int)B, (int)H, \
+                                                            (int)W, (int)C, act)
+  ADNM_PROF(K == 3 ? "dwconv_k3" : "dwconv_k5", st, (double)sizeof(T) * B * H * W * C * (MODE == 1 ? 3 : (aux ? 3 : 2)));
+  if (K == 3) {
+    if (wcm) ADNM_DWCONV(3, true);
+    else ADNM_DWCONV(3, false);
+  } else {
+    if (wcm) ADNM_DWCONV(5, true);
+    else ADNM_DWCONV(5, false);
+  }
+#undef ADNM_DWCONV
 }
 
 template <typename T>
 void launch_wgrad(const void* dpre, int64_t ldd, const void* x, int64_t ldx, float* part, float* dwgt, float* dbias, int64_t B, int64_t H,
-                  int64_t W, int64_t C, int K, hipStream_t st) {
+                  int64_t W, int64_t C, int K, int wcm, hipStream_t st) {
   const WGeo g = wgeo(B, H, W, C, K);
   const dim3 grid(g.gx, g.npb);
   if (K == 3)
-    { ADNM_PROF("dwconv_wgrad_k3", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 3><<<grid, 64 * 3 * kWgSlices, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb); }
+    { ADNM_PROF("dwconv_wgrad_k3", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 3><<<grid, 64 * 3 * kWgSlices, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb, wcm); }
   else
-    { ADNM_PROF("dwconv_wgrad_k5", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 5><<<grid, 64 * 5 * kWgSlices, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb); }
+    { ADNM_PROF("dwconv_wgrad_k5", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 5><<<grid, 64 * 5 * kWgSlices, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb, wcm); }
   adnm_launch_fold("dwconv_wgrad_fold", part, g.rows, (K * K + 1) * (int)C, {dwgt, K * K * (int)C}, {dbias, (int)C}, {nullptr, 0}, {nullptr, 0}, st);
 }
 
 }  // namespace
 
 extern "C" int adnm_dwconv_fwd(const void* x, int64_t ldx, const float* wgt, const float* bias, const void* addend, int64_t ldadd,
-                               void* y, int64_t ldy, int64_t B, int64_t H, int64_t W, int64_t C, int KH, int KW, int act, int dtype,
-                               adnm_stream_t stream) {
+                               void* y, int64_t ldy, int64_t B, int64_t H, int64_t W, int64_t C, int KH, int KW, int act, int wlayout,
+                               int dtype, adnm_stream_t stream) {
   if (int rc = check("dwconv_fwd", x, B, H, W, C, KH, KW, act, dtype)) return rc;
   ADNM_REQUIRE(wgt && y, "dwconv_fwd: null pointer");
+  ADNM_REQUIRE(wlayout == 0 || wlayout == 1, "dwconv_fwd: weight layout %d not in {0 tap-major, 1 channel-major}", wlayout);
   ADNM_REQUIRE(ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0 && (!addend || (ldadd >= C && ldadd % 4 == 0)),
                "dwconv_fwd: pixel strides must be >= C and multiples of 4");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == ADNM_F32) launch_conv<float, 0>(x, ldx, wgt, bias, addend, ldadd, y, ldy, B, H, W, C, KH, act, st);
-  else launch_conv<uint16_t, 0>(x, ldx, wgt, bias, addend, ldadd, y, ldy, B, H, W, C, KH, act, st);
+  if (dtype == ADNM_F32) launch_conv<float, 0>(x, ldx, wgt, bias, addend, ldadd, y, ldy, B, H, W, C, KH, act, wlayout, st);
+  else launch_conv<uint16_t, 0>(x, ldx, wgt, bias, addend, ldadd, y, ldy, B, H, W, C, KH, act, wlayout, st);
   ADNM_CHECK_LAUNCH("dwconv_fwd");
   return ADNM_OK;
 }
@@ -288,9 +313,10 @@ extern "C" int64_t adnm_dwconv_bwd_ws_bytes(int64_t B, int64_t H, int64_t W, int
 
 extern "C" int adnm_dwconv_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* wgt, const float* bias,
                                void* dpre, void* dx, int64_t lddx, float* dwgt, float* dbias, void* ws, int64_t ws_bytes, int64_t B,
-                               int64_t H, int64_t W, int64_t C, int KH, int KW, int act, int dtype, adnm_stream_t stream) {
+                               int64_t H, int64_t W, int64_t C, int KH, int KW, int act, int wlayout, int dtype, adnm_stream_t stream) {
   if (int rc = check("dwconv_bwd", x, B, H, W, C, KH, KW, act, dtype)) return rc;
   ADNM_REQUIRE(dy && wgt && dx, "dwconv_bwd: null pointer");
+  ADNM_REQUIRE(wlayout == 0 || wlayout == 1, "dwconv_bwd: weight layout %d not in {0 tap-major, 1 channel-major}", wlayout);
   ADNM_REQUIRE(act == ADNM_ACT_NONE || dpre, "dwconv_bwd: dpre scratch required when an activation is fused");
   ADNM_REQUIRE(ldx >= C && lddy >= C && lddx >= C && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0,
                "dwconv_bwd: pixel strides must be >= C and multiples of 4");
@@ -303,18 +329,18 @@ extern "C" int adnm_dwconv_bwd(const void* dy, int64_t lddy, const void* x, int6
   int64_t ldg = lddy;
   if (dtype == ADNM_F32) {
     if (act != ADNM_ACT_NONE) {
-      launch_conv<float, 1>(x, ldx, wgt, bias, dy, lddy, dpre, C, B, H, W, C, KH, act, st);
+      launch_conv<float, 1>(x, ldx, wgt, bias, dy, lddy, dpre, C, B, H, W, C, KH, act, wlayout, st);
       g = dpre; ldg = C;
     }
-    launch_conv<float, 2>(g, ldg, wgt, nullptr, nullptr, 0, dx, lddx, B, H, W, C, KH, 0, st);
-    if (dwgt) launch_wgrad<float>(g, ldg, x, ldx, (float*)ws, dwgt, dbias, B, H, W, C, KH, st);
+    launch_conv<float, 2>(g, ldg, wgt, nullptr, nullptr, 0, dx, lddx, B, H, W, C, KH, 0, wlayout, st);
+    if (dwgt) launch_wgrad<float>(g, ldg, x, ldx, (float*)ws, dwgt, dbias, B, H, W, C, KH, wlayout, st);
   } else {
     if (act != ADNM_ACT_NONE) {
-      launch_conv<uint16_t, 1>(x, ldx, wgt, bias, dy, lddy, dpre, C, B, H, W, C, KH, act, st);
+      launch_conv<uint16_t, 1>(x, ldx, wgt, bias, dy, lddy, dpre, C, B, H, W, C, KH, act, wlayout, st);
       g = dpre; ldg = C;
     }
-    launch_conv<uint16_t, 2>(g, ldg, wgt, nullptr, nullptr, 0, dx, lddx, B, H, W, C, KH, 0, st);
-    if (dwgt) launch_wgrad<uint16_t>(g, ldg, x, ldx, (float*)ws, dwgt, dbias, B, H, W, C, KH, st);
+    launch_conv<uint16_t, 2>(g, ldg, wgt, nullptr, nullptr, 0, dx, lddx, B, H, W, C, KH, 0, wlayout, st);
+    if (dwgt) launch_wgrad<uint16_t>(g, ldg, x, ldx, (float*)ws, dwgt, dbias, B, H, W, C, KH, wlayout, st);
   }
   ADNM_CHECK_LAUNCH("dwconv_bwd");
   return ADNM_OK;

@@ -120,19 +120,20 @@ int adnm_ssd_scan_bwd(const void* dy, int64_t lddy, int64_t dy_hstride, const vo
  * model_untils.py:180-188 (FeedForward.dwconv), :203-211 (ConvFFD.dw_conv), WTConv2d.py:81,86 —
  * applied directly on the token layout, so the reference's BLD<->BCHW permute().contiguous()
  * copies disappear.  x pixel stride ldx, y pixel stride ldy, addend pixel stride ldadd (elements);
- * wgt: TAP-MAJOR (KH,KW,C) fp32 (one float4 per tap and channel quad); KH == KW in {3,5}; C % 4 == 0
+ * wgt, fp32: wlayout 0 = TAP-MAJOR (KH,KW,C) (one float4 per tap and channel quad: what the parameter-prep kernels
+ * emit), wlayout 1 = nn.Conv2d's own (C,1,KH,KW) (no transposes around the call); KH == KW in {3,5}; C % 4 == 0
  * (the 5-channel input stage is zero-padded to 8 channels by the caller). */
 int adnm_dwconv_fwd(const void* x, int64_t ldx, const float* wgt, const float* bias, const void* addend,
                     int64_t ldadd, void* y, int64_t ldy, int64_t B, int64_t H, int64_t W, int64_t C, int KH,
-                    int KW, int act, int dtype, adnm_stream_t stream);
+                    int KW, int act, int wlayout, int dtype, adnm_stream_t stream);
 /* dpre:(B,H,W,C) contiguous scratch in activation dtype (ignored when act==NONE).
- * dwgt:(KH,KW,C) tap-major, dbias:(C) or NULL: OVERWRITTEN.  dwgt == NULL skips the weight-gradient pass
+ * dwgt: same layout as wgt (wlayout), dbias:(C) or NULL: OVERWRITTEN.  dwgt == NULL skips the weight-gradient pass
  * (constant taps, e.g. the average pools of EncoderToDecoder expressed as a depthwise conv). */
 int64_t adnm_dwconv_bwd_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t C, int KH, int KW);
 int adnm_dwconv_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* wgt,
                     const float* bias, void* dpre, void* dx, int64_t lddx, float* dwgt, float* dbias, void* ws,
                     int64_t ws_bytes, int64_t B, int64_t H, int64_t W, int64_t C, int KH, int KW, int act,
-                    int dtype, adnm_stream_t stream);
+                    int wlayout, int dtype, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- Haar butterflies, NHWC (K3)
  * wavelet_transform / inverse_wavelet_transform with db1 (WTConv2d.py:31-51): per 2x2 block
@@ -206,6 +207,10 @@ int64_t adnm_skipgate_grad_floats(int64_t C);
 int64_t adnm_skipgate_bwd_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t C);
 int adnm_skipgate_bwd(const float* dout, const float* x, const float* const* params, const float* pooled, const float* conv, float* dx,
                       float* dparams, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W, int64_t C, adnm_stream_t stream);
+
+/* out[c] = sum_r x[r*n + c] for a contiguous (rows, n) fp32 matrix — nn.Linear's bias gradient (autograd's sum over the token
+ * rows) when the weight gradient itself is a library GEMM.  Deterministic (fixed tree), OVERWRITES out. */
+int adnm_colsum(const float* x, float* out, int64_t rows, int64_t n, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- short GEMMs of the deep stages (K6b, MFMA)
  * nn.Linear with M <= 65536 token rows and up to 16384 features: Mamba2.in_proj/out_proj (ADNssd.py:309,461),
