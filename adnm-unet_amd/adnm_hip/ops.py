@@ -1097,3 +1097,70 @@ class RainLossFn(torch.autograd.Function):
 
 def rainloss(pred, target, omega_t, alpha, gamma):
     return RainLossFn.apply(pred, target, omega_t, alpha, gamma)
+
+
+class TokMeanTapFn(torch.autograd.Function):
+    """(x, mean over tokens): Channel_Att_Bridge's global average pool.  x comes back as an autograd alias so that the
+    gradient of its later consumers and the pool's broadcast gradient are summed in ONE pass (tokmean_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        B, L, C = x.shape
+        xc = x if x.is_contiguous() else x.contiguous()
+        mean = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        nb = lib.query("adnm_tokmean_ws_bytes", B, L, C)
+        ws = _ws(nb, x.device)
+        lib.call("adnm_tokmean_fwd", xc.data_ptr(), mean.data_ptr(), ws.data_ptr(), nb, B, L, C, _stream())
+        ctx.shp = (B, L, C)
+        return x, mean
+
+    @staticmethod
+    def backward(ctx, dxa, dmean):
+        B, L, C = ctx.shp
+        if dmean is None:
+            return dxa
+        if dxa is not None and not dxa.is_contiguous():
+            dxa = dxa.contiguous()
+        dx = torch.empty((B, L, C), dtype=torch.float32, device=dmean.device)
+        lib.call("adnm_tokmean_bwd", _p(dxa), dmean.contiguous().data_ptr(), dx.data_ptr(), B, L, C, _stream())
+        return dx
+
+
+def tokmean_tap(x):
+    """-> (alias of x, (B, C) mean over tokens).  Callers should hand the alias to x's later consumers."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] % 4 == 0:
+        return TokMeanTapFn.apply(x)
+    return x, x.mean(1)
+
+
+class Conv1d3Fn(torch.autograd.Function):
+    """nn.Conv1d(1, 1, 3, padding=1) on (B, 1, n): one single-workgroup launch each way."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        _need_gpu(x)
+        B, _, n = x.shape
+        xc, wc = x.contiguous(), w.contiguous()
+        y = torch.empty_like(xc)
+        lib.call("adnm_conv1d3_fwd", xc.data_ptr(), wc.data_ptr(), _p(bias), y.data_ptr(), B, n, _stream())
+        ctx.save_for_backward(xc, wc)
+        ctx.meta = (w.shape, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wc = ctx.saved_tensors
+        B, _, n = xc.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(xc)
+        dwb = torch.empty(4, dtype=torch.float32, device=xc.device)
+        lib.call("adnm_conv1d3_bwd", dy.data_ptr(), xc.data_ptr(), wc.data_ptr(), dx.data_ptr(), dwb.data_ptr(), B, n, _stream())
+        wshape, has_bias = ctx.meta
+        return dx, dwb[:3].view(wshape), dwb[3:4] if has_bias else None
+
+
+def conv1d3(x, w, bias):
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[1] == 1 and w.numel() == 3 and x.shape[0] * x.shape[2] <= (1 << 20):
+        return Conv1d3Fn.apply(x, w, bias)
+    return torch.nn.functional.conv1d(x, w, bias, padding=1)

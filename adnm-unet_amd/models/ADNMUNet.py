@@ -246,7 +246,9 @@ class Decoder(nn.Module):
     def forward(self, x, skips):
         """(ADNMUNet.py:603-636 of the reference).  skips[i] = encoder_layer_residual[i]."""
         dead = self.compute_dead_branches
-        gates = self.fusion(skips, live=None if dead else {4, 5, 6})
+        aliases = []
+        gates = self.fusion(skips, live=None if dead else {4, 5, 6}, alias_out=aliases)
+        skips = aliases   # same tensors; their gradients now meet the bridge pool's inside one kernel
         feats = {}
         feats[0] = self.e2ds[0](x=skips[6], res=gates[6])
         # e2ds[1], e2ds[2] are only consumed by decoder2 / decoder3: run them on side streams so their ~100 tiny,

@@ -442,9 +442,14 @@ class Channel_Att_Bridge(nn.Module):
             setattr(self, f"att{i + 1}", nn.Linear(c_list_sum, c_list[i]))
         self.sigmoid1 = IntensityGate()
 
-    def forward(self, t, live=None):
-        att = torch.cat([t[i].mean(1) for i in range(len(t))], dim=-1).unsqueeze(1)  # (B,1,sum C)
-        att = self.get_all_att(att)
+    def forward(self, t, live=None, alias_out=None):
+        """alias_out: optional list that receives autograd aliases of the skips — later consumers that read those instead of
+        t[i] get their gradient summed with the pool's in one HIP pass (ops.tokmean_tap)."""
+        taps = [ops.tokmean_tap(t[i]) for i in range(len(t))]
+        if alias_out is not None:
+            alias_out[:] = [a for a, _ in taps]
+        att = torch.cat([m for _, m in taps], dim=-1).unsqueeze(1)  # (B,1,sum C)
+        att = ops.conv1d3(att, self.get_all_att.weight, self.get_all_att.bias)
         out = {}
         for i in range(7):
             if live is not None and i not in live:

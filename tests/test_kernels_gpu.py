@@ -528,3 +528,30 @@ def test_skgemm_strided_operands(monkeypatch):
     ref = big_in[:, 32:32 + K].double() @ w.double().t()
     assert_close(y, ref, OUT_TOL, "strided y")
     assert float(big_out[:, :16].abs().max()) == 0.0 and float(big_out[:, 16 + N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,L,C", [(4, 4096, 32), (2, 16, 1024), (3, 700, 64)])
+def test_tokmean_tap(B, L, C):
+    x, c1, c2 = T(f"tm.x{L}", (B, L, C)), T(f"tm.c1{L}", (B, L, C)), T(f"tm.c2{L}", (B, C))
+    xo = leaf(x.double())
+    ((xo * c1.double()).sum() + (xo.mean(1) * c2.double()).sum()).backward()
+    xg = leaf(x, DEV)
+    xa, m = ops.tokmean_tap(xg)
+    ((xa * c1.to(DEV)).sum() + (m * c2.to(DEV)).sum()).backward()
+    assert_close(m, x.double().mean(1), OUT_TOL, "mean")
+    assert_close(xg.grad, xo.grad, GRAD_TOL, "dx = consumer gradient + broadcast pool gradient")
+
+
+def test_conv1d3():
+    B, n = 4, 2144
+    x, cot = T("c1.x", (B, 1, n)), T("c1.c", (B, 1, n))
+    w, b = torch.tensor([[[0.3, -0.8, 0.5]]]), torch.tensor([0.1])
+    xo, wo, bo = leaf(x.double()), leaf(w.double()), leaf(b.double())
+    (F.conv1d(xo, wo, bo, padding=1) * cot.double()).sum().backward()
+    xg, wg, bg = leaf(x, DEV), leaf(w, DEV), leaf(b, DEV)
+    y = ops.conv1d3(xg, wg, bg)
+    (y * cot.to(DEV)).sum().backward()
+    assert_close(y, F.conv1d(x.double(), w.double(), b.double(), padding=1), OUT_TOL, "y")
+    assert_close(xg.grad, xo.grad, GRAD_TOL, "dx")
+    assert_close(wg.grad, wo.grad, GRAD_TOL, "dw")
+    assert_close(bg.grad, bo.grad, GRAD_TOL, "db")
