@@ -1164,3 +1164,38 @@ def conv1d3(x, w, bias):
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[1] == 1 and w.numel() == 3 and x.shape[0] * x.shape[2] <= (1 << 20):
         return Conv1d3Fn.apply(x, w, bias)
     return torch.nn.functional.conv1d(x, w, bias, padding=1)
+
+
+class Attn4Fn(torch.autograd.Function):
+    """softmax(q k^T * scale) v for 4-wide heads straight from to_qkv's (B, L, 3*inner) output (csrc/attn4.hip)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, scale):
+        _need_gpu(qkv)
+        qkv = qkv.contiguous()
+        B, L, three = qkv.shape
+        inner = three // 3
+        out = torch.empty((B, L, inner), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty((B, heads, L), dtype=torch.float32, device=qkv.device)
+        lib.call("adnm_attn4_fwd", qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, L, heads, float(scale), _stream())
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.meta = (heads, float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        heads, scale = ctx.meta
+        B, L, _ = qkv.shape
+        dqkv = torch.empty_like(qkv)
+        lib.call("adnm_attn4_bwd", dout.contiguous().data_ptr(), qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), B, L, heads, scale,
+                 _stream())
+        return dqkv, None, None
+
+
+def attn4_supported(qkv, heads):
+    return qkv.is_cuda and qkv.dtype == torch.float32 and qkv.dim() == 3 and qkv.shape[-1] == 12 * heads and qkv.shape[1] <= 2048
+
+
+def attn4(qkv, heads, scale):
+    return Attn4Fn.apply(qkv, heads, scale)

@@ -37,7 +37,10 @@ class StandardAttention(nn.Module):
 
     def forward(self, x, H, W):
         b, n, _ = x.shape
-        q, k, v = ops.linear(x, self.to_qkv.weight, None).chunk(3, dim=-1)
+        qkv = ops.linear(x, self.to_qkv.weight, None)
+        if self.dropout.p == 0.0 and ops.attn4_supported(qkv, self.heads):   # 4-wide heads: fused, no (L, L) score tensor
+            return ops.linear(ops.attn4(qkv, self.heads, self.scale), self.to_out.weight, self.to_out.bias)
+        q, k, v = qkv.chunk(3, dim=-1)
         sp = lambda t: t.reshape(b, n, self.heads, -1).transpose(1, 2)
         att = self.dropout(torch.softmax(torch.matmul(sp(q), sp(k).transpose(-1, -2)) * self.scale, dim=-1))
         out = torch.matmul(att, sp(v)).transpose(1, 2).reshape(b, n, self.inner_dim)

@@ -208,6 +208,16 @@ int64_t adnm_skipgate_bwd_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t C);
 int adnm_skipgate_bwd(const float* dout, const float* x, const float* const* params, const float* pooled, const float* conv, float* dx,
                       float* dparams, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W, int64_t C, adnm_stream_t stream);
 
+/* ---------------------------------------------------------------- soft-max attention with 4-wide heads (K16)
+ * StandardAttention.forward (models/ADNssd.py:38-46 of the reference) between to_qkv and to_out:
+ *   out[b,l,h*4+d] = sum_j softmax_j(scale * q[b,h,l,:] . k[b,h,j,:]) v[b,h,j,d],   heads = inner/4, L <= 2048
+ * qkv: (B, L, 3*inner) fp32 contiguous = to_qkv's output as it is ([q | k | v], head h at columns h*4..h*4+3 of each third);
+ * out: (B, L, inner); lse: (B, heads, L) log-sum-exp of the scaled scores, saved for backward.  No (L, L) tensor is
+ * materialised.  bwd: dqkv (B, L, 3*inner) OVERWRITTEN. */
+int adnm_attn4_fwd(const float* qkv, float* out, float* lse, int64_t B, int64_t L, int64_t heads, float scale, adnm_stream_t stream);
+int adnm_attn4_bwd(const float* dout, const float* qkv, const float* out, const float* lse, float* dqkv, int64_t B, int64_t L, int64_t heads,
+                   float scale, adnm_stream_t stream);
+
 /* ---------------------------------------------------------------- Channel_Att_Bridge pooling (K15)
  * model_untils.py:570-592 of the reference: mean[b,c] = (1/L) sum_l x[b,l,c] for contiguous fp32 (B,L,C) tokens (the
  * reference's AdaptiveAvgPool2d(1) of each skip), C % 4 == 0; bwd: dx = dxa + dmean/L broadcast over l (dxa = the gradient of

@@ -555,3 +555,21 @@ def test_conv1d3():
     assert_close(xg.grad, xo.grad, GRAD_TOL, "dx")
     assert_close(wg.grad, wo.grad, GRAD_TOL, "dw")
     assert_close(bg.grad, bo.grad, GRAD_TOL, "db")
+
+
+@pytest.mark.parametrize("B,L,heads", [(4, 256, 32), (2, 64, 64), (1, 100, 3), (1, 1024, 8)])
+def test_attn4(B, L, heads):
+    """fused 4-wide-head attention vs the reference expression (ADNssd.py:38-46) in fp64."""
+    inner, scale = heads * 4, 4 ** -0.5
+    qkv, cot = T(f"at.q{L}{heads}", (B, L, 3 * inner), 1.5), T(f"at.c{L}{heads}", (B, L, inner))
+    qo = leaf(qkv.double())
+    q, k, v = qo.chunk(3, dim=-1)
+    sp = lambda t: t.reshape(B, L, heads, 4).transpose(1, 2)
+    att = torch.softmax(torch.matmul(sp(q), sp(k).transpose(-1, -2)) * scale, dim=-1)
+    yo = torch.matmul(att, sp(v)).transpose(1, 2).reshape(B, L, inner)
+    (yo * cot.double()).sum().backward()
+    qg = leaf(qkv, DEV)
+    yg = ops.attn4(qg, heads, scale)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, OUT_TOL, "attention out")
+    assert_close(qg.grad, qo.grad, GRAD_TOL, "dqkv")
