@@ -71,6 +71,7 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
 #pragma unroll
     for (int q = 0; q < KQ; ++q) dst[q] = rv ? *reinterpret_cast<const float4*>(x + row * ldx + 16 * q + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
+  const bool vec_ok = (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
   constexpr bool kPrefetch = KQ < 16 && NB < 16;   // the widest variants have no registers to spare for a second row block
   fetch(rb, xa);
   __syncthreads();
@@ -86,19 +87,27 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
       for (int e = 0; e < 4; ++e) {
         const int s = q * 4 + e;
 #pragma unroll
-        for (int cb = 0; cb < NB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], wl[(cb * ksteps + s) * 64 + lane], acc[cb], 0, 0, 0);
+        // operands swapped (W fragment as A, X fragment as B): the accumulator tile is Y^T, i.e. a lane ends up with FOUR
+        // CONSECUTIVE output columns of one row -> float4 stores (8 per row block instead of 32 scalar ones)
+        for (int cb = 0; cb < NB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(cb * ksteps + s) * 64 + lane], ae[e], acc[cb], 0, 0, 0);
       }
     }
-    // C layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+    // C^T layout: column (lane & 15) -> row of Y, row (lane >> 4) * 4 + reg -> column of Y
+    {
+      const int64_t orow = rb * 16 + i;
+      if (orow < M) {
 #pragma unroll
-    for (int cb = 0; cb < NB; ++cb) {
-      const int n = cb * 16 + i;
-      if (n < N) {
-        const float bv = bias ? bias[n] : 0.f;
+        for (int cb = 0; cb < NB; ++cb) {
+          const int n = cb * 16 + kk * 4;
+          if (vec_ok && n + 3 < N) {
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
+            *reinterpret_cast<float4*>(y + orow * ldy + n) = make_float4(acc[cb][0] + bv.x, acc[cb][1] + bv.y, acc[cb][2] + bv.z, acc[cb][3] + bv.w);
+          } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t orow = rb * 16 + kk * 4 + r;
-          if (orow < M) y[orow * ldy + n] = acc[cb][r] + bv;
+            for (int r = 0; r < 4; ++r)
+              if (n + r < N) y[orow * ldy + n + r] = acc[cb][r] + (bias ? bias[n + r] : 0.f);
+          }
         }
       }
     }
