@@ -235,7 +235,11 @@ WGeo wgeo(int64_t B, int64_t H, int64_t W, int64_t C, int K) {
   g.gx = (int)adnm_cdiv(C4, g.cgb);
   const int slots = 64 / g.cgb;
   const int64_t tiles = B * H * adnm_cdiv(W, TW);
-  int64_t npb = adnm_cdiv(tiles, (int64_t)slots * 8);          // ~8 tiles per lane
+  // tiles per lane: 8 on the big maps; on the deep ones fewer (down to 2 = one trip of the two-tiles-in-flight loop), so that the
+  // grid still has ~256 workgroups instead of a handful of lanes walking a long dependent chain
+  int64_t tpl = (tiles * g.gx) / ((int64_t)slots * 256);
+  tpl = tpl < 2 ? 2 : (tpl > 8 ? 8 : tpl);
+  int64_t npb = adnm_cdiv(tiles, (int64_t)slots * tpl);
   int64_t cap = (4 << 20) / ((int64_t)(K * K + 1) * C * 4);     // keep the partials under ~4 MB
   if (cap > 1024) cap = 1024;
   if (cap < 32) cap = 32;

@@ -280,9 +280,10 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   float* part = (float*)ws;
   p.C = split ? part : c;
   p.ldc = split ? J : ldc;
-  p.slice_stride = split ? I * J : 0;
-  p.bsum = dbias ? (split ? part + (int64_t)pl.nbs * I * J : dbias) : nullptr;
-  p.bsum_stride = split ? I : 0;
+  const int64_t rowlen = I * J + (dbias ? I : 0);   // a partial row = [output tile rows | bias sums]: one fold for both
+  p.slice_stride = split ? rowlen : 0;
+  p.bsum = dbias ? (split ? part + I * J : dbias) : nullptr;
+  p.bsum_stride = split ? rowlen : 0;
   const unsigned grid = (unsigned)adnm_cdiv((int64_t)pl.ntiles * pl.nbs, kWaves / pl.wpt);
   {
     ADNM_PROF(op == ADNM_SKGEMM_NT ? "skgemm_nt" : (op == ADNM_SKGEMM_NN ? "skgemm_nn" : "skgemm_tn"), st, 4.0 * ((double)M * (K + N) + (double)N * K));
@@ -292,8 +293,7 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   }
   ADNM_CHECK_LAUNCH("skgemm");
   if (split) {
-    adnm_launch_fold("skgemm_fold", part, pl.nbs, (int)(I * J), {c, (int)(I * J)}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
-    if (dbias) adnm_launch_fold("skgemm_fold", part + (int64_t)pl.nbs * I * J, pl.nbs, (int)I, {dbias, (int)I}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
+    adnm_launch_fold("skgemm_fold", part, pl.nbs, (int)rowlen, {c, (int)(I * J)}, {dbias, dbias ? (int)I : 0}, {nullptr, 0}, {nullptr, 0}, st);
     ADNM_CHECK_LAUNCH("skgemm_fold");
   }
   return ADNM_OK;

@@ -204,7 +204,8 @@ __global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const float* __restri
     __syncthreads();
   }
   if (wave == 0) {
-    float* dst = part + (int64_t)blockIdx.x * N * K;
+    const int64_t rowlen = (int64_t)N * K + (bpart ? N : 0);   // one partial row = [dW tile rows | bias sums]: ONE fold for both
+    float* dst = part + (int64_t)blockIdx.x * rowlen;
 #pragma unroll
     for (int a = 0; a < NBN; ++a) {
 #pragma unroll
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const float* __restri
           if (n < N && k < K) dst[(int64_t)n * K + k] = acc[a][b][r];
         }
       }
-      if (bpart && kk == 0 && nb0 + a * 16 + i < N) bpart[(int64_t)blockIdx.x * N + nb0 + a * 16 + i] = bsum[a];
+      if (bpart && kk == 0 && nb0 + a * 16 + i < N) dst[(int64_t)N * K + nb0 + a * 16 + i] = bsum[a];
     }
   }
 }
@@ -327,15 +328,15 @@ extern "C" int adnm_tsgemm_tn(const float* dy, int64_t lddy, const float* x, int
   }
   const int nblk = tn_blocks(M);
   float* part = (float*)ws;
-  float* bpart = dbias ? part + (int64_t)nblk * N * K : nullptr;
+  float* bpart = dbias ? part : nullptr;   // non-null = "emit the bias sums at the end of every partial row"
   hipStream_t st = (hipStream_t)stream;
 #define TN(A, B) if (a == A && b == B) launch_tn<A, B>(dy, lddy, x, ldx, part, bpart, M, (int)N, (int)K, nblk, ntiles, st)
   TN(1, 1); TN(1, 2); TN(1, 4); TN(1, 8); TN(1, 13); TN(1, 16); TN(2, 1); TN(2, 2); TN(2, 4); TN(2, 8); TN(2, 13);
   TN(4, 1); TN(4, 2); TN(4, 4); TN(8, 1); TN(8, 2); TN(13, 1); TN(13, 2); TN(16, 1);
 #undef TN
   ADNM_CHECK_LAUNCH("tsgemm_tn");
-  adnm_launch_fold("tsgemm_tn_fold", part, nblk, (int)(N * K), {dw, (int)(N * K)}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
-  if (dbias) adnm_launch_fold("tsgemm_tn_fold", bpart, nblk, (int)N, {dbias, (int)N}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
+  adnm_launch_fold("tsgemm_tn_fold", part, nblk, (int)(N * K + (dbias ? N : 0)), {dw, (int)(N * K)}, {dbias, dbias ? (int)N : 0}, {nullptr, 0},
+                   {nullptr, 0}, st);
   ADNM_CHECK_LAUNCH("tsgemm_tn_fold");
   return ADNM_OK;
 }
