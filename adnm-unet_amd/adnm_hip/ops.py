@@ -47,6 +47,27 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+# Gradient destinations: FlatTrainer registers, for every parameter (keyed by data_ptr), the slice of its flat gradient buffer.
+# Backward functions that allocate a parameter gradient themselves take that slice instead of fresh memory, so the value is
+# born in place and the trainer's gather copy for it disappears.  A second claim of the same slice inside one backward pass
+# (a weight used by two autograd nodes) gets fresh memory: autograd then adds the two as usual.
+GRAD_DST = {}
+GRAD_DST_OWNER = [0]
+_GRAD_CLAIMED = set()
+
+
+def grad_claims_reset():
+    _GRAD_CLAIMED.clear()
+
+
+def grad_dst(ptr, shape, device, dtype=torch.float32):
+    g = GRAD_DST.get(ptr)
+    if g is None or ptr in _GRAD_CLAIMED or tuple(g.shape) != tuple(shape) or g.dtype != dtype:
+        return torch.empty(tuple(shape), dtype=dtype, device=device)
+    _GRAD_CLAIMED.add(ptr)
+    return g.detach()   # a fresh tensor object on the same memory: AccumulateGrad only keeps ("steals") a gradient nobody else references
+
+
 def _need_gpu(t):
     if not t.is_cuda:
         raise RuntimeError("adnm_hip kernels run on the GPU only (there is no CPU fallback); got a CPU tensor")
@@ -682,7 +703,7 @@ class AdnPrepFn(torch.autograd.Function):
         params = ctx.saved_tensors
         dm, di, gn, P = ctx.dims
         gouts = [g.contiguous() for g in gouts]
-        dparams = [torch.empty_like(p) for p in params]
+        dparams = [grad_dst(p.data_ptr(), p.shape, p.device, p.dtype) for p in params]
         nb = lib.query("adnm_adnprep_bwd_ws_bytes")
         ws = _ws(nb, params[0].device)
         lib.call("adnm_adnprep_bwd", lib.ptr_table(params), lib.ptr_table(gouts), lib.ptr_table(dparams), dm, di, gn, P, ws.data_ptr(), nb,
@@ -863,36 +884,36 @@ def k_linear_dx(dy2, w, out=None):
     return dx
 
 
-def colsum(t):
+def colsum(t, out=None):
     """sum over the rows of a 2-D fp32 matrix (bias gradient) with the deterministic fold kernel."""
     if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous()):
-        return t.sum(0)
-    out = torch.empty(t.shape[1], dtype=torch.float32, device=t.device)
+        return t.sum(0) if out is None else torch.sum(t, 0, out=out)
+    if out is None:
+        out = torch.empty(t.shape[1], dtype=torch.float32, device=t.device)
     lib.call("adnm_colsum", t.data_ptr(), out.data_ptr(), t.shape[0], t.shape[1], _stream())
     return out
 
 
-def k_linear_dw(dy2, x2, want_bias):
-    """dW = dY^T X (N,K), dbias = column sums of dY."""
+def k_linear_dw(dy2, x2, want_bias, w_ptr=0, b_ptr=0):
+    """dW = dY^T X (N,K), dbias = column sums of dY.  w_ptr / b_ptr: data_ptr of the parameters (gradient-destination lookup)."""
     M, N = dy2.shape
     K = x2.shape[1]
+    dev = x2.device
+    dw = grad_dst(w_ptr, (N, K), dev)
+    db = grad_dst(b_ptr, (N,), dev) if want_bias else None
     if ts_ok_tn(M, N, K, x2):
-        dev = x2.device
-        dw = torch.empty((N, K), dtype=torch.float32, device=dev)
-        db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
         nb = lib.query("adnm_tsgemm_tn_ws_bytes", M, N, K)
         ws = _ws(nb, dev)
         lib.call("adnm_tsgemm_tn", dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), dw.data_ptr(), _p(db), ws.data_ptr(), nb, M, N, K,
                  _stream())
         return dw, db
     if sk_ok(SK_TN, M, N, K, dy2, x2):
-        dw = torch.empty((N, K), dtype=torch.float32, device=x2.device)
-        db = torch.empty(N, dtype=torch.float32, device=x2.device) if want_bias else None
         if sk_pick((SK_TN, M, N, K, want_bias), lambda: _skgemm(SK_TN, dy2, x2, None, dw, db, M, N, K),
                    lambda: (torch.mm(dy2.t(), x2), colsum(dy2) if want_bias else None)):
             _skgemm(SK_TN, dy2, x2, None, dw, db, M, N, K)
             return dw, db
-    return torch.mm(dy2.t(), x2), (colsum(dy2) if want_bias else None)
+    torch.mm(dy2.t(), x2, out=dw)
+    return dw, (colsum(dy2, out=db) if want_bias else None)
 
 
 class LinearFn(torch.autograd.Function):
@@ -908,6 +929,7 @@ class LinearFn(torch.autograd.Function):
         y = k_linear(x2, w, bias)
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
+        ctx.ptrs = (w.data_ptr(), bias.data_ptr() if bias is not None else 0)
         ctx.shp = shp
         return y.view(*shp[:-1], w.shape[0])
 
@@ -918,7 +940,7 @@ class LinearFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, N)
         dy2 = dy2 if dy2.stride(-1) == 1 else dy2.contiguous()
         dx = k_linear_dx(dy2, w).view(ctx.shp) if ctx.needs_input_grad[0] else None
-        dw, db = k_linear_dw(dy2, x2, ctx.has_bias)
+        dw, db = k_linear_dw(dy2, x2, ctx.has_bias, *ctx.ptrs)
         return dx, dw, db
 
 

@@ -20,7 +20,7 @@ clip_grad_norm_ (train.py:140) and torch.optim.AdamW over 669 tensors (train_unt
 import torch
 import torch.distributed as dist
 
-from . import lib
+from . import lib, ops
 
 
 class FlatTrainer:
@@ -37,6 +37,7 @@ class FlatTrainer:
 
     # ------------------------------------------------------------------ one-time setup
     def _fwd_bwd(self, x, tgt):
+        ops.grad_claims_reset()
         out = self.model(x)
         loss = self.loss_fn(out, tgt)
         loss.backward()
@@ -63,11 +64,25 @@ class FlatTrainer:
             self.g_views.append(self.flat_g[o:o + p.numel()].view_as(p))
             p.grad = None
         self.used, self.n = used, total
+        # backward functions that allocate parameter gradients write them straight into these slices (ops.grad_dst)
+        ops.GRAD_DST.clear()
+        ops.GRAD_DST.update({p.data_ptr(): gv for p, gv in zip(used, self.g_views)})
+        ops.GRAD_DST_OWNER[0] = id(self)
         if self.fused:
             self.ws = torch.empty(int(lib.query("adnm_adamw_ws_bytes")), dtype=torch.uint8, device=dev)
 
+    def __del__(self):
+        try:
+            if ops.GRAD_DST_OWNER[0] == id(self):   # do not leave destinations of a dead trainer behind
+                ops.GRAD_DST.clear()
+        except Exception:
+            pass
+
     def _gather(self):
-        torch._foreach_copy_(self.g_views, [p.grad for p in self.used])
+        """Copy the gradients that were not born inside the flat buffer (same data_ptr = already in place)."""
+        pairs = [(gv, p.grad) for gv, p in zip(self.g_views, self.used) if p.grad.data_ptr() != gv.data_ptr()]
+        if pairs:
+            torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
 
     def prepare(self, x, tgt):
         """Dry-run backward (finds the parameters that receive gradients), flatten, and capture the graph."""
