@@ -287,6 +287,7 @@ class RowNormTapFn(torch.autograd.Function):
         y, mu, rstd = k_rownorm_fwd(x2, w, b, scale, shift, eps, mean)
         ctx.save_for_backward(x2, w, b, scale, mu, rstd)
         ctx.mean, ctx.shp, ctx.has_shift = mean, shp, shift is not None
+        ctx.set_materialize_grads(False)
         return y.view(shp), x
 
     @staticmethod
@@ -1135,6 +1136,7 @@ class TokMeanTapFn(torch.autograd.Function):
         ws = _ws(nb, x.device)
         lib.call("adnm_tokmean_fwd", xc.data_ptr(), mean.data_ptr(), ws.data_ptr(), nb, B, L, C, _stream())
         ctx.shp = (B, L, C)
+        ctx.set_materialize_grads(False)   # an unused output arrives as None, not as a full-size zeros tensor
         return x, mean
 
     @staticmethod
@@ -1144,8 +1146,10 @@ class TokMeanTapFn(torch.autograd.Function):
             return dxa
         if dxa is not None and not dxa.is_contiguous():
             dxa = dxa.contiguous()
+        if dmean.stride(-1) != 1 or dmean.stride(0) % 4 or dmean.data_ptr() % 16:   # usually a column slice of the (B, sum C) concat gradient
+            dmean = dmean.contiguous()
         dx = torch.empty((B, L, C), dtype=torch.float32, device=dmean.device)
-        lib.call("adnm_tokmean_bwd", _p(dxa), dmean.contiguous().data_ptr(), dx.data_ptr(), B, L, C, _stream())
+        lib.call("adnm_tokmean_bwd", _p(dxa), dmean.data_ptr(), dmean.stride(0), dx.data_ptr(), B, L, C, _stream())
         return dx
 
 

@@ -202,12 +202,12 @@ __global__ __launch_bounds__(kBlock) void tokmean_kernel(const float* __restrict
 
 // dx[b,l,c] = dxa[b,l,c] + dmean[b,c] / L   (dxa may be NULL): the pool's broadcast gradient and the gradient of the other
 // consumers of the same tensor in one pass (autograd would expand, divide and add in three)
-__global__ __launch_bounds__(kBlock) void tokmean_bwd_kernel(const float* __restrict__ dxa, const float* __restrict__ dmean, float* __restrict__ dx,
-                                                             int64_t L, int C4, int64_t total4, float inv_l) {
+__global__ __launch_bounds__(kBlock) void tokmean_bwd_kernel(const float* __restrict__ dxa, const float* __restrict__ dmean, int64_t ldm,
+                                                             float* __restrict__ dx, int64_t L, int C4, int64_t total4, float inv_l) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (int64_t)gridDim.x * kBlock) {
     const int q = (int)(i % C4);
     const int64_t b = i / ((int64_t)C4 * L);
-    const float4 m = *reinterpret_cast<const float4*>(dmean + (b * C4 + q) * 4);
+    const float4 m = *reinterpret_cast<const float4*>(dmean + b * ldm + q * 4);
     float4 v = dxa ? *reinterpret_cast<const float4*>(dxa + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     v.x = fmaf(m.x, inv_l, v.x); v.y = fmaf(m.y, inv_l, v.y); v.z = fmaf(m.z, inv_l, v.z); v.w = fmaf(m.w, inv_l, v.w);
     *reinterpret_cast<float4*>(dx + i * 4) = v;
@@ -429,13 +429,14 @@ extern "C" int adnm_tokmean_fwd(const float* x, float* mean, void* ws, int64_t w
   return ADNM_OK;
 }
 
-extern "C" int adnm_tokmean_bwd(const float* dxa, const float* dmean, float* dx, int64_t B, int64_t L, int64_t C, adnm_stream_t stream) {
+extern "C" int adnm_tokmean_bwd(const float* dxa, const float* dmean, int64_t ldm, float* dx, int64_t B, int64_t L, int64_t C, adnm_stream_t stream) {
   ADNM_REQUIRE(dmean && dx, "tokmean_bwd: null pointer");
   ADNM_REQUIRE(B > 0 && L > 0 && C > 0 && C % 4 == 0, "tokmean_bwd: bad shape");
+  ADNM_REQUIRE(ldm >= C && ldm % 4 == 0 && (reinterpret_cast<uintptr_t>(dmean) & 15) == 0, "tokmean_bwd: dmean rows must be 16-byte aligned (ldm %% 4 == 0)");
   hipStream_t st = (hipStream_t)stream;
   const int64_t total4 = B * L * (C / 4);
   ADNM_PROF("tokmean_bwd", st, 4.0 * B * L * C * (dxa ? 2 : 1));
-  tokmean_bwd_kernel<<<grid_for(total4), kBlock, 0, st>>>(dxa, dmean, dx, L, (int)(C / 4), total4, 1.0f / (float)L);
+  tokmean_bwd_kernel<<<grid_for(total4), kBlock, 0, st>>>(dxa, dmean, ldm, dx, L, (int)(C / 4), total4, 1.0f / (float)L);
   ADNM_CHECK_LAUNCH("tokmean_bwd");
   return ADNM_OK;
 }

@@ -220,12 +220,12 @@ int adnm_attn4_bwd(const float* dout, const float* qkv, const float* out, const 
 
 /* ---------------------------------------------------------------- Channel_Att_Bridge pooling (K15)
  * model_untils.py:570-592 of the reference: mean[b,c] = (1/L) sum_l x[b,l,c] for contiguous fp32 (B,L,C) tokens (the
- * reference's AdaptiveAvgPool2d(1) of each skip), C % 4 == 0; bwd: dx = dxa + dmean/L broadcast over l (dxa = the gradient of
+ * reference's AdaptiveAvgPool2d(1) of each skip), C % 4 == 0; bwd: dx = dxa + dmean/L broadcast over l (dmean rows ldm apart; dxa = the gradient of
  * the tensor's other consumers, or NULL), one pass.  conv1d3: nn.Conv1d(1,1,3,padding=1) over the concatenated channel axis
  * of (B,n) (get_all_att); bwd writes dx and dwb = [dw0, dw1, dw2, dbias] (OVERWRITTEN). */
 int64_t adnm_tokmean_ws_bytes(int64_t B, int64_t L, int64_t C);
 int adnm_tokmean_fwd(const float* x, float* mean, void* ws, int64_t ws_bytes, int64_t B, int64_t L, int64_t C, adnm_stream_t stream);
-int adnm_tokmean_bwd(const float* dxa, const float* dmean, float* dx, int64_t B, int64_t L, int64_t C, adnm_stream_t stream);
+int adnm_tokmean_bwd(const float* dxa, const float* dmean, int64_t ldm, float* dx, int64_t B, int64_t L, int64_t C, adnm_stream_t stream);
 int adnm_conv1d3_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t n, adnm_stream_t stream);
 int adnm_conv1d3_bwd(const float* dy, const float* x, const float* w, float* dx, float* dwb, int64_t B, int64_t n, adnm_stream_t stream);
 
