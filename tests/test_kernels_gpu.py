@@ -147,6 +147,8 @@ def test_ssd_rejects_unsupported():
     (2, 10, 14, 32, 5, lib.ACT_NONE, False),      # wavelet-domain 5x5
     (1, 5, 3, 12, 5, lib.ACT_GELU, True),
     (1, 1, 1, 4, 3, lib.ACT_SILU, True),
+    (1, 131, 130, 24, 3, lib.ACT_NONE, True),     # column-walker weight gradient on ragged strips (H, W not multiples of 4 / SEG)
+    (3, 128, 129, 8, 3, lib.ACT_GELU, False),
 ])
 def test_dwconv(B, H, W, C, K, act, bias):
     x, w = T("dw.x", (B, H * W, C)), T("dw.w", (C, 1, K, K), 0.5)
