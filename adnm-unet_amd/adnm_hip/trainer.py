@@ -57,11 +57,20 @@ class FlatTrainer:
         self.exp_avg_sq = torch.zeros(total, dtype=dt, device=dev)
         self.state = torch.zeros(4, dtype=torch.float32, device=dev)
         self.g_views = []
+        def shaped(flat, o, p):
+            """view of the flat slice with p's logical shape.  Dense conv weights (Cout, Cin>1, kh, kw) get channels-last strides:
+            MIOpen's NHWC kernels then read them (and write their gradients) as they lie, instead of re-laying them out in a
+            copy kernel on every call (13 convs x 3 passes per step)."""
+            t = flat[o:o + p.numel()]
+            if p.dim() == 4 and p.shape[1] > 1 and p.is_cuda:
+                co, ci, kh, kw = p.shape
+                return t.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+            return t.view_as(p)
         for p, o in zip(used, offs):
-            view = self.flat_p[o:o + p.numel()].view_as(p)
+            view = shaped(self.flat_p, o, p)
             view.copy_(p.data)
             p.data = view
-            self.g_views.append(self.flat_g[o:o + p.numel()].view_as(p))
+            self.g_views.append(shaped(self.flat_g, o, p))
             p.grad = None
         self.used, self.n = used, total
         # backward functions that allocate parameter gradients write them straight into these slices (ops.grad_dst)

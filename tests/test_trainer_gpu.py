@@ -45,3 +45,35 @@ def test_fused_step_matches_torch(use_graph, max_norm):
     # parameters that never receive a gradient are untouched (no decay), as torch.optim.AdamW leaves them
     unused = [k for k, p in mine.named_parameters() if all(p is not q for q in tr.used)]
     assert "alpha1" in unused and "act.beta" in unused
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_whole_model_step_vs_reference_fixture(use_graph):
+    """FlatTrainer (flat buffers, channels-last conv weights, in-place gradient destinations, hipGraph replay, fused
+    clip + AdamW) on the whole ADNM-UNet: loss, pre-clip gradient norm and every parameter after one step against the values the
+    reference produced with clip_grad_norm_(0.025) + torch.optim.AdamW (tests/golden, train.py:140, train_untils.py:35-42)."""
+    from models.ADNMUNet import create_ADNMUNet
+    from models.loss import enRainfallLoss
+    from util import load_npz
+    z = load_npz("visionmamba_64_b2")
+    model = create_ADNMUNet(5, 20, 6, img_size=64)
+    recipe.fill_parameters(model)
+    model = model.to(DEV).train()
+    frames = recipe.radar_batch(2, 25, 64, name="radar64").to(DEV)
+    x, tgt = frames[:, :5], frames[:, 5:]
+    tr = FlatTrainer(model, enRainfallLoss(0.57, 0.25, gamma=0.0), lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2, max_norm=0.025,
+                     use_graph=use_graph)
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    loss = tr.step(x, tgt)
+    assert abs(float(loss) - float(z["loss"])) <= 1e-4 * abs(float(z["loss"]))
+    assert abs(float(tr.grad_norm()) - float(z["clip_pre_norm"])) <= 1e-3 * float(z["clip_pre_norm"])
+    names, ref_sums, gn = [str(n) for n in z["names"]], z["param_sum_after_step"].numpy(), z["grad_norms"].numpy()
+    named = dict(model.named_parameters())
+    for i, k in enumerate(names):
+        p = named[k]
+        s = float(p.double().sum())
+        assert abs(s - ref_sums[i]) <= 2.5e-3 * p.numel() ** 0.5 + 1e-5 * abs(ref_sums[i]) + 1e-6, k
+        if gn[i] < 0:   # the reference leaves these without a gradient: neither updated nor decayed
+            assert torch.equal(p, before[k]), k
+    # state_dict still has the reference's logical shapes (conv weights are channels-last views of the flat buffer)
+    assert model.state_dict()["refiner.out_proj.conv.0.conv.weight"].shape == (64, 32, 3, 3)
