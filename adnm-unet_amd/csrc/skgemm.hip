@@ -121,7 +121,12 @@ __global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
 #pragma unroll
       for (int a = 0; a < kT; ++a)
 #pragma unroll
-        for (int b = 0; b < kT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][e], bv[b][e], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < kT; ++b) {
+          // B_RC (the NT op): operands swapped, so the accumulator block is C^T and a lane ends up with four CONSECUTIVE output
+          // columns of one row (float4 stores); otherwise the 4 interleaved column blocks already give that
+          if (B_RC) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[b][e], av[a][e], acc[a][b], 0, 0, 0);
+          else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][e], bv[b][e], acc[a][b], 0, 0, 0);
+        }
   };
   // fetches are unconditional (past the end they re-read the last chunk): a branch around them would make the compiler's
   // wait-count bookkeeping assume the worst path and wait for the NEW loads before the first MFMA
@@ -170,32 +175,40 @@ __global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
   // epilogue.  MFMA C layout: column = lane & 15, row = (lane >> 4) * 4 + reg (local to the 16 x 16 block)
   float* Cp = p.C + (int64_t)bslice * p.slice_stride;
   const bool add_bias = p.bias && bslice == 0;
-  float bias_v[kT] = {0.f, 0.f, 0.f, 0.f};
-  if (B_RC && add_bias) {
+  if (B_RC) {
+    // C^T blocks: column (lane & 15) -> row i of C, row (lane >> 4) * 4 + reg -> column j of C
+    const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(Cp) & 15) == 0 && (!add_bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
 #pragma unroll
-    for (int b = 0; b < kT; ++b) {
-      const int jg = j0 + 16 * b + l15;
-      bias_v[b] = p.bias[jg < p.J ? jg : p.J - 1];
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < kT; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int il = kk * 4 + r;
-      const int ig = A_RC ? i0 + 16 * a + il : i0 + 4 * il + a;
+    for (int a = 0; a < kT; ++a) {
+      const int ig = i0 + 16 * a + l15;
       if (ig >= p.I) continue;
-      if (B_RC) {
 #pragma unroll
-        for (int b = 0; b < kT; ++b) {
-          const int jg = j0 + 16 * b + l15;
-          if (jg < p.J) Cp[(int64_t)ig * p.ldc + jg] = acc[a][b][r] + bias_v[b];
+      for (int b = 0; b < kT; ++b) {
+        const int jg = j0 + 16 * b + 4 * kk;
+        if (vec_ok && jg + 3 < p.J) {
+          float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (add_bias) bv4 = *reinterpret_cast<const float4*>(p.bias + jg);
+          *reinterpret_cast<float4*>(Cp + (int64_t)ig * p.ldc + jg) =
+              make_float4(acc[a][b][0] + bv4.x, acc[a][b][1] + bv4.y, acc[a][b][2] + bv4.z, acc[a][b][3] + bv4.w);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (jg + r < p.J) Cp[(int64_t)ig * p.ldc + jg + r] = acc[a][b][r] + (add_bias ? p.bias[jg + r] : 0.f);
         }
-      } else {
+      }
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < kT; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int il = kk * 4 + r;
+        const int ig = A_RC ? i0 + 16 * a + il : i0 + 4 * il + a;
+        if (ig >= p.I) continue;
         const int jg = j0 + 4 * l15;
         if (jg < p.J) *reinterpret_cast<float4*>(Cp + (int64_t)ig * p.ldc + jg) = make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
       }
-    }
+  }
   if (!A_RC && p.bsum && (tile % p.tiles_j) == 0) {   // bias gradient: the kk lanes hold different reduction rows
 #pragma unroll
     for (int t = 0; t < kT; ++t) bs[t] += __shfl_xor(bs[t], 16, 64), bs[t] += __shfl_xor(bs[t], 32, 64);
