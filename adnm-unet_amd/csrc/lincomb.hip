@@ -12,7 +12,7 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kMaxPartBlocks = 256;
+constexpr int kMaxPartBlocks = 1024;  // 4 workgroups per CU: enough waves in flight to stream at HBM rate (256 left 1 per CU: ~2 TB/s)
 
 inline int lanes_per_row(int64_t d) {
   int l = 1;
@@ -77,24 +77,42 @@ __global__ __launch_bounds__(kBlock) void lincomb_bwd_kernel(const T* __restrict
     gm[i] = (gamma && c < C) ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
     ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int64_t row = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x / lpr); row < M; row += (int64_t)gridDim.x * rows_per_block) {
+  // two rows per trip with ALL loads issued before the first store: the dx pointers are opaque to the compiler (no restrict
+  // through the struct), so without this it orders every load behind the previous row's stores
+  const int64_t rstride = (int64_t)gridDim.x * rows_per_block;
+  for (int64_t row = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x / lpr); row < M; row += 2 * rstride) {
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int c = (i * lpr + lane_in_row) * 4;
       if (c >= C) continue;
-      const float4 g = Io<T>::ld4(dy + row * lddy + c);
-      const float4 gg = make_float4(g.x * gm[i].x, g.y * gm[i].y, g.z * gm[i].z, g.w * gm[i].w);
-      float4 mix = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 g[2], v[2][K];
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const float4 v = Io<T>::ld4((const T*)o.x[k] + row * o.ld[k] + c);
-        ds[k] += gg.x * v.x + gg.y * v.y + gg.z * v.z + gg.w * v.w;
-        mix.x = fmaf(sc[k], v.x, mix.x); mix.y = fmaf(sc[k], v.y, mix.y);
-        mix.z = fmaf(sc[k], v.z, mix.z); mix.w = fmaf(sc[k], v.w, mix.w);
-        if (gr.dx[k]) Io<T>::st4((T*)gr.dx[k] + row * gr.ld[k] + c, make_float4(sc[k] * gg.x, sc[k] * gg.y, sc[k] * gg.z, sc[k] * gg.w));
+      for (int u = 0; u < 2; ++u) {
+        const int64_t r = row + u * rstride;
+        const bool ok = r < M;
+        const int64_t rr = ok ? r : row;
+        g[u] = Io<T>::ld4(dy + rr * lddy + c);
+        if (!ok) g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[u][k] = Io<T>::ld4((const T*)o.x[k] + rr * o.ld[k] + c);
       }
-      ag[i].x = fmaf(g.x, mix.x, ag[i].x); ag[i].y = fmaf(g.y, mix.y, ag[i].y);
-      ag[i].z = fmaf(g.z, mix.z, ag[i].z); ag[i].w = fmaf(g.w, mix.w, ag[i].w);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t r = row + u * rstride;
+        if (r >= M) continue;
+        const float4 gg = make_float4(g[u].x * gm[i].x, g[u].y * gm[i].y, g[u].z * gm[i].z, g[u].w * gm[i].w);
+        float4 mix = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const float4 vv = v[u][k];
+          ds[k] += gg.x * vv.x + gg.y * vv.y + gg.z * vv.z + gg.w * vv.w;
+          mix.x = fmaf(sc[k], vv.x, mix.x); mix.y = fmaf(sc[k], vv.y, mix.y);
+          mix.z = fmaf(sc[k], vv.z, mix.z); mix.w = fmaf(sc[k], vv.w, mix.w);
+          if (gr.dx[k]) Io<T>::st4((T*)gr.dx[k] + r * gr.ld[k] + c, make_float4(sc[k] * gg.x, sc[k] * gg.y, sc[k] * gg.z, sc[k] * gg.w));
+        }
+        ag[i].x = fmaf(g[u].x, mix.x, ag[i].x); ag[i].y = fmaf(g[u].y, mix.y, ag[i].y);
+        ag[i].z = fmaf(g[u].z, mix.z, ag[i].z); ag[i].w = fmaf(g[u].w, mix.w, ag[i].w);
+      }
     }
   }
   const int sstride = C + 4;

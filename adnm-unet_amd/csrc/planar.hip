@@ -396,12 +396,26 @@ __global__ __launch_bounds__(256) void instnorm_bwd_scalar_kernel(const float* _
                                                                   float* __restrict__ dscale, float* __restrict__ dshift) {
   __shared__ float sm[2][4];
   float a = 0.f, q = 0.f;
-  const int64_t n = (int64_t)rows * C;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const int64_t r = i / C;
-    const int c = (int)(i % C);
-    a += part[r * 2 * C + c];
-    q += part[r * 2 * C + C + c];
+  // float4 loads, four rows in flight per thread: this is one workgroup walking a few thousand floats, so what matters is the
+  // number of dependent load round trips (it took 15 us as a scalar loop)
+  const int C4 = C >> 2;
+  const int64_t n4 = (int64_t)rows * C4;
+  for (int64_t i0 = threadIdx.x; i0 < n4; i0 += 4 * 256) {
+    float4 va[4], vq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + (int64_t)u * 256;
+      const bool ok = i < n4;
+      const int64_t r = ok ? i / C4 : 0;
+      const int c = ok ? (int)(i % C4) * 4 : 0;
+      va[u] = ok ? *reinterpret_cast<const float4*>(part + r * 2 * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      vq[u] = ok ? *reinterpret_cast<const float4*>(part + r * 2 * C + C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a += (va[u].x + va[u].y) + (va[u].z + va[u].w);
+      q += (vq[u].x + vq[u].y) + (vq[u].z + vq[u].w);
+    }
   }
   a = wave_sum(a);
   q = wave_sum(q);

@@ -13,7 +13,7 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kMaxPartBlocks = 256;
+constexpr int kMaxPartBlocks = 1024;  // 4 workgroups per CU: enough waves in flight to stream at HBM rate (256 left 1 per CU: ~2 TB/s)
 
 __host__ __device__ inline int lanes_per_row(int64_t d) {
   int l = 1;
