@@ -179,7 +179,7 @@ IGeo igeo(int64_t HW, int64_t C) {
   while (g.cgb < 64 && g.cgb < C4) g.cgb <<= 1;
   g.gx = (int)adnm_cdiv(C4, g.cgb);
   const int slots = kBlock / g.cgb;
-  int64_t ppc = (int64_t)slots * 8;
+  int64_t ppc = (int64_t)slots * 8;   // more, smaller chunks were measured SLOWER: every apply workgroup re-merges all chunk partials
   int64_t nch = adnm_cdiv(HW, ppc);
   if (nch > 128) {
     nch = 128;
@@ -214,6 +214,33 @@ __device__ __forceinline__ void fold_slots(float4 (&v)[NV], int cgb, float* smem
         v[k].x += t.x; v[k].y += t.y; v[k].z += t.z; v[k].w += t.w;
       }
   }
+}
+
+// Sum of the nchunk chunk partials [S1 | S2] of (b, channel quad), computed ONCE per workgroup: the pixel slots split the
+// chunks, fold_slots adds them up, wave 0 publishes through LDS.  (Every thread walking all chunks itself made the apply
+// kernels prologue-bound: 13 us for a 16 MB map.)  All threads of the block must call it.
+__device__ __forceinline__ void merge_partials(const float* __restrict__ part, int b, int nchunk, int C, int c, bool cv, int cgb, float4& s1,
+                                               float4& s2) {
+  __shared__ __attribute__((aligned(16))) float msm[3 * 2 * 64 * 4];
+  __shared__ __attribute__((aligned(16))) float mout[2][64][4];
+  const int cgl = threadIdx.x & (cgb - 1), slot = threadIdx.x / cgb, slots = kBlock / cgb;
+  float4 v[2] = {f4zero(), f4zero()};
+  if (cv) {
+    for (int k = slot; k < nchunk; k += slots) {
+      const float* src = part + ((int64_t)b * nchunk + k) * 2 * C;
+      const float4 a = *reinterpret_cast<const float4*>(src + c), q = *reinterpret_cast<const float4*>(src + C + c);
+      v[0].x += a.x; v[0].y += a.y; v[0].z += a.z; v[0].w += a.w;
+      v[1].x += q.x; v[1].y += q.y; v[1].z += q.z; v[1].w += q.w;
+    }
+  }
+  fold_slots<2>(v, cgb, msm);
+  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < cgb) {
+    *reinterpret_cast<float4*>(&mout[0][cgl][0]) = v[0];
+    *reinterpret_cast<float4*>(&mout[1][cgl][0]) = v[1];
+  }
+  __syncthreads();
+  s1 = *reinterpret_cast<const float4*>(&mout[0][cgl][0]);
+  s2 = *reinterpret_cast<const float4*>(&mout[1][cgl][0]);
 }
 
 // pass 1 of forward: shifted sums.  part[(b,chunk), {S1,S2}, c] with shift K = x[b,0,c]
@@ -269,20 +296,15 @@ __global__ __launch_bounds__(kBlock) void instnorm_apply_kernel(const T* __restr
   const int C4 = C >> 2;
   const int cgl = threadIdx.x & (cgb - 1), slot = threadIdx.x / cgb, slots = kBlock / cgb;
   const int cg = blockIdx.x * cgb + cgl;
-  if (cg >= C4) return;
-  const int c = cg * 4;
+  const bool cv = cg < C4;
+  const int c = cv ? cg * 4 : 0;
   const int b = blockIdx.z;
+  float4 s1, s2;
+  merge_partials(part, b, nchunk, C, c, cv, cgb, s1, s2);
+  if (!cv) return;
   const T* xb = x + (int64_t)b * HW * C + c;
   T* yb = y + (int64_t)b * HW * C + c;
   const float4 K = Io<T>::ld4(xb);
-  float4 s1 = f4zero(), s2 = f4zero();
-#pragma unroll 8
-  for (int k = 0; k < nchunk; ++k) {
-    const float* src = part + ((int64_t)b * nchunk + k) * 2 * C;
-    const float4 a = *reinterpret_cast<const float4*>(src + c), q = *reinterpret_cast<const float4*>(src + C + c);
-    s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
-    s2.x += q.x; s2.y += q.y; s2.z += q.z; s2.w += q.w;
-  }
   const float inv = 1.0f / (float)HW;
   const float4 m = make_float4(s1.x * inv, s1.y * inv, s1.z * inv, s1.w * inv);  // mean of (x-K)
   const float4 mu = make_float4(K.x + m.x, K.y + m.y, K.z + m.z, K.w + m.w);
@@ -356,23 +378,18 @@ __global__ __launch_bounds__(kBlock) void instnorm_bwd_apply_kernel(const T* __r
   const int C4 = C >> 2;
   const int cgl = threadIdx.x & (cgb - 1), slot = threadIdx.x / cgb, slots = kBlock / cgb;
   const int cg = blockIdx.x * cgb + cgl;
-  if (cg >= C4) return;
-  const int c = cg * 4;
+  const bool cv = cg < C4;
+  const int c = cv ? cg * 4 : 0;
   const int b = blockIdx.z;
+  float4 s1, s2;
+  merge_partials(part, b, nchunk, C, c, cv, cgb, s1, s2);
+  if (!cv) return;
   const T* xb = x + (int64_t)b * HW * C + c;
   const T* db = dy + (int64_t)b * HW * C + c;
   T* ob = dx + (int64_t)b * HW * C + c;
   const float4 mu = *reinterpret_cast<const float4*>(mu_in + (int64_t)b * C + c);
   const float4 rs = *reinterpret_cast<const float4*>(rstd_in + (int64_t)b * C + c);
   const float sc = scale ? *scale : 1.f, sh = shift ? *shift : 0.f;
-  float4 s1 = f4zero(), s2 = f4zero();
-#pragma unroll 8
-  for (int k = 0; k < nchunk; ++k) {
-    const float* src = part + ((int64_t)b * nchunk + k) * 2 * C;
-    const float4 a = *reinterpret_cast<const float4*>(src + c), q = *reinterpret_cast<const float4*>(src + C + c);
-    s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
-    s2.x += q.x; s2.y += q.y; s2.z += q.z; s2.w += q.w;
-  }
   const float inv = 1.0f / (float)HW;
   s1.x *= inv; s1.y *= inv; s1.z *= inv; s1.w *= inv;
   s2.x *= inv; s2.y *= inv; s2.z *= inv; s2.w *= inv;
