@@ -25,14 +25,22 @@ from . import lib, ops
 
 class FlatTrainer:
     def __init__(self, model, loss_fn, lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2, max_norm=0.0,
-                 process_group=None, use_graph=True, fused=True):
+                 process_group=None, use_graph=True, fused=True, stages="auto"):
+        """stages: two-stage backward cut at model.forward_stage1 / forward_stage2 (ADNM-UNet: encoder | decoder + refiner), so that
+        the second stage's gradients are all-reduced while the first stage's backward still runs.  True / False force it; "auto"
+        reads ADNM_STAGES (default off).  Measured on one MI355X: the two captured graphs cost 14.0 ms of GPU time against 12.95 ms
+        for the single graph (stalls inside the second replay), while the encoder's backward — the window that hides the ring — is
+        only 2.4 ms long, so the cut pays at 2 ranks (xGMI: one link, ~3.7 ms ring) and not at 8 (~0.9 ms); hence opt-in."""
         self.model, self.loss_fn = model, loss_fn
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.use_graph, self.fused = use_graph, fused
+        can_stage = hasattr(model, "forward_stage1") and hasattr(model, "forward_stage2") and hasattr(model, "stage1_parameters")
+        import os
+        self.staged = can_stage and (os.environ.get("ADNM_STAGES", "0") == "1" if stages == "auto" else bool(stages))
         self.used = None
-        self.graph = None
+        self.graph = self.graph2 = None
         self._steps = 0
 
     # ------------------------------------------------------------------ one-time setup
@@ -46,6 +54,11 @@ class FlatTrainer:
     @torch.no_grad()
     def _flatten(self):
         used = [p for p in self.model.parameters() if p.requires_grad and p.grad is not None]
+        if self.staged:   # flat layout [stage-2 (late) parameters | stage-1 (early) parameters]: each stage's gradients are one range
+            first = {id(p) for p in self.model.stage1_parameters()}
+            self.late = [p for p in used if id(p) not in first]
+            self.early = [p for p in used if id(p) in first]
+            used = self.late + self.early
         dev, dt = used[0].device, used[0].dtype
         offs, total = [], 0
         for p in used:
@@ -73,6 +86,7 @@ class FlatTrainer:
             self.g_views.append(shaped(self.flat_g, o, p))
             p.grad = None
         self.used, self.n = used, total
+        self.n_late = offs[len(self.late)] if self.staged and self.early else total
         # backward functions that allocate parameter gradients write them straight into these slices (ops.grad_dst)
         ops.GRAD_DST.clear()
         ops.GRAD_DST.update({p.data_ptr(): gv for p, gv in zip(used, self.g_views)})
@@ -87,11 +101,43 @@ class FlatTrainer:
         except Exception:
             pass
 
-    def _gather(self):
-        """Copy the gradients that were not born inside the flat buffer (same data_ptr = already in place)."""
-        pairs = [(gv, p.grad) for gv, p in zip(self.g_views, self.used) if p.grad.data_ptr() != gv.data_ptr()]
+    def _gather(self, lo=0, hi=None):
+        """Copy the gradients of used[lo:hi] that were not born inside the flat buffer (same data_ptr = already in place)."""
+        hi = len(self.used) if hi is None else hi
+        pairs = [(gv, p.grad) for gv, p in zip(self.g_views[lo:hi], self.used[lo:hi]) if p.grad.data_ptr() != gv.data_ptr()]
         if pairs:
             torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
+
+    # two-stage backward: A = forward + backward of stage 2 (down to the cut), B = backward of stage 1
+    def _stage_a(self, x, tgt):
+        ops.grad_claims_reset()
+        cut = self.model.forward_stage1(x)
+        # a true cut: stage 2 runs on detached twins, so stage A's backward stops there (a skip tensor also reaches the loss THROUGH the
+        # rest of the encoder; that path belongs to stage B, which starts from the originals with the twins' gradients)
+        twins, origs, args = {}, [], []
+        for t in cut:
+            if torch.is_tensor(t) and t.requires_grad:
+                if id(t) not in twins:   # a tensor handed over twice gets one twin, so its gradient is the sum over both uses
+                    twins[id(t)] = t.detach().requires_grad_(True)
+                    origs.append(t)
+                args.append(twins[id(t)])
+            else:
+                args.append(t)
+        loss = self.loss_fn(self.model.forward_stage2(*args), tgt)
+        uniq = [twins[id(t)] for t in origs]
+        # backward(inputs=...) accumulates through the ordinary AccumulateGrad path (which keeps a fresh gradient without copying it;
+        # autograd.grad() was measured to cost ~290 extra device copies per step here)
+        for t in uniq:
+            t.grad = None
+        torch.autograd.backward(loss, inputs=self.late + uniq)
+        self._carry = [(t, tw.grad) for t, tw in zip(origs, uniq) if tw.grad is not None]
+        self._gather(0, len(self.late))
+        return loss
+
+    def _stage_b(self):
+        ts, gs = [t for t, _ in self._carry], [g for _, g in self._carry]
+        torch.autograd.backward(ts, grad_tensors=gs, inputs=self.early)
+        self._gather(len(self.late), len(self.used))
 
     def prepare(self, x, tgt):
         """Dry-run backward (finds the parameters that receive gradients), flatten, and capture the graph."""
@@ -107,39 +153,77 @@ class FlatTrainer:
             for _ in range(2):
                 for p in self.used:
                     p.grad = None
-                self._fwd_bwd(self.sx, self.st)
-                self._gather()
+                self._run_eager(self.sx, self.st)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         for p in self.used:
             p.grad = None
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread may query events while we capture; only this thread's calls are checked
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.static_loss = self._fwd_bwd(self.sx, self.st)
+        if not self.staged:
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.static_loss = self._fwd_bwd(self.sx, self.st)
+                self._gather()
+        else:
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.static_loss = self._stage_a(self.sx, self.st)
+            self.graph2 = torch.cuda.CUDAGraph()   # same memory pool: stage B reads what stage A saved for it
+            with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                self._stage_b()
+
+    def _run_eager(self, x, tgt, between=None):
+        if not self.staged:
+            loss = self._fwd_bwd(x, tgt)
             self._gather()
+            return loss
+        loss = self._stage_a(x, tgt)
+        if between is not None:
+            between()
+        self._stage_b()
+        return loss
 
     # ------------------------------------------------------------------ per step
     def step(self, x, tgt):
         if self.used is None:
             self.prepare(x, tgt)
+        nccl = self.world > 1 and dist.get_backend(self.group) == "nccl"
+        works = []
+
+        def reduce(lo, hi):
+            """average flat_g[lo:hi] over the ranks; RCCL: asynchronously on its own stream (it first waits for what this stream has
+            enqueued so far, i.e. the stage that produced the range), so the next stage's kernels run beside the ring"""
+            if self.world == 1 or hi <= lo:
+                return
+            t = self.flat_g[lo:hi]
+            if nccl:
+                works.append(dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                t.div_(self.world)
+
         if self.graph is not None:
             if x.data_ptr() != self.sx.data_ptr():
                 self.sx.copy_(x, non_blocking=True)
                 self.st.copy_(tgt, non_blocking=True)
             self.graph.replay()
+            if self.staged:
+                reduce(0, self.n_late)
+                self.graph2.replay()
+                reduce(self.n_late, self.n)
+            else:
+                reduce(0, self.n)
             loss = self.static_loss
         else:
-            loss = self._fwd_bwd(x, tgt)
-            self._gather()
+            if self.staged:
+                loss = self._run_eager(x, tgt, between=lambda: reduce(0, self.n_late))
+                reduce(self.n_late, self.n)
+            else:
+                loss = self._run_eager(x, tgt)
+                reduce(0, self.n)
             for p in self.used:
                 p.grad = None
-        if self.world > 1:
-            if dist.get_backend(self.group) == "nccl":
-                dist.all_reduce(self.flat_g, op=dist.ReduceOp.AVG, group=self.group)
-            else:
-                dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
-                self.flat_g.div_(self.world)
+        for w in works:
+            w.wait()   # the compute stream waits for the rings; the host does not block
         self._optimizer_step()
         self._steps += 1
         return loss

@@ -324,11 +324,19 @@ class VisionMamba(nn.Module):
 
     def forward(self, x, mask=None):
         """x: (B, T_in, 1, H, W) float32 -> (B, T_out, 1, H, W) (ADNMUNet.py:824-829 of the reference)."""
-        x = x.squeeze(2)
-        x, skips, res = self.encoder(x)
-        x = self.decoder(x, skips)
-        out = self.refiner(x, res)
-        return out.unsqueeze(2)
+        return self.forward_stage2(*self.forward_stage1(x))
+
+    # The same forward cut at the encoder / decoder boundary.  adnm_hip.trainer.FlatTrainer uses the cut for a two-stage
+    # backward on multi-GPU runs: the decoder + refiner gradients are all-reduced over xGMI while the encoder's backward runs.
+    def forward_stage1(self, x):
+        x, skips, res = self.encoder(x.squeeze(2))
+        return (x, res, *skips)
+
+    def forward_stage2(self, x, res, *skips):
+        return self.refiner(self.decoder(x, list(skips)), res).unsqueeze(2)
+
+    def stage1_parameters(self):
+        return self.encoder.parameters()
 
 
 def get_scalar_parameters(model):

@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--prof-steps", type=int, default=3)
+    ap.add_argument("--stages", default="auto", choices=["auto", "0", "1"],
+                    help="two-stage backward (encoder | decoder+refiner) that overlaps the gradient all-reduce with the encoder's backward: "
+                         "auto = the ADNM_STAGES environment variable (default off: on one MI355X the second graph replay costs "
+                         "more than an 8-rank ring takes)")
     ap.add_argument("--dump-prof", default="", help="write the per-(kernel, shape) HIP-event table of the instrumented steps to this file")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): replay fwd+bwd as a captured hipGraph; 0: eager launches")
     ap.add_argument("--blas", default="hipblas", choices=["default", "hipblas", "hipblaslt"],
@@ -162,7 +166,7 @@ def main():
     criterion = enRainfallLoss(omega_t=0.57, alpha=0.25, gamma=0.).to(dev)  # train_untils.py:43
     # AdamW recipe of train_untils.py:35-42; clip threshold = norm_max of the warm-up epochs (train.py:87,122-124)
     trainer = FlatTrainer(model, criterion, lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2, max_norm=0.025,
-                          use_graph=bool(args.graph))
+                          use_graph=bool(args.graph), stages="auto" if args.stages == "auto" else bool(int(args.stages)))
     frames = recipe.radar_batch(args.batch, args.in_frames + args.out_frames, args.size, salt=rank, name="bench").to(dev)
     x, tgt = frames[:, :args.in_frames].contiguous(), frames[:, args.in_frames:].contiguous()
     trainer.prepare(x, tgt)
@@ -258,7 +262,7 @@ def main():
             "config": {"workload": f"ADNM-UNet create_ADNMUNet({args.in_frames},{args.out_frames},6) {args.size}x{args.size} full training step "
                                    "(fwd + enRainfallLoss + bwd + clip_grad_norm_ + AdamW), recipe parameters, synthetic radar frames in HBM",
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch, "frames": f"{args.in_frames}->{args.out_frames}",
-                       "parallelism": f"dp{world}" if world > 1 else "single", "launch": "hipGraph replay" if args.graph else "eager",
+                       "parallelism": f"dp{world}" if world > 1 else "single", "launch": ("hipGraph replay" if args.graph else "eager") + (", two-stage backward with overlapped all-reduce" if trainer.staged else ""),
                        "loss": round(loss_val, 6)},
             "roofline": roofline,
         }

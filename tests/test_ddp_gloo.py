@@ -41,7 +41,19 @@ class Toy(nn.Module):
         self.s = nn.Parameter(torch.tensor(1.0))
 
     def forward(self, x):
-        return self.b(torch.tanh(self.a(x))) * self.s
+        return self.forward_stage2(*self.forward_stage1(x))
+
+    # the cut FlatTrainer uses for its two-stage backward on > 1 rank (all-reduce of stage 2's gradients while stage 1's backward
+    # runs); the hidden tensor is handed over twice on purpose: the trainer must differentiate it once
+    def forward_stage1(self, x):
+        h = torch.tanh(self.a(x))
+        return (h, h)
+
+    def forward_stage2(self, h1, h2):
+        return self.b(0.5 * (h1 + h2)) * self.s
+
+    def stage1_parameters(self):
+        return self.a.parameters()
 
 
 def _worker(rank, world, port, q):
@@ -109,12 +121,13 @@ def _trainer_worker(rank, world, port, q):
     from adnm_hip.trainer import FlatTrainer
     model = Toy()
     tr = FlatTrainer(model, lambda o, t: (o - t).pow(2).mean(), lr=1e-2, eps=1e-9, weight_decay=1e-2, max_norm=0.5,
-                     use_graph=False, fused=False)  # CPU: exercises flattening + all-reduce; the HIP optimiser needs a GPU
+                     use_graph=False, fused=False, stages=True)  # CPU: flattening + two-stage backward + all-reduce (HIP optimiser needs a GPU)
     torch.manual_seed(100 + rank)
     xs = [torch.randn(5, 8) for _ in range(3)]
     ts = [torch.randn(5, 4) for _ in range(3)]
     for x, t in zip(xs, ts):
         tr.step(x, t)
+    assert tr.staged and len(tr.early) == 2 and len(tr.late) == 3 and 0 < tr.n_late < tr.n   # 2 ranks -> two-stage backward
     q.put((rank, _plain({"final": {k: p.detach().clone() for k, p in model.named_parameters()}, "xs": xs, "ts": ts,
                          "n_used": len(tr.used)})))
     dist.barrier()

@@ -47,8 +47,8 @@ def test_fused_step_matches_torch(use_graph, max_norm):
     assert "alpha1" in unused and "act.beta" in unused
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_whole_model_step_vs_reference_fixture(use_graph):
+@pytest.mark.parametrize("use_graph,stages", [(False, False), (True, False), (False, True), (True, True)])
+def test_whole_model_step_vs_reference_fixture(use_graph, stages):
     """FlatTrainer (flat buffers, channels-last conv weights, in-place gradient destinations, hipGraph replay, fused
     clip + AdamW) on the whole ADNM-UNet: loss, pre-clip gradient norm and every parameter after one step against the values the
     reference produced with clip_grad_norm_(0.025) + torch.optim.AdamW (tests/golden, train.py:140, train_untils.py:35-42)."""
@@ -61,12 +61,17 @@ def test_whole_model_step_vs_reference_fixture(use_graph):
     model = model.to(DEV).train()
     frames = recipe.radar_batch(2, 25, 64, name="radar64").to(DEV)
     x, tgt = frames[:, :5], frames[:, 5:]
+    # stages=True: the two-stage backward (encoder | decoder + refiner, two graphs) that multi-GPU runs use to overlap the gradient
+    # all-reduce with the encoder's backward — same numbers required
     tr = FlatTrainer(model, enRainfallLoss(0.57, 0.25, gamma=0.0), lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2, max_norm=0.025,
-                     use_graph=use_graph)
+                     use_graph=use_graph, stages=stages)
+    assert tr.staged == stages
     before = {k: p.detach().clone() for k, p in model.named_parameters()}
     loss = tr.step(x, tgt)
     assert abs(float(loss) - float(z["loss"])) <= 1e-4 * abs(float(z["loss"]))
     assert abs(float(tr.grad_norm()) - float(z["clip_pre_norm"])) <= 1e-3 * float(z["clip_pre_norm"])
+    if stages:
+        assert 0 < tr.n_late < tr.n and len(tr.early) > 100 and len(tr.late) > 100
     names, ref_sums, gn = [str(n) for n in z["names"]], z["param_sum_after_step"].numpy(), z["grad_norms"].numpy()
     named = dict(model.named_parameters())
     for i, k in enumerate(names):
