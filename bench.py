@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--in-frames", type=int, default=5)
     ap.add_argument("--out-frames", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=8, help="timed oracle steps of the CPU baseline (~1.5 s each on 16 threads: ~12-15 s in all)")
     ap.add_argument("--prof-steps", type=int, default=3)
     ap.add_argument("--stages", default="auto", choices=["auto", "0", "1"],
                     help="two-stage backward (encoder | decoder+refiner) that overlaps the gradient all-reduce with the encoder's backward: "
