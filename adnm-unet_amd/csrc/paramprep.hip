@@ -171,7 +171,8 @@ struct WtPtrs {
   float *bias, *bias_t;
 };
 
-__global__ __launch_bounds__(kBlock) void wt_prep_fwd_kernel(WtPtrs p, int C, int Cp, int KK, int levels) {
+template <int KK>
+__global__ __launch_bounds__(kBlock) void wt_prep_fwd_kernel(WtPtrs p, int C, int Cp, int levels) {
   // one thread per (group, padded channel): writes its K*K taps
   const int per0 = Cp, perl = 4 * Cp;
   const int total = per0 + levels * perl;
@@ -181,7 +182,11 @@ __global__ __launch_bounds__(kBlock) void wt_prep_fwd_kernel(WtPtrs p, int C, in
     const int cg = g == 0 ? C : 4 * C, cgp = g == 0 ? Cp : 4 * Cp;
     const bool live = c < cg;
     const float sc = live ? p.s[g][c] : 0.f;
-    for (int t = 0; t < KK; ++t) p.t[g][t * cgp + c] = live ? p.w[g][c * KK + t] * sc : 0.f;
+    float wv[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) wv[t] = live ? p.w[g][c * KK + t] : 0.f;   // all taps in flight, then the strided stores
+#pragma unroll
+    for (int t = 0; t < KK; ++t) p.t[g][t * cgp + c] = wv[t] * sc;
     if (g == 0 && p.bias_t) p.bias_t[c] = live ? p.bias[c] * sc : 0.f;
   }
 }
@@ -307,7 +312,12 @@ extern "C" int adnm_wtprep_fwd(float* const* w, float* const* s, float* bias, fl
   for (int k = 0; k <= levels; ++k) ADNM_REQUIRE(w[k] && s[k] && taps[k], "wtprep_fwd: table entry %d is null", k);
   hipStream_t st = (hipStream_t)stream;
   const int total = (int)(Cp + levels * 4 * Cp);
-  { ADNM_PROF("wt_prep_fwd", st, 8.0 * total * K * K); wt_prep_fwd_kernel<<<grid_for(total), kBlock, 0, st>>>(wt_ptrs(w, s, taps, bias, bias_t, (int)levels), (int)C, (int)Cp, (int)(K * K), (int)levels); }
+  {
+    ADNM_PROF("wt_prep_fwd", st, 8.0 * total * K * K);
+    const WtPtrs pp = wt_ptrs(w, s, taps, bias, bias_t, (int)levels);
+    if (K == 3) wt_prep_fwd_kernel<9><<<grid_for(total), kBlock, 0, st>>>(pp, (int)C, (int)Cp, (int)levels);
+    else wt_prep_fwd_kernel<25><<<grid_for(total), kBlock, 0, st>>>(pp, (int)C, (int)Cp, (int)levels);
+  }
   ADNM_CHECK_LAUNCH("wtprep_fwd");
   return ADNM_OK;
 }
