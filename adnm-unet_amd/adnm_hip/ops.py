@@ -238,12 +238,6 @@ def k_gate_bwd(dy, h, F):
     return dh
 
 
-def tap_major(w):
-    """nn.Conv2d depthwise weight (C,1,KH,KW) -> tap-major (KH*KW, C) fp32 (differentiable)."""
-    c = w.shape[0]
-    return w.reshape(c, -1).t().contiguous().float()
-
-
 # ======================================================================================= autograd
 class RowNormFn(torch.autograd.Function):
     """y = scale * ((x-mu)*rstd*w + b) + shift over the last dim (RMSNorm when mean=False)."""

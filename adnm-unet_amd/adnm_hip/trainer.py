@@ -17,6 +17,8 @@ clip_grad_norm_ (train.py:140) and torch.optim.AdamW over 669 tensors (train_unt
     cost host time.  The collective and the optimiser stay outside the graph, so learning-rate schedules and the
     adaptive clip threshold of train.py:122-130 remain ordinary host-side floats.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -37,7 +39,6 @@ class FlatTrainer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.use_graph, self.fused = use_graph, fused
         can_stage = hasattr(model, "forward_stage1") and hasattr(model, "forward_stage2") and hasattr(model, "stage1_parameters")
-        import os
         self.staged = can_stage and (os.environ.get("ADNM_STAGES", "0") == "1" if stages == "auto" else bool(stages))
         self.used = None
         self.graph = self.graph2 = None
