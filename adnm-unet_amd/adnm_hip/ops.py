@@ -238,6 +238,13 @@ def k_gate_bwd(dy, h, F):
     return dh
 
 
+def tap_major(w):
+    """nn.Conv2d depthwise weight (C,1,KH,KW) -> tap-major (KH*KW, C) fp32: the layout the parameter-prep kernels emit (used by the tests
+    to feed the raw tap-major entry points)."""
+    c = w.shape[0]
+    return w.reshape(c, -1).t().contiguous().float()
+
+
 # ======================================================================================= autograd
 class RowNormFn(torch.autograd.Function):
     """y = scale * ((x-mu)*rstd*w + b) + shift over the last dim (RMSNorm when mean=False)."""
