@@ -33,3 +33,26 @@ class enRainfallLoss(nn.Module):
 class RainfallLoss(enRainfallLoss):
     def __init__(self, omega_t=0.57, alpha=0.25):
         super().__init__(omega_t, alpha, gamma=0.0)
+
+
+class Weighted_mse_mae(nn.Module):
+    """The baselines' loss (loss.py:73-98 of the reference; ConvLSTM recipe train_untils.py:57-61) — BASELINE config 1's
+    plumbing case.  Plain torch: it is not on the hot path.  input / target: (B, S, C, H, W)."""
+
+    def __init__(self, mse_weight=1.0, mae_weight=1.0, NORMAL_LOSS_GLOBAL_SCALE=0.00005, LAMBDA=None, thresholds=[]):
+        super().__init__()
+        self.NORMAL_LOSS_GLOBAL_SCALE, self.mse_weight, self.mae_weight = NORMAL_LOSS_GLOBAL_SCALE, mse_weight, mae_weight
+        self._lambda, self.thresholds = LAMBDA, thresholds
+
+    def forward(self, input, target):
+        steps = (1, 1, 2, 5, 10, 30)   # balancing weights: +1, +3, +5, +20 as the target crosses successive thresholds
+        w = torch.full_like(input, float(steps[0]))
+        for i, th in enumerate(self.thresholds):
+            w = w + (steps[i + 1] - steps[i]) * (target >= th).to(input.dtype)
+        d = input - target
+        mse = (w * d * d).sum((2, 3, 4)).t()    # (S, B)
+        mae = (w * d.abs()).sum((2, 3, 4)).t()
+        if self._lambda is not None:            # later frames weigh more
+            ramp = (1.0 + self._lambda * torch.arange(mse.shape[0], device=mse.device, dtype=mse.dtype)).unsqueeze(1)
+            mse, mae = mse * ramp, mae * ramp
+        return self.NORMAL_LOSS_GLOBAL_SCALE * (self.mse_weight * mse.mean() + self.mae_weight * mae.mean())

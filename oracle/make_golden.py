@@ -7,6 +7,7 @@ small modules, expected outputs / gradients.  Run:  python oracle/make_golden.py
 import os
 import sys
 import json
+import re
 import numpy as np
 import torch
 
@@ -27,7 +28,16 @@ def npy(t):
     return t.detach().cpu().numpy()
 
 
+ONLY = None  # regex from --only: fixtures whose name does not match are left as they are on disk
+
+
+def wanted(name):
+    return ONLY is None or re.search(ONLY, name) is not None
+
+
 def save(name, **arrays):
+    if not wanted(name):
+        return
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **{k: (npy(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()})
     print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
@@ -36,6 +46,8 @@ def save(name, **arrays):
 def module_case(name, mod, inputs, call=None, grad_inputs=()):
     """Fill `mod` by recipe, run fwd + bwd against a recipe cotangent, save params, inputs,
     output, input grads and parameter grads."""
+    if not wanted(name):
+        return
     recipe.fill_parameters(mod)
     ins = {k: v.clone().requires_grad_(k in grad_inputs) for k, v in inputs.items()}
     out = call(mod, **ins) if call else mod(**ins)
@@ -142,58 +154,123 @@ def main():
     l1 = Ls.enRainfallLoss(0.57, 0.25, gamma=0.1)(pred, tgt)
     save("en_rainfall_loss", pred=pred, target=tgt, loss_g0=l0, grad_g0=pr.grad, loss_g01=l1)
 
-    # G9 whole model, create_ADNMUNet(5,20,6) configuration
-    manifest = None
-    for size, batch in ((64, 2), (128, 1), (256, 1)):
-        model = H.build_visionmamba(size)
-        if manifest is None:
-            # per-tensor init constant (None for randomly initialised tensors): lets the recipe rebuild
-            # the exact state_dict from this manifest alone, with no model object
-            consts = {}
-            for k, v in model.state_dict().items():
-                f = v.double().flatten()
-                consts[k] = float(f[0]) if bool((f == f[0]).all()) else None
+    # G9 whole model, create_ADNMUNet(5,20,6) configuration (+ config 4's 10->40 at 256x256, + the benchmarked B=4 batch)
+    if wanted("state_dict_manifest"):
+        model = H.build_visionmamba(64)
+        consts = {}
+        for k, v in model.state_dict().items():   # per-tensor init constant (None for randomly initialised tensors): lets the
+            f = v.double().flatten()              # recipe rebuild the exact state_dict from this manifest alone
+            consts[k] = float(f[0]) if bool((f == f[0]).all()) else None
         recipe.fill_parameters(model)
-        if manifest is None:
-            trainable = {k: p.requires_grad for k, p in model.named_parameters()}
-            manifest = {k: {"shape": list(v.shape), "const": consts[k], "trainable": bool(trainable[k]),
-                            "sum": float(v.double().sum()), "abs": float(v.double().abs().sum())}
-                        for k, v in model.state_dict().items()}
-            with open(os.path.join(OUT, "state_dict_manifest.json"), "w") as f:
-                json.dump(manifest, f, separators=(",", ":"))
-        frames = recipe.radar_batch(batch, 25, size, name=f"radar{size}")
-        x, tgt = frames[:, :5], frames[:, 5:]
-        taps = {}
-        hooks = [model.encoder.register_forward_hook(lambda m, i, o: taps.__setitem__("encoder", o[0])),
-                 model.decoder.register_forward_hook(lambda m, i, o: taps.__setitem__("decoder", o)),
-                 model.refiner.refiner4.register_forward_hook(lambda m, i, o: taps.__setitem__("refiner4", o))]
-        out = model(x)
-        loss = Ls.enRainfallLoss(0.57, 0.25, gamma=0.0)(out, tgt)
-        loss.backward()
-        for h in hooks:
-            h.remove()
-        names = [k for k, _ in model.named_parameters()]
-        gnorm = np.array([float(p.grad.double().norm()) if p.grad is not None else -1.0 for _, p in model.named_parameters()])
-        total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
-        flat = out.flatten()
-        idx = torch.from_numpy((recipe.uniform01(f"sample{size}", 4096) * flat.numel()).astype(np.int64))
-        arrays = dict(out_idx=idx, out_samples=flat[idx], out_norm=out.double().norm(), out_mean=out.double().mean(),
-                      loss=loss, grad_total_norm=total, grad_norms=gnorm, names=np.array(names))
-        for k, v in taps.items():
-            fl = v.flatten()
-            ii = torch.from_numpy((recipe.uniform01(f"tap{k}{size}", 1024) * fl.numel()).astype(np.int64))
-            arrays[f"tap.{k}.idx"], arrays[f"tap.{k}.val"], arrays[f"tap.{k}.norm"] = ii, fl[ii], v.double().norm()
-        if size == 64:
-            arrays["out_full"] = out
-        # one AdamW step with train.py's recipe (train_untils.py:35-42, train.py:140 clip at norm_max 0.025)
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2)
-        pre = torch.nn.utils.clip_grad_norm_(model.parameters(), 0.025)
-        opt.step()
-        arrays["clip_pre_norm"] = pre
-        arrays["param_sum_after_step"] = np.array([float(p.double().sum()) for _, p in model.named_parameters()])
-        save(f"visionmamba_{size}_b{batch}", **arrays)
+        trainable = {k: p.requires_grad for k, p in model.named_parameters()}
+        manifest = {k: {"shape": list(v.shape), "const": consts[k], "trainable": bool(trainable[k]),
+                        "sum": float(v.double().sum()), "abs": float(v.double().abs().sum())}
+                    for k, v in model.state_dict().items()}
+        with open(os.path.join(OUT, "state_dict_manifest.json"), "w") as f:
+            json.dump(manifest, f, separators=(",", ":"))
         del model
+    whole_model_case("visionmamba_64_b2", 64, 2, radar="radar64", full_out=True)
+    whole_model_case("visionmamba_128_b1", 128, 1, radar="radar128")
+    whole_model_case("visionmamba_256_b1", 256, 1, radar="radar256")
+    # round 2: the exact benchmarked workload (bench.py: B=4, radar_batch(name="bench", salt=rank 0)), BASELINE config 2's shape
+    whole_model_case("visionmamba_128_b4", 128, 4, radar="bench", deltas=True)
+    # round 2: BASELINE config 4 (10 -> 40 frames, 256x256): channels=10, out_channels=40 (ADNMUNet.py:906-940)
+    whole_model_case("visionmamba_256_10to40_b1", 256, 1, radar="radar256x", cin=10, cout=40, deltas=True)
+    convlstm_case()
+
+
+def whole_model_case(name, size, batch, radar, cin=5, cout=20, full_out=False, deltas=False):
+    if not wanted(name):
+        return
+    ref = H.load_reference()
+    Ls = ref.loss
+    model = H.build_visionmamba(size, channels=cin, out_channels=cout)
+    recipe.fill_parameters(model)
+    frames = recipe.radar_batch(batch, cin + cout, size, name=radar)
+    x, tgt = frames[:, :cin], frames[:, cin:]
+    taps = {}
+    hooks = [model.encoder.register_forward_hook(lambda m, i, o: taps.__setitem__("encoder", o[0])),
+             model.decoder.register_forward_hook(lambda m, i, o: taps.__setitem__("decoder", o)),
+             model.refiner.refiner4.register_forward_hook(lambda m, i, o: taps.__setitem__("refiner4", o))]
+    out = model(x)
+    loss = Ls.enRainfallLoss(0.57, 0.25, gamma=0.0)(out, tgt)
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    names = [k for k, _ in model.named_parameters()]
+    gnorm = np.array([float(p.grad.double().norm()) if p.grad is not None else -1.0 for _, p in model.named_parameters()])
+    total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
+    flat = out.flatten()
+    idx = torch.from_numpy((recipe.uniform01(f"sample{name if deltas else size}", 4096) * flat.numel()).astype(np.int64))
+    arrays = dict(out_idx=idx, out_samples=flat[idx], out_norm=out.double().norm(), out_mean=out.double().mean(),
+                  loss=loss, grad_total_norm=total, grad_norms=gnorm, names=np.array(names))
+    for k, v in taps.items():
+        fl = v.flatten()
+        ii = torch.from_numpy((recipe.uniform01(f"tap{k}{name if deltas else size}", 1024) * fl.numel()).astype(np.int64))
+        arrays[f"tap.{k}.idx"], arrays[f"tap.{k}.val"], arrays[f"tap.{k}.norm"] = ii, fl[ii], v.double().norm()
+    if full_out:
+        arrays["out_full"] = out
+    if deltas:
+        # gradient DIRECTIONS, not only norms: the projection of every parameter gradient on a recipe probe vector
+        arrays["grad_probe"] = np.array([float((p.grad.double().flatten() * torch.from_numpy(recipe.sym("probe." + k, p.numel()))).sum())
+                                         if p.grad is not None else 0.0 for k, p in model.named_parameters()])
+        before = [p.detach().double().clone() for p in model.parameters()]
+    # one AdamW step with train.py's recipe (train_untils.py:35-42, train.py:140 clip at norm_max 0.025)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2)
+    pre = torch.nn.utils.clip_grad_norm_(model.parameters(), 0.025)
+    opt.step()
+    arrays["clip_pre_norm"] = pre
+    arrays["param_sum_after_step"] = np.array([float(p.double().sum()) for _, p in model.named_parameters()])
+    if deltas:
+        # per-parameter update (p_after - p_before): its sum, and every element of the <= 8-element tensors (the 360 scalars)
+        d = [p.detach().double() - b for p, b in zip(model.parameters(), before)]
+        arrays["delta_sum"] = np.array([float(t.sum()) for t in d])
+        arrays["delta_abs"] = np.array([float(t.abs().sum()) for t in d])
+        small = [t.flatten() for t in d if t.numel() <= 8]
+        arrays["delta_small"] = torch.cat(small)
+        arrays["delta_small_sizes"] = np.array([t.numel() for t in small])
+    save(name, **arrays)
+    del model
+
+
+def convlstm_case():
+    """BASELINE config 1 (plumbing): the reference's ConvLSTM encoder-forecaster, 5 -> 5 frames, batch 2, on the CPU
+    (ConvLSTM.py:219-256; it only accepts 256x256 input, its first state grid is the 64x64 of :219)."""
+    name = "convlstm_5to5_b2"
+    if not wanted(name):
+        return
+    import importlib
+    H.load_reference()
+    saved = list(sys.path)
+    sys.path.insert(0, H.REF_ROOT)
+    try:
+        C = importlib.import_module("models.ConvLSTM")
+    finally:
+        sys.path[:] = saved
+        for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+            sys.modules["_adnm_ref_" + k] = sys.modules.pop(k)
+    ref = H.load_reference()
+    model = C.create_ConvLSTM(5)
+    recipe.fill_parameters(model)
+    frames = recipe.radar_batch(2, 10, 256, name="convlstm")
+    x, tgt = frames[:, :5], frames[:, 5:]
+    out = model(x)
+    crit = ref.loss.Weighted_mse_mae(thresholds=[20, 30, 35, 40])   # train_untils.py:25,61 (Shanghai thresholds)
+    loss = crit(out, tgt)
+    loss.backward()
+    names = [k for k, _ in model.named_parameters()]
+    gnorm = np.array([float(p.grad.double().norm()) if p.grad is not None else -1.0 for _, p in model.named_parameters()])
+    flat = out.flatten()
+    idx = torch.from_numpy((recipe.uniform01("convlstm.sample", 4096) * flat.numel()).astype(np.int64))
+    shapes = {k: list(v.shape) for k, v in model.state_dict().items()}
+    save(name, out_idx=idx, out_samples=flat[idx], out_norm=out.double().norm(), loss=loss, grad_norms=gnorm, names=np.array(names),
+         state_keys=np.array(list(shapes)), state_shapes=np.array([str(v) for v in shapes.values()]),
+         n_params=np.array(sum(p.numel() for p in model.parameters())))
 
 
 if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None, help="regex: regenerate only the fixtures whose name matches")
+    ONLY = ap.parse_args().only
     main()

@@ -29,25 +29,42 @@ def test_manifest_recipe_roundtrip():
             assert abs(float(v.double().sum()) - m[k]["sum"]) <= 1e-6 * max(1.0, m[k]["abs"]), k
 
 
-CASES = [(64, 2)] + ([(128, 1), (256, 1)] if os.environ.get("ADNM_SLOW") else [])
+# (fixture, size, batch, T_in, T_out, radar recipe name); the slow ones run when ADNM_SLOW=1 (they were run when the fixtures were made)
+CASES = [("visionmamba_64_b2", 64, 2, 5, 20, "radar64")] + ([
+    ("visionmamba_128_b1", 128, 1, 5, 20, "radar128"), ("visionmamba_256_b1", 256, 1, 5, 20, "radar256"),
+    ("visionmamba_128_b4", 128, 4, 5, 20, "bench"),                     # the benchmarked workload (BASELINE config 2's shape)
+    ("visionmamba_256_10to40_b1", 256, 1, 10, 40, "radar256x"),         # BASELINE config 4's model
+] if os.environ.get("ADNM_SLOW") else [])
 
 
-@pytest.mark.parametrize("size,batch", CASES)
-def test_visionmamba(size, batch):
-    m = manifest()
-    z = load_npz(f"visionmamba_{size}_b{batch}")
-    sd = recipe.state_dict_from_manifest(m)
+def recipe_state(cin, cout):
+    """Recipe-filled fp64 state_dict + trainable flags: from the manifest for 5->20, from this package's own constructor
+    (same 992 keys, other shapes at the two ends) for other frame counts."""
+    if (cin, cout) == (5, 20):
+        m = manifest()
+        return {k: v.double() for k, v in recipe.state_dict_from_manifest(m).items()}, {k: m[k]["trainable"] for k in m}
+    from models.ADNMUNet import create_ADNMUNet
+    model = create_ADNMUNet(cin, cout, 6)
+    recipe.fill_parameters(model)
+    train = {k: False for k in model.state_dict()}
+    train.update({k: p.requires_grad for k, p in model.named_parameters()})
+    return {k: v.detach().double() for k, v in model.state_dict().items()}, train
+
+
+@pytest.mark.parametrize("name,size,batch,cin,cout,radar", CASES)
+def test_visionmamba(name, size, batch, cin, cout, radar):
+    z = load_npz(name)
+    sd, trainable = recipe_state(cin, cout)
     names = [str(n) for n in z["names"]]
     # fp64 oracle: leaves only the reference's own fp32 round-off in the comparison
-    sd = {k: v.double() for k, v in sd.items()}
-    params = {k: sd[k].clone().requires_grad_(True) for k in names if m[k]["trainable"]}
+    params = {k: sd[k].clone().requires_grad_(True) for k in names if trainable[k]}
     full = dict(sd)
     full.update(params)
-    frames = recipe.radar_batch(batch, 25, size, name=f"radar{size}")
-    x, tgt = frames[:, :5].double(), frames[:, 5:].double()
+    frames = recipe.radar_batch(batch, cin + cout, size, name=radar)
+    x, tgt = frames[:, :cin].double(), frames[:, cin:].double()
     taps = {}
     out = O.vision_mamba(full, x, taps=taps)
-    assert out.shape == (batch, 20, 1, size, size)
+    assert out.shape == (batch, cout, 1, size, size)
     assert_close(out.flatten()[z["out_idx"]], z["out_samples"], 5e-5, "output samples")
     assert abs(float(out.double().norm()) - float(z["out_norm"])) <= 5e-5 * float(z["out_norm"])
     for k in ("encoder", "decoder", "refiner4"):
@@ -61,7 +78,7 @@ def test_visionmamba(size, batch):
     gtot = float(z["grad_total_norm"])
     sq = 0.0
     for i, k in enumerate(names):
-        if not m[k]["trainable"]:
+        if not trainable[k]:
             continue
         g = params[k].grad
         if gn[i] < 0:  # the reference leaves .grad = None (307 tensors)
@@ -73,9 +90,15 @@ def test_visionmamba(size, batch):
         # scalar parameters' gradients are cancelling sums over whole feature maps: their fp32
         # round-off in the reference scales with the total gradient norm, not with their own value
         assert abs(n - gn[i]) <= 2e-3 * gn[i] + 2e-4 * gtot, f"{k}: grad norm {n} vs {gn[i]}"
+        if "grad_probe" in z:   # direction, not only length: projection on a recipe probe vector
+            pr = float((g.double().flatten() * torch.from_numpy(recipe.sym("probe." + k, g.numel()))).sum())
+            ref = float(z["grad_probe"][i])
+            # a random projection of an error vector d has size ~|d|/sqrt(3): 5e-3*|g| is ~4 sigma of the 2e-3 norm tolerance, while a
+            # sign-flipped gradient is off by ~2*|g|/sqrt(3)
+            assert abs(pr - ref) <= 5e-3 * gn[i] + 2e-4 * gtot, f"{k}: grad probe {pr} vs {ref}"
     total = sq ** 0.5
     assert abs(total - float(z["grad_total_norm"])) <= 1e-3 * float(z["grad_total_norm"])
-    assert int((gn < 0).sum()) - sum(1 for k in names if not m[k]["trainable"]) == 307
+    assert int((gn < 0).sum()) - sum(1 for k in names if not trainable[k]) == 307
 
 
 def test_skip_dead_is_identical():

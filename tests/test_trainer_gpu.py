@@ -82,3 +82,27 @@ def test_whole_model_step_vs_reference_fixture(use_graph, stages):
             assert torch.equal(p, before[k]), k
     # state_dict still has the reference's logical shapes (conv weights are channels-last views of the flat buffer)
     assert model.state_dict()["refiner.out_proj.conv.0.conv.weight"].shape == (64, 32, 3, 3)
+
+
+def test_benchmarked_workload_step_vs_reference_fixture():
+    """The exact workload bench.py times (B=4, 128x128, 5->20, recipe batch "bench", hipGraph replay, fused clip + AdamW): loss,
+    pre-clip norm and the UPDATE of every parameter (p_after - p_before; element-wise for the 360 scalar mixes) against what the
+    reference produced for the same batch (fixture visionmamba_128_b4, oracle/make_golden.py)."""
+    from models.ADNMUNet import create_ADNMUNet
+    from models.loss import enRainfallLoss
+    from util import load_npz, check_update_deltas
+    z = load_npz("visionmamba_128_b4")
+    model = create_ADNMUNet(5, 20, 6, img_size=128)
+    recipe.fill_parameters(model)
+    model = model.to(DEV).train()
+    frames = recipe.radar_batch(4, 25, 128, name="bench").to(DEV)
+    x, tgt = frames[:, :5].contiguous(), frames[:, 5:].contiguous()
+    tr = FlatTrainer(model, enRainfallLoss(0.57, 0.25, gamma=0.0), lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2, max_norm=0.025,
+                     use_graph=True)
+    before = [p.detach().double().clone() for p in model.parameters()]
+    loss = tr.step(x, tgt)
+    assert abs(float(loss) - float(z["loss"])) <= 1e-4 * abs(float(z["loss"]))
+    assert abs(float(tr.grad_norm()) - float(z["clip_pre_norm"])) <= 1e-3 * float(z["clip_pre_norm"])
+    names = [str(n) for n in z["names"]]
+    assert names == [k for k, _ in model.named_parameters()]
+    check_update_deltas(z, names, [p.detach().double() - b for p, b in zip(model.parameters(), before)])

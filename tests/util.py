@@ -33,3 +33,24 @@ def assert_close(a, b, tol, what="", atol=0.0):
     err = float((a - b).norm())
     bound = tol * float(b.norm()) + atol * (b.numel() ** 0.5)
     assert err <= bound, f"{what}: |err| {err:.3e} > {bound:.3e} (rel-L2 {err / (float(b.norm()) + 1e-30):.3e}, tol {tol:.1e})"
+
+
+def check_update_deltas(z, names, deltas, lr=1e-3):
+    """The update itself, p_after - p_before, against the reference's: the first AdamW step moves every element by
+    -lr * g / (|g| + eps) - lr * wd * p, i.e. by ~lr in the direction of -sign(g).  Small tensors (<= 8 elements: the 360
+    scalar mixes) are compared element by element; large ones by the sum and the absolute sum of the update, where only
+    elements whose gradient is ~0 (|g| ~ eps = 1e-9 after clipping) may differ."""
+    small = iter(torch.split(z["delta_small"].double(), [int(n) for n in z["delta_small_sizes"]]))
+    for i, (k, d) in enumerate(zip(names, deltas)):
+        n = d.numel()
+        d = d.flatten().cpu()
+        if n <= 8:
+            ref = next(small)
+            if float(z["grad_norms"][i]) < 0:
+                assert float(d.abs().max()) == 0.0, f"{k}: a parameter without gradient must not move"
+                continue
+            # a fully fledged step is lr; allow 2 % of it (|g| is never near eps for the live scalars)
+            assert float((d - ref).abs().max()) <= 0.02 * lr, f"{k}: update {d.tolist()} vs reference {ref.tolist()}"
+        else:
+            assert abs(float(d.abs().sum()) - float(z["delta_abs"][i])) <= 0.01 * lr * n + 1e-12, f"{k}: |update| sum"
+            assert abs(float(d.sum()) - float(z["delta_sum"][i])) <= 0.02 * lr * n ** 0.5 + 0.002 * lr * n, f"{k}: update sum"
