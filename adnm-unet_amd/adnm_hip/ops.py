@@ -5,6 +5,8 @@ torch's caching allocator only, so a whole training step is hipGraph-capturable.
 Layout convention: token tensors are (B, L, C) / (M, C) channels-last; a "row view" is a 2-D
 tensor with stride (ld, 1) — kernels take the row stride, so column slices of wide buffers are
 passed without copies."""
+import threading
+
 import torch
 
 from . import lib
@@ -47,25 +49,56 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
-# Gradient destinations: FlatTrainer registers, for every parameter (keyed by data_ptr), the slice of its flat gradient buffer.
-# Backward functions that allocate a parameter gradient themselves take that slice instead of fresh memory, so the value is
-# born in place and the trainer's gather copy for it disappears.  A second claim of the same slice inside one backward pass
-# (a weight used by two autograd nodes) gets fresh memory: autograd then adds the two as usual.
-GRAD_DST = {}
-GRAD_DST_OWNER = [0]
-_GRAD_CLAIMED = set()
+class GradRegistry:
+    """Gradient destinations.  A FlatTrainer registers, for every parameter (keyed by data_ptr — device pointers are unique
+    across the GPUs of a process), the slice of ITS flat gradient buffer.  Backward functions that allocate a parameter gradient
+    themselves take that slice instead of fresh memory, so the value is born in place and the trainer's gather copy for it
+    disappears.  A second claim of the same slice inside one backward pass (a weight used by two autograd nodes) gets fresh
+    memory: autograd then adds the two as usual.
 
+    State is per owner (= per trainer, hence per device / per replica) and guarded by a lock: autograd runs backward on its own
+    engine threads, one per device, so under the reference's nn.DataParallel flow (train.py:99-102) several threads come
+    through here at once and must not see each other's claims."""
 
-def grad_claims_reset():
-    _GRAD_CLAIMED.clear()
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._dst = {}       # data_ptr -> (owner id, view into the owner's flat gradient buffer)
+        self._claimed = {}   # owner id -> set of data_ptrs claimed in the running backward pass
 
+    def register(self, owner, mapping):
+        with self._lock:
+            self.drop(owner, locked=True)
+            for ptr, view in mapping.items():
+                self._dst[ptr] = (owner, view)
+            self._claimed[owner] = set()
 
-def grad_dst(ptr, shape, device, dtype=torch.float32):
-    g = GRAD_DST.get(ptr)
-    if g is None or ptr in _GRAD_CLAIMED or tuple(g.shape) != tuple(shape) or g.dtype != dtype:
+    def drop(self, owner, locked=False):
+        if not locked:
+            with self._lock:
+                return self.drop(owner, locked=True)
+        for ptr in [k for k, (o, _) in self._dst.items() if o == owner]:
+            del self._dst[ptr]
+        self._claimed.pop(owner, None)
+
+    def reset_claims(self, owner):
+        with self._lock:
+            if owner in self._claimed:
+                self._claimed[owner].clear()
+
+    def take(self, ptr, shape, device, dtype=torch.float32):
+        with self._lock:
+            ent = self._dst.get(ptr)
+            if ent is not None:
+                owner, g = ent
+                if ptr not in self._claimed[owner] and tuple(g.shape) == tuple(shape) and g.dtype == dtype:
+                    self._claimed[owner].add(ptr)
+                    # a fresh tensor object on the same memory: AccumulateGrad only keeps ("steals") a gradient nobody else references
+                    return g.detach()
         return torch.empty(tuple(shape), dtype=dtype, device=device)
-    _GRAD_CLAIMED.add(ptr)
-    return g.detach()   # a fresh tensor object on the same memory: AccumulateGrad only keeps ("steals") a gradient nobody else references
+
+
+GRADS = GradRegistry()
+grad_dst = GRADS.take
 
 
 def _need_gpu(t):

@@ -1,24 +1,27 @@
 """The training step around the hot path, MI355X-style:
 
-    [hipGraph replay]  forward -> loss -> backward -> gather gradients into ONE flat fp32 buffer
-    [RCCL]             all-reduce(AVG) of that flat buffer over xGMI            (world > 1 only)
+    [hipGraph A]   forward -> loss -> backward of the LATE stage (refiner + decoder)  -> its gradients land in flat_g[0:n_late]
+    [RCCL]         all-reduce of flat_g[0:n_late] on RCCL's stream over xGMI ..........  runs beside:
+    [hipGraph B]   backward of the EARLY stage (encoder)                               -> flat_g[n_late:n]
+    [RCCL]         all-reduce of flat_g[n_late:n]
     [3 HIP launches]   global grad-norm, clip_grad_norm_ scaling, AdamW on flat p / g / m / v
 
 replacing the reference's nn.DataParallel scatter/replicate/gather (train.py:99-102), its per-tensor
-clip_grad_norm_ (train.py:140) and torch.optim.AdamW over 669 tensors (train_untils.py:35-42).
+clip_grad_norm_ (train.py:140) and torch.optim.AdamW over 669 tensors (train_untils.py:35-42).  On one GPU (or with
+overlap=False) graphs A and B are ONE graph and there is one bucket.
 
   * Parameters that receive gradients are re-homed as views into one flat buffer (state_dict unchanged), so the
-    optimiser is a single streaming kernel and the gradient collective is ONE large message — the right shape for
-    xGMI rings (few, large transfers).  The 307 parameters the reference never gives a gradient (e2ds[3..6], att1..4,
-    ...) are discovered by a dry-run backward and left out: they are never decayed nor updated, exactly like
-    torch.optim.AdamW skipping p.grad is None.
-  * The whole fwd+bwd is captured once as a hipGraph (our kernels are enqueued through ctypes on torch's capture
-    stream; all memory comes from torch's graph-private pool) and replayed: the ~3.5k launches of a step no longer
-    cost host time.  The collective and the optimiser stay outside the graph, so learning-rate schedules and the
-    adaptive clip threshold of train.py:122-130 remain ordinary host-side floats.
+    optimiser is a single streaming kernel and the gradient collective is a few LARGE messages in reverse execution order
+    (refiner -> decoder -> encoder) — the right shape for xGMI rings.  The 307 parameters the reference never
+    gives a gradient (e2ds[3..6], att1..4, ...) are discovered by a dry-run backward and left out: they are never decayed nor
+    updated, exactly like torch.optim.AdamW skipping p.grad is None.
+  * fwd+bwd is captured once as hipGraphs (our kernels are enqueued through ctypes on torch's capture stream; all memory
+    comes from torch's graph-private pool) and replayed.  The collectives and the optimiser stay outside the graphs, so
+    learning-rate schedules and the adaptive clip threshold of train.py:122-130 remain ordinary host-side floats, and the
+    collectives are plain torch.distributed calls between graph launches (nothing RCCL-specific is captured).
+  * reduce_dtype="bf16": the wire format of the collective is bf16 (146 MB instead of 292 MB); sums are formed by RCCL in
+    bf16, the 1/world average and the return to fp32 happen in one HIP pass.
 """
-import os
-
 import torch
 import torch.distributed as dist
 
@@ -27,26 +30,29 @@ from . import lib, ops
 
 class FlatTrainer:
     def __init__(self, model, loss_fn, lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2, max_norm=0.0,
-                 process_group=None, use_graph=True, fused=True, stages="auto"):
-        """stages: two-stage backward cut at model.forward_stage1 / forward_stage2 (ADNM-UNet: encoder | decoder + refiner), so that
-        the second stage's gradients are all-reduced while the first stage's backward still runs.  True / False force it; "auto"
-        reads ADNM_STAGES (default off).  Measured on one MI355X: the two captured graphs cost 14.0 ms of GPU time against 12.95 ms
-        for the single graph (stalls inside the second replay), while the encoder's backward — the window that hides the ring — is
-        only 2.4 ms long, so the cut pays at 2 ranks (xGMI: one link, ~3.7 ms ring) and not at 8 (~0.9 ms); hence opt-in."""
+                 process_group=None, use_graph=True, fused=True, overlap="auto", reduce_dtype="f32", stages=None):
+        """overlap: cut the backward at model.forward_stage1 / forward_stage2 (ADNM-UNet: encoder | decoder + refiner) and all-reduce
+        the late stage's gradients while the early stage's backward runs.  "auto" = whenever there is more than one rank.
+        `stages` is the older name of the same switch (True / False)."""
         self.model, self.loss_fn = model, loss_fn
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.use_graph, self.fused = use_graph, fused
+        if stages is not None:
+            overlap = bool(stages) if stages != "auto" else "auto"
         can_stage = hasattr(model, "forward_stage1") and hasattr(model, "forward_stage2") and hasattr(model, "stage1_parameters")
-        self.staged = can_stage and (os.environ.get("ADNM_STAGES", "0") == "1" if stages == "auto" else bool(stages))
+        self.staged = can_stage and (self.world > 1 if overlap == "auto" else bool(overlap))
+        assert reduce_dtype in ("f32", "bf16")
+        self.reduce_dtype = reduce_dtype
         self.used = None
         self.graph = self.graph2 = None
+        self.buckets = []
         self._steps = 0
 
     # ------------------------------------------------------------------ one-time setup
     def _fwd_bwd(self, x, tgt):
-        ops.grad_claims_reset()
+        ops.GRADS.reset_claims(id(self))
         out = self.model(x)
         loss = self.loss_fn(out, tgt)
         loss.backward()
@@ -55,7 +61,8 @@ class FlatTrainer:
     @torch.no_grad()
     def _flatten(self):
         used = [p for p in self.model.parameters() if p.requires_grad and p.grad is not None]
-        if self.staged:   # flat layout [stage-2 (late) parameters | stage-1 (early) parameters]: each stage's gradients are one range
+        self.late, self.early = used, []
+        if self.staged:   # flat layout [late-stage parameters | early-stage parameters]: each stage's gradients are one range
             first = {id(p) for p in self.model.stage1_parameters()}
             self.late = [p for p in used if id(p) not in first]
             self.early = [p for p in used if id(p) in first]
@@ -71,10 +78,10 @@ class FlatTrainer:
         self.exp_avg_sq = torch.zeros(total, dtype=dt, device=dev)
         self.state = torch.zeros(4, dtype=torch.float32, device=dev)
         self.g_views = []
+
         def shaped(flat, o, p):
             """view of the flat slice with p's logical shape.  Dense conv weights (Cout, Cin>1, kh, kw) get channels-last strides:
-            MIOpen's NHWC kernels then read them (and write their gradients) as they lie, instead of re-laying them out in a
-            copy kernel on every call (13 convs x 3 passes per step)."""
+            the NHWC conv kernels then read them (and write their gradients) as they lie."""
             t = flat[o:o + p.numel()]
             if p.dim() == 4 and p.shape[1] > 1 and p.is_cuda:
                 co, ci, kh, kw = p.shape
@@ -88,17 +95,18 @@ class FlatTrainer:
             p.grad = None
         self.used, self.n = used, total
         self.n_late = offs[len(self.late)] if self.staged and self.early else total
-        # backward functions that allocate parameter gradients write them straight into these slices (ops.grad_dst)
-        ops.GRAD_DST.clear()
-        ops.GRAD_DST.update({p.data_ptr(): gv for p, gv in zip(used, self.g_views)})
-        ops.GRAD_DST_OWNER[0] = id(self)
+        # gradient buckets in the order they become ready (= the order they are all-reduced)
+        self.buckets = [(0, self.n_late)] + ([(self.n_late, total)] if self.n_late < total else [])
+        if self.world > 1 and self.reduce_dtype == "bf16":
+            self.comm = torch.empty(total, dtype=torch.bfloat16, device=dev)
+        # backward functions that allocate parameter gradients write them straight into these slices (ops.GRADS)
+        ops.GRADS.register(id(self), {p.data_ptr(): gv for p, gv in zip(used, self.g_views)})
         if self.fused:
             self.ws = torch.empty(int(lib.query("adnm_adamw_ws_bytes")), dtype=torch.uint8, device=dev)
 
     def __del__(self):
         try:
-            if ops.GRAD_DST_OWNER[0] == id(self):   # do not leave destinations of a dead trainer behind
-                ops.GRAD_DST.clear()
+            ops.GRADS.drop(id(self))   # do not leave destinations of a dead trainer behind
         except Exception:
             pass
 
@@ -109,12 +117,12 @@ class FlatTrainer:
         if pairs:
             torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
 
-    # two-stage backward: A = forward + backward of stage 2 (down to the cut), B = backward of stage 1
+    # two-stage backward: A = forward + backward of the late stage (down to the cut), B = backward of the early stage
     def _stage_a(self, x, tgt):
-        ops.grad_claims_reset()
+        ops.GRADS.reset_claims(id(self))
         cut = self.model.forward_stage1(x)
-        # a true cut: stage 2 runs on detached twins, so stage A's backward stops there (a skip tensor also reaches the loss THROUGH the
-        # rest of the encoder; that path belongs to stage B, which starts from the originals with the twins' gradients)
+        # a true cut: the late stage runs on detached twins, so stage A's backward stops there (a skip tensor also reaches the loss
+        # THROUGH the rest of the encoder; that path belongs to stage B, which starts from the originals with the twins' gradients)
         twins, origs, args = {}, [], []
         for t in cut:
             if torch.is_tensor(t) and t.requires_grad:
@@ -141,7 +149,7 @@ class FlatTrainer:
         self._gather(len(self.late), len(self.used))
 
     def prepare(self, x, tgt):
-        """Dry-run backward (finds the parameters that receive gradients), flatten, and capture the graph."""
+        """Dry-run backward (finds the parameters that receive gradients), flatten, and capture the graph(s)."""
         self.model.zero_grad(set_to_none=True)
         self._fwd_bwd(x, tgt)
         self._flatten()
@@ -183,48 +191,70 @@ class FlatTrainer:
         self._stage_b()
         return loss
 
+    # ------------------------------------------------------------------ the collective
+    def _cast(self, src, dst, scale=1.0):
+        """fp32 <-> bf16 copy of a gradient range (HIP pass on the GPU; torch on the CPU test path)."""
+        if self.fused and src.is_cuda:
+            name = "adnm_cast_f32_bf16" if src.dtype == torch.float32 else "adnm_cast_bf16_f32"
+            lib.call(name, src.data_ptr(), dst.data_ptr(), src.numel(), float(scale), torch.cuda.current_stream().cuda_stream)
+        else:
+            dst.copy_(src.to(dst.dtype) if scale == 1.0 else (src.float() * scale).to(dst.dtype))
+
+    def _reduce_begin(self, lo, hi, pending):
+        """Start averaging flat_g[lo:hi] over the ranks.  RCCL: asynchronously on its own stream (it first waits for what the
+        compute stream has enqueued so far, i.e. the graph that produced the range), so the next graph runs beside the ring."""
+        if self.world == 1 or hi <= lo:
+            return
+        nccl = dist.get_backend(self.group) == "nccl"
+        if self.reduce_dtype == "bf16":
+            t = self.comm[lo:hi]
+            self._cast(self.flat_g[lo:hi], t)
+            op = dist.ReduceOp.SUM
+        else:
+            t = self.flat_g[lo:hi]
+            op = dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM
+        work = dist.all_reduce(t, op=op, group=self.group, async_op=True)
+        pending.append((work, lo, hi, nccl))
+
+    def _reduce_end(self, pending):
+        for work, lo, hi, nccl in pending:
+            work.wait()   # the compute stream waits for the ring; the host does not block (RCCL)
+            if self.reduce_dtype == "bf16":
+                self._cast(self.comm[lo:hi], self.flat_g[lo:hi], 1.0 / self.world)
+            elif not nccl:
+                self.flat_g[lo:hi].div_(self.world)
+
     # ------------------------------------------------------------------ per step
-    def step(self, x, tgt):
+    def step(self, x, tgt, eager=False):
+        """One training step.  eager=True launches the same work without the captured graphs (bench.py's instrumented steps:
+        per-launch HIP events cannot be recorded inside a graph replay)."""
         if self.used is None:
             self.prepare(x, tgt)
-        nccl = self.world > 1 and dist.get_backend(self.group) == "nccl"
-        works = []
-
-        def reduce(lo, hi):
-            """average flat_g[lo:hi] over the ranks; RCCL: asynchronously on its own stream (it first waits for what this stream has
-            enqueued so far, i.e. the stage that produced the range), so the next stage's kernels run beside the ring"""
-            if self.world == 1 or hi <= lo:
-                return
-            t = self.flat_g[lo:hi]
-            if nccl:
-                works.append(dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
-            else:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-                t.div_(self.world)
-
-        if self.graph is not None:
+        pending = []
+        if self.graph is not None and not eager:
             if x.data_ptr() != self.sx.data_ptr():
                 self.sx.copy_(x, non_blocking=True)
                 self.st.copy_(tgt, non_blocking=True)
             self.graph.replay()
+            self._reduce_begin(*self.buckets[0], pending)
             if self.staged:
-                reduce(0, self.n_late)
                 self.graph2.replay()
-                reduce(self.n_late, self.n)
-            else:
-                reduce(0, self.n)
+                if len(self.buckets) > 1:
+                    self._reduce_begin(*self.buckets[1], pending)
             loss = self.static_loss
         else:
-            if self.staged:
-                loss = self._run_eager(x, tgt, between=lambda: reduce(0, self.n_late))
-                reduce(self.n_late, self.n)
-            else:
-                loss = self._run_eager(x, tgt)
-                reduce(0, self.n)
             for p in self.used:
                 p.grad = None
-        for w in works:
-            w.wait()   # the compute stream waits for the rings; the host does not block
+            if self.staged:
+                loss = self._run_eager(x, tgt, between=lambda: self._reduce_begin(*self.buckets[0], pending))
+                if len(self.buckets) > 1:
+                    self._reduce_begin(*self.buckets[1], pending)
+            else:
+                loss = self._run_eager(x, tgt)
+                self._reduce_begin(*self.buckets[0], pending)
+            for p in self.used:
+                p.grad = None
+        self._reduce_end(pending)
         self._optimizer_step()
         self._steps += 1
         return loss

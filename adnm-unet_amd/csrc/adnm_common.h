@@ -48,6 +48,30 @@ void adnm_launch_fold(const char* prof_name, const float* part, int rows, int n,
     }                                                                        \
   } while (0)
 
+// More than 64 KB of dynamic LDS needs hipFuncSetAttribute on the function — per DEVICE (HIP keeps function attributes per
+// device, and the reference's nn.DataParallel flow, train.py:99-102, drives several devices from one process).  `done` is the
+// call site's own bitmask of devices already opted in; setting the attribute twice is harmless, so a race only repeats the call.
+#include <atomic>
+static inline int adnm_allow_lds(const void* fn, size_t smem, std::atomic<uint64_t>& done, const char* name) {
+  if (smem <= 64 * 1024) return ADNM_OK;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_relaxed) & bit) return ADNM_OK;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) {
+    adnm_set_error("%s: cannot raise the dynamic LDS limit to %zu bytes on device %d: %s", name, smem, dev, hipGetErrorString(e));
+    return ADNM_ELAUNCH;
+  }
+  done.fetch_or(bit, std::memory_order_relaxed);
+  return ADNM_OK;
+}
+#define ADNM_ALLOW_LDS(kernel, smem, name)                                             \
+  do {                                                                                 \
+    static std::atomic<uint64_t> lds_done__{0};                                        \
+    if (int rc__ = adnm_allow_lds((const void*)(kernel), (smem), lds_done__, name)) return rc__; \
+  } while (0)
+
 static inline int64_t adnm_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t adnm_align(int64_t a, int64_t b) { return adnm_cdiv(a, b) * b; }
 

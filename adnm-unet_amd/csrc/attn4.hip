@@ -131,11 +131,7 @@ extern "C" int adnm_attn4_fwd(const float* qkv, float* out, float* lse, int64_t 
   if (int rc = check("attn4_fwd", B, L, heads)) return rc;
   hipStream_t st = (hipStream_t)stream;
   const size_t smem = (size_t)L * 2 * sizeof(float4);
-  static bool attr = false;
-  if (!attr && smem > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)attn4_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  ADNM_ALLOW_LDS(attn4_fwd_kernel, smem, "attn4_fwd");
   ADNM_PROF("attn4_fwd", st, 4.0 * B * L * heads * (16.0 + 1.0));
   attn4_fwd_kernel<<<dim3((unsigned)(B * heads), (unsigned)adnm_cdiv(L, 64)), kBlock, smem, st>>>(qkv, out, lse, (int)L, (int)heads, scale);
   ADNM_CHECK_LAUNCH("attn4_fwd");
@@ -148,11 +144,7 @@ extern "C" int adnm_attn4_bwd(const float* dout, const float* qkv, const float* 
   if (int rc = check("attn4_bwd", B, L, heads)) return rc;
   hipStream_t st = (hipStream_t)stream;
   const size_t smem = (size_t)L * (4 * sizeof(float4) + 2 * sizeof(float));
-  static bool attr = false;
-  if (!attr && smem > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)attn4_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  ADNM_ALLOW_LDS(attn4_bwd_kernel, smem, "attn4_bwd");
   ADNM_PROF("attn4_bwd", st, 4.0 * B * L * heads * (12.0 * 2 + 4 * 2 + 1));
   attn4_bwd_kernel<<<dim3((unsigned)(B * heads), (unsigned)adnm_cdiv(L, 64)), kBlock, smem, st>>>(dout, qkv, out, lse, dqkv, (int)L, (int)heads, scale);
   ADNM_CHECK_LAUNCH("attn4_bwd");

@@ -68,7 +68,52 @@ __global__ __launch_bounds__(kBlock) void adamw_kernel(float* __restrict__ p, co
     reinterpret_cast<float4*>(v)[i] = vv;
   }
 }
+// wire format of the gradient all-reduce (reduce_dtype = bf16): one streaming pass each way, 8 elements per lane
+__global__ __launch_bounds__(kBlock) void cast_f32_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n, float scale) {
+  const int64_t n8 = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n8; i += (int64_t)gridDim.x * kBlock) {
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    uint4 o;
+    o.x = (uint32_t)f32_to_bf16(a.x * scale) | ((uint32_t)f32_to_bf16(a.y * scale) << 16);
+    o.y = (uint32_t)f32_to_bf16(a.z * scale) | ((uint32_t)f32_to_bf16(a.w * scale) << 16);
+    o.z = (uint32_t)f32_to_bf16(b.x * scale) | ((uint32_t)f32_to_bf16(b.y * scale) << 16);
+    o.w = (uint32_t)f32_to_bf16(b.z * scale) | ((uint32_t)f32_to_bf16(b.w * scale) << 16);
+    reinterpret_cast<uint4*>(dst)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[(n8 << 3) + threadIdx.x] = f32_to_bf16(src[(n8 << 3) + threadIdx.x] * scale);
+}
+__global__ __launch_bounds__(kBlock) void cast_bf16_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, int64_t n, float scale) {
+  const int64_t n8 = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n8; i += (int64_t)gridDim.x * kBlock) {
+    const uint4 v = reinterpret_cast<const uint4*>(src)[i];
+    reinterpret_cast<float4*>(dst)[2 * i] = make_float4(scale * __uint_as_float(v.x << 16), scale * __uint_as_float(v.x & 0xffff0000u),
+                                                        scale * __uint_as_float(v.y << 16), scale * __uint_as_float(v.y & 0xffff0000u));
+    reinterpret_cast<float4*>(dst)[2 * i + 1] = make_float4(scale * __uint_as_float(v.z << 16), scale * __uint_as_float(v.z & 0xffff0000u),
+                                                            scale * __uint_as_float(v.w << 16), scale * __uint_as_float(v.w & 0xffff0000u));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[(n8 << 3) + threadIdx.x] = scale * bf16_to_f32(src[(n8 << 3) + threadIdx.x]);
+}
 }  // namespace
+
+static int cast_launch(const void* src, void* dst, int64_t n, float scale, adnm_stream_t stream, bool to_bf16) {
+  ADNM_REQUIRE(src && dst && n > 0, "cast: null pointer or n <= 0");
+  ADNM_REQUIRE(((uintptr_t)src | (uintptr_t)dst) % 16 == 0, "cast: buffers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t blocks = adnm_cdiv(adnm_cdiv(n, 8), kBlock);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  ADNM_PROF(to_bf16 ? "cast_f32_bf16" : "cast_bf16_f32", st, 6.0 * n);
+  if (to_bf16) cast_f32_bf16_kernel<<<(unsigned)blocks, kBlock, 0, st>>>((const float*)src, (uint16_t*)dst, n, scale);
+  else cast_bf16_f32_kernel<<<(unsigned)blocks, kBlock, 0, st>>>((const uint16_t*)src, (float*)dst, n, scale);
+  ADNM_CHECK_LAUNCH("cast");
+  return ADNM_OK;
+}
+extern "C" int adnm_cast_f32_bf16(const void* src, void* dst, int64_t n, float scale, adnm_stream_t stream) {
+  return cast_launch(src, dst, n, scale, stream, true);
+}
+extern "C" int adnm_cast_bf16_f32(const void* src, void* dst, int64_t n, float scale, adnm_stream_t stream) {
+  return cast_launch(src, dst, n, scale, stream, false);
+}
 
 extern "C" int64_t adnm_adamw_ws_bytes(void) { return kNormBlocks * (int64_t)sizeof(float); }
 

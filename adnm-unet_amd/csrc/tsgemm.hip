@@ -234,24 +234,22 @@ int tn_blocks(int64_t M) {
 }
 
 template <int KQ, int NB>
-void launch_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, float* y, int64_t ldy, int64_t M,
+int launch_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, float* y, int64_t ldy, int64_t M,
                int N, int K, hipStream_t st) {
   const size_t smem = (size_t)NB * (K / 4) * 64 * sizeof(float);
   ADNM_PROF("tsgemm_nt", st, 4.0 * ((double)M * (K + N) + (double)N * K));
   tsgemm_nt_kernel<KQ, NB><<<nt_blocks(M), kBlock, smem, st>>>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, N, K);
+  return ADNM_OK;
 }
 
 template <int NBN, int NBK>
-void launch_tn(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* part, float* bpart, int64_t M, int N, int K, int nblk,
+int launch_tn(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* part, float* bpart, int64_t M, int N, int K, int nblk,
                int ntiles, hipStream_t st) {
   const size_t smem = (size_t)(kWaves / 2) * (NBN * NBK * 256 + NBN * 16) * sizeof(float);
-  static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in (host-side attribute, not a stream operation)
-  if (!attr_set && smem > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)tsgemm_tn_kernel<NBN, NBK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  ADNM_ALLOW_LDS((tsgemm_tn_kernel<NBN, NBK>), smem, "tsgemm_tn");   // > 64 KB of dynamic LDS: per-device opt-in (host-side attribute)
   ADNM_PROF("tsgemm_tn", st, 4.0 * ((double)M * (K + N) + (double)N * K));
   tsgemm_tn_kernel<NBN, NBK><<<dim3(nblk, ntiles), kBlock, smem, st>>>(dy, lddy, x, ldx, part, bpart, M, N, K);
+  return ADNM_OK;
 }
 
 // tile the N axis so that one block keeps at most 32 accumulator blocks: returns NBN (blocks of 16 rows per tile)
@@ -279,7 +277,7 @@ extern "C" int adnm_tsgemm_supported(int64_t M, int64_t N, int64_t K) {
   const int nb = pick((int)adnm_cdiv(N, 16), kNB, 6);
   if (pick((int)(K / 16), kKQ, 6) != K / 16) return 0;  // K/16 must be one of the instantiated depths
   if (N * K > 8192) return 0;  // the weight must stay a small, register/LDS-resident operand (refiner-family shapes)
-  return nb > 0 && (size_t)nb * (K / 4) * 64 * 4 <= 160 * 1024 ? 1 : 0;
+  return nb > 0 && nb * (K / 16) <= 32 ? 1 : 0;   // <= 32 accumulator/operand blocks per wave: the instantiated, spill-free variants
 }
 
 // Y[M,N] = X[M,K] . Wp^T (+bias), Wp[n][k] = w[n*ws_n + k*ws_k].  K % 16 == 0, K <= 256, N <= 256.
@@ -292,11 +290,18 @@ extern "C" int adnm_tsgemm_nt(const float* x, int64_t ldx, const float* w, int64
   const int kq = pick((int)(K / 16), kKQ, 6), nb = pick((int)adnm_cdiv(N, 16), kNB, 6);
   ADNM_REQUIRE(kq == K / 16, "tsgemm_nt: K/16=%lld not in {1,2,4,8,13,16}", (long long)(K / 16));
   hipStream_t st = (hipStream_t)stream;
-#define NT(KQ, NB) if (kq == KQ && nb == NB) launch_nt<KQ, NB>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, (int)N, (int)K, st)
-#define NT_ROW(KQ) NT(KQ, 1); NT(KQ, 2); NT(KQ, 4); NT(KQ, 8); NT(KQ, 13); NT(KQ, 16)
-  NT_ROW(1); NT_ROW(2); NT_ROW(4); NT_ROW(8); NT_ROW(13); NT_ROW(16);
-#undef NT_ROW
+  // only the variants adnm_tsgemm_supported admits (N*K <= 8192, i.e. KQ*NB <= 32 blocks: <= 64 accumulator + 64 operand VGPRs,
+  // no scratch) are instantiated
+  int rc = ADNM_EINVAL;
+#define NT(KQ, NB) if (kq == KQ && nb == NB) rc = launch_nt<KQ, NB>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, (int)N, (int)K, st)
+  NT(1, 1); NT(1, 2); NT(1, 4); NT(1, 8); NT(1, 13); NT(1, 16);
+  NT(2, 1); NT(2, 2); NT(2, 4); NT(2, 8); NT(2, 13); NT(2, 16);
+  NT(4, 1); NT(4, 2); NT(4, 4); NT(4, 8);
+  NT(8, 1); NT(8, 2); NT(8, 4);
+  NT(13, 1); NT(13, 2);
+  NT(16, 1); NT(16, 2);
 #undef NT
+  ADNM_REQUIRE(rc == ADNM_OK, "tsgemm_nt: no kernel variant for K/16=%d, N/16=%d", kq, nb);
   ADNM_CHECK_LAUNCH("tsgemm_nt");
   return ADNM_OK;
 }
@@ -330,10 +335,15 @@ extern "C" int adnm_tsgemm_tn(const float* dy, int64_t lddy, const float* x, int
   float* part = (float*)ws;
   float* bpart = dbias ? part : nullptr;   // non-null = "emit the bias sums at the end of every partial row"
   hipStream_t st = (hipStream_t)stream;
-#define TN(A, B) if (a == A && b == B) launch_tn<A, B>(dy, lddy, x, ldx, part, bpart, M, (int)N, (int)K, nblk, ntiles, st)
+  int rc = ADNM_EINVAL;
+#define TN(A, B) if (a == A && b == B) rc = launch_tn<A, B>(dy, lddy, x, ldx, part, bpart, M, (int)N, (int)K, nblk, ntiles, st)
   TN(1, 1); TN(1, 2); TN(1, 4); TN(1, 8); TN(1, 13); TN(1, 16); TN(2, 1); TN(2, 2); TN(2, 4); TN(2, 8); TN(2, 13);
   TN(4, 1); TN(4, 2); TN(4, 4); TN(8, 1); TN(8, 2); TN(13, 1); TN(13, 2); TN(16, 1);
 #undef TN
+  if (rc != ADNM_OK) {
+    if (rc == ADNM_EINVAL) adnm_set_error("tsgemm_tn: no kernel variant for N/16=%d, K/16=%d", a, b);
+    return rc;
+  }
   ADNM_CHECK_LAUNCH("tsgemm_tn");
   adnm_launch_fold("tsgemm_tn_fold", part, nblk, (int)(N * K + (dbias ? N : 0)), {dw, (int)(N * K)}, {dbias, dbias ? (int)N : 0}, {nullptr, 0},
                    {nullptr, 0}, st);

@@ -1,37 +1,68 @@
 #!/usr/bin/env python3
 """ADNM-UNet training-step benchmark (BASELINE.json metric: training sequences/sec, 5->20 x 128x128).
 
-  python bench.py --gpus N --steps K --warmup W            (N=1: single process)
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, RCCL)
+  python bench.py --gpus N --steps K --warmup W
+      N = 1: this process is the one rank.
+      N > 1 and no WORLD_SIZE in the environment: this process touches NO GPU, starts N child ranks of itself
+             (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), relays rank 0's JSON
+             line and exits with the children's status.
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+      the driver's form: WORLD_SIZE is set, this process is one rank; --gpus must equal WORLD_SIZE (checked).
 
-One step = forward -> enRainfallLoss -> backward -> (gradient all-reduce) -> clip_grad_norm_ -> AdamW.step ->
-zero_grad on a synthetic radar batch already resident in HBM (train.py:133-146 of the reference).  Rank 0
-prints ONE JSON line.  `roofline` is measured live with HIP events recorded by libadnm_hip around every one of
-its kernel launches (adnm_prof_enable/collect) during extra instrumented steps after the timed region;
-`cpu_baseline` times the oracle (oracle/adnm_oracle.py, the CPU restatement of the reference's algorithm) on
-the host cores for the same workload, rank 0 / N=1 only.
+One step = forward -> enRainfallLoss -> backward -> (bucketed gradient all-reduce over RCCL, overlapped with backward) ->
+clip_grad_norm_ -> AdamW.step -> zero_grad on a synthetic radar batch already resident in HBM (train.py:133-146 of the
+reference).  Protocol: W >= 10 warm-up steps, then 5 windows of exactly K steps, each bracketed by
+barrier + torch.cuda.synchronize() on both sides and reduced with MAX over ranks; `value` / `ms_per_step` come from the
+MEDIAN window, every window is listed in `windows_ms_per_step`.  Rank 0 prints ONE JSON line.
+
+`roofline`: per-kernel HIP-event timing recorded by libadnm_hip around each of its launches (adnm_prof_enable/collect), on the
+stream the kernels run on, during extra eagerly-launched steps after the timed region.  The reported kernel is the one with
+the largest AGGREGATE time over the library's kernels; `families` lists every north-star kernel family (K1 SSD reduction,
+depthwise stencils, wavelet transform, row norms, MFMA GEMMs, dense convs, optimiser) the same way.  `traffic` is the
+PMC-measured HBM bytes of that kernel from profiles/r02_pmc_traffic.json — used only if that file was made from the same
+kernel sources (hash of csrc/), else null.  `cpu_baseline` times the oracle (oracle/adnm_oracle.py, the CPU restatement of
+the reference's algorithm) on the host cores for the same workload, rank 0 / N=1 only.
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "adnm-unet_amd"))
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+N_WINDOWS = 5
+
+# profiler scope (csrc/*.hip ADNM_PROF names) -> north-star kernel family
+FAMILIES = [
+    ("K1 ssd reduction fwd (reduce+apply)", ("ssd_reduce", "ssd_outer_reduce", "ssd_fold", "ssd_apply", "ssd_kv")),
+    ("K1 ssd reduction bwd", ("ssd_bwd", "ssd_bc_fold", "ssd_dkv")),
+    ("K4 depthwise 3x3 stencil", ("dwconv_k3",)),
+    ("K3 depthwise 5x5 stencil (WTConv)", ("dwconv_k5",)),
+    ("K3/K4 depthwise weight gradient", ("dwconv_wgrad_k3", "dwconv_wgrad_k5", "dwconv_wgrad_fold")),
+    ("K3 Haar DWT/IDWT", ("haar_dwt", "haar_idwt", "wt_level_fwd", "wt_level_bwd")),
+    ("K2/K7 row norms", ("rownorm_fwd", "rownorm_bwd", "rownorm_bwd_fold")),
+    ("K8 instance norm", ("instnorm_stats", "instnorm_apply", "instnorm_bwd_stats", "instnorm_bwd_apply", "instnorm_bwd_scalar")),
+    ("K6 tall-skinny MFMA GEMM", ("tsgemm_nt", "tsgemm_tn", "tsgemm_tn_fold")),
+    ("K6b short MFMA GEMM", ("skgemm_nt", "skgemm_nn", "skgemm_tn", "skgemm_fold")),
+    ("K5/K9 dense 3x3 / transposed conv (MFMA)", ("conv3_fwd", "conv3_dgrad", "conv3_wgrad", "convt_fwd", "convt_dgrad", "convt_wgrad")),
+    ("scalar/gamma mixes + gates", ("lincomb_fwd", "lincomb_bwd", "lincomb_bwd_fold", "catmix_fwd", "catmix_bwd", "gate_fwd", "gate_bwd",
+                                    "igate_fwd", "igate_bwd")),
+    ("K12 optimiser (sumsq + AdamW)", ("grad_sumsq", "adamw_update")),
+]
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE config 2: 4)")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--in-frames", type=int, default=5)
@@ -39,17 +70,38 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8, help="timed oracle steps of the CPU baseline (~1.5 s each on 16 threads: ~12-15 s in all)")
     ap.add_argument("--prof-steps", type=int, default=3)
-    ap.add_argument("--stages", default="auto", choices=["auto", "0", "1"],
-                    help="two-stage backward (encoder | decoder+refiner) that overlaps the gradient all-reduce with the encoder's backward: "
-                         "auto = the ADNM_STAGES environment variable (default off: on one MI355X the second graph replay costs "
-                         "more than an 8-rank ring takes)")
+    ap.add_argument("--overlap", type=int, default=-1,
+                    help="gradient all-reduce overlapped with backward in bucket order (N>1): 1 on, 0 one blocking all-reduce after "
+                         "backward, -1 (default) = on whenever N>1")
+    ap.add_argument("--reduce-dtype", default="f32", choices=["f32", "bf16"], help="wire dtype of the gradient all-reduce (N>1)")
     ap.add_argument("--dump-prof", default="", help="write the per-(kernel, shape) HIP-event table of the instrumented steps to this file")
-    ap.add_argument("--graph", type=int, default=1, help="1 (default): replay fwd+bwd as a captured hipGraph; 0: eager launches")
-    ap.add_argument("--blas", default="hipblas", choices=["default", "hipblas", "hipblaslt"],
-                    help="library used for the plain GEMMs (default rocBLAS: its long-reduction weight-grad GEMMs are 6x faster here)")
+    ap.add_argument("--graph", type=int, default=1, help="1 (default): replay fwd+bwd as captured hipGraphs; 0: eager launches")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------ multi-GPU entry
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this script.  The parent never initialises HIP (a
+    process that has may not exec/fork GPU children safely, and must not hold a context on device 0)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if os.environ.get("ADNM_PIN_DEVICES") == "1":   # one visible device per rank (what an unmodified train.py needs, INTEGRATION.md §1.3)
+            env["HIP_VISIBLE_DEVICES"], env["LOCAL_RANK"] = str(r), "0"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+# ------------------------------------------------------------------------------------------------ profiler table
 def collect_profile(lib):
     buf = ctypes.create_string_buffer(1 << 20)  # one call: collecting also clears the records
     lib.query("adnm_prof_collect", buf, len(buf))
@@ -60,23 +112,6 @@ def collect_profile(lib):
     return rows
 
 
-# profiler scope name -> device kernel name, for the kernels whose every launch has ONE shape (so the per-kernel PMC
-# average of profiles/r01_pmc_traffic.json IS the per-launch traffic of that shape)
-PMC_KERNEL = {"adamw_update": "adamw_kernel", "grad_sumsq": "sumsq_partial_kernel"}
-
-
-def pmc_traffic(scope_name):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.py) of this
-    same command; None when that kernel runs several shapes or no PMC pass is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    dev = PMC_KERNEL.get(scope_name)
-    if dev is None or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        rec = json.load(f).get(dev)
-    return round(rec["hbm_bytes_per_launch"]) if rec else None
-
-
 def by_kernel(rows):
     out = {}
     for key, r in rows.items():
@@ -84,6 +119,30 @@ def by_kernel(rows):
         for f in ("launches", "ms", "bytes"):
             a[f] += r[f]
     return out
+
+
+def csrc_hash():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "adnm-unet_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_table():
+    """profiles/r02_pmc_traffic.json: {"csrc_hash": ..., "commit": ..., "kernels": {scope: {"hbm_bytes_per_step": ...,
+    "launches_per_step": ...}}} made by tools/pmc_traffic.py from two rocprofv3 --pmc passes of this command.  Only trusted for
+    the kernel sources it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, "no committed PMC pass"
+    with open(path) as f:
+        t = json.load(f)
+    if t.get("csrc_hash") != csrc_hash():
+        return None, f"profiles/r02_pmc_traffic.json was measured on other kernel sources (csrc hash {t.get('csrc_hash')}), not used"
+    return t, f"profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE; commit {t.get('commit')})"
 
 
 def host_cores():
@@ -100,6 +159,7 @@ def host_cores():
 
 def cpu_baseline(args, steps):
     """The oracle's full training step on the host CPU (kind 'port': the reference's Python cannot travel)."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import adnm_oracle as O
     from adnm_hip import recipe
@@ -134,45 +194,55 @@ def cpu_baseline(args, steps):
                       f"torch.set_num_threads({cores}); median {t:.2f} s/step"}
 
 
+# ------------------------------------------------------------------------------------------------ one rank
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` (it launches its own "
+                         f"ranks) or under torch.distributed.run with --nproc-per-node equal to --gpus")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    local = local % torch.cuda.device_count()  # (a 1-GPU rehearsal box runs every rank on device 0, backend gloo)
+    backend = os.environ.get("ADNM_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; gloo = the 1-GPU-box rehearsal of the N>1 flow
+    ndev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and local >= ndev:
+        raise SystemExit(f"bench.py: rank {rank} wants device {local} but only {ndev} are visible")
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("ADNM_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world
 
     from adnm_hip import lib, recipe
     from adnm_hip.trainer import FlatTrainer
     from models.ADNMUNet import create_ADNMUNet
     from models.loss import enRainfallLoss
     lib.load()
-    if args.blas != "default":
-        torch.backends.cuda.preferred_blas_library(args.blas)  # plain library GEMMs: rocBLAS ("hipblas") or hipBLASLt
 
     model = create_ADNMUNet(args.in_frames, args.out_frames, 6, img_size=args.size)
     recipe.fill_parameters(model)  # identical replicas on every rank, same parameters as the parity fixtures
     model = model.to(dev).train()
     criterion = enRainfallLoss(omega_t=0.57, alpha=0.25, gamma=0.).to(dev)  # train_untils.py:43
+    overlap = (world > 1) if args.overlap < 0 else bool(args.overlap)
     # AdamW recipe of train_untils.py:35-42; clip threshold = norm_max of the warm-up epochs (train.py:87,122-124)
     trainer = FlatTrainer(model, criterion, lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2, max_norm=0.025,
-                          use_graph=bool(args.graph), stages="auto" if args.stages == "auto" else bool(int(args.stages)))
+                          use_graph=bool(args.graph), overlap=overlap, reduce_dtype=args.reduce_dtype)
     frames = recipe.radar_batch(args.batch, args.in_frames + args.out_frames, args.size, salt=rank, name="bench").to(dev)
     x, tgt = frames[:, :args.in_frames].contiguous(), frames[:, args.in_frames:].contiguous()
     trainer.prepare(x, tgt)
-
-    def step():
-        return trainer.step(x, tgt)
 
     def sync():
         if world > 1:
@@ -180,32 +250,30 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        trainer.step(x, tgt)
     sync()
     if rank == 0:
         print("[bench] warm-up done, timing ...", file=sys.stderr, flush=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float32)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+    windows = []
+    for w in range(N_WINDOWS):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = trainer.step(x, tgt)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax)
+        windows.append(dt)
+        if rank == 0:
+            print(f"[bench] window {w}: {1e3 * dt / args.steps:.3f} ms/step", file=sys.stderr, flush=True)
+    dt = sorted(windows)[N_WINDOWS // 2]
     loss_val = float(loss.detach())
-    if rank == 0:
-        print(f"[bench] timed region: {1e3 * dt / args.steps:.2f} ms/step", file=sys.stderr, flush=True)
 
     def eager_step():  # same work, launched eagerly: per-launch HIP events cannot be recorded inside a graph replay
-        g = trainer.graph
-        trainer.graph = None
-        for p in trainer.used:
-            p.grad = None
-        try:
-            return trainer.step(x, tgt)
-        finally:
-            trainer.graph = g
+        return trainer.step(x, tgt, eager=True)
 
     # ---- instrumented steps (outside the timed region): per-kernel HIP-event timing inside libadnm_hip
     prof = {}
@@ -229,31 +297,51 @@ def main():
         dist.barrier()
 
     if rank == 0:
+        ps = max(args.prof_steps, 1)
         total_ms = sum(r["ms"] for r in prof.values()) or 1.0
         if args.dump_prof:
             with open(args.dump_prof, "w") as f:
                 f.write("kernel@bytes_per_launch\tlaunches_per_step\tavg_us\tms_per_step\tGB/s\n")
                 for key, r in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
-                    f.write(f"{key}\t{r['launches'] / args.prof_steps:.1f}\t{1e3 * r['ms'] / r['launches']:.2f}\t{r['ms'] / args.prof_steps:.4f}\t"
+                    f.write(f"{key}\t{r['launches'] / ps:.1f}\t{1e3 * r['ms'] / r['launches']:.2f}\t{r['ms'] / ps:.4f}\t"
                             f"{r['bytes'] / max(r['ms'], 1e-9) / 1e6:.1f}\n")
-        # the dominant kernel = the (kernel, shape) instance with the largest share of the HIP-kernel time
-        dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
+        agg = by_kernel(prof)
+        pmc, pmc_src = pmc_table()
+
+        def line(names):
+            """aggregate over profiler scopes: per-step launches / ms / algorithmic bytes, achieved GB/s, fraction of the HBM peak,
+            PMC traffic per step and its ratio to the algorithmic bytes (None without a matching PMC pass)"""
+            rs = [agg[n] for n in names if n in agg]
+            if not rs:
+                return None
+            ms, by, ln = sum(r["ms"] for r in rs) / ps, sum(r["bytes"] for r in rs) / ps, sum(r["launches"] for r in rs) / ps
+            ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            tr = None
+            if pmc:
+                got = [pmc["kernels"].get(n) for n in names if n in agg]
+                if got and all(g is not None for g in got):
+                    tr = sum(g["hbm_bytes_per_step"] for g in got)
+            return {"launches_per_step": round(ln, 1), "ms_per_step": round(ms, 4), "algorithmic_MB_per_step": round(by / 1e6, 2),
+                    "GBps": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "traffic_MB_per_step": None if tr is None else round(tr / 1e6, 2),
+                    "traffic_over_algorithmic": None if tr is None or by <= 0 else round(tr / by, 3)}
+
+        kernels = {n: line((n,)) for n, _ in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        families = {fam: line(names) for fam, names in FAMILIES if line(names)}
         roofline = None
-        kernels = {}
-        for name, r in sorted(by_kernel(prof).items(), key=lambda kv: -kv[1]["ms"]):
-            kernels[name] = {"launches_per_step": r["launches"] / args.prof_steps, "ms_per_step": round(r["ms"] / args.prof_steps, 4),
-                             "avg_us": round(1e3 * r["ms"] / r["launches"], 2),
-                             "GBps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1) if r["ms"] > 0 else None}
-        if dom:
-            name, r = dom
-            ach = r["bytes"] / (r["ms"] * 1e-3) / 1e9
-            roofline = {"kernel": name.split("@")[0], "shape_bytes": int(float(name.split("@")[1])), "launches_per_step": r["launches"] / args.prof_steps,
-                        "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name.split("@")[0]),
-                        "avg_launch_us": round(1e3 * r["ms"] / r["launches"], 2),
-                        "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"]),
-                        "hip_kernels_ms_per_step": round(total_ms / args.prof_steps, 3),
-                        "instrumented_step_ms": round(prof_step_ms, 3)}
+        if agg:
+            # the dominant kernel = the library kernel with the largest AGGREGATE time per step (all its shapes together)
+            name = max(agg.items(), key=lambda kv: kv[1]["ms"])[0]
+            r, k = agg[name], kernels[name]
+            per_launch_bytes = r["bytes"] / r["launches"]
+            avg_us = 1e3 * r["ms"] / r["launches"]
+            roofline = {"kernel": name, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["frac"],
+                        "traffic": None if k["traffic_MB_per_step"] is None else round(1e6 * k["traffic_MB_per_step"] / k["launches_per_step"]),
+                        "traffic_source": pmc_src, "launches_per_step": k["launches_per_step"], "avg_launch_us": round(avg_us, 2),
+                        "algorithmic_bytes_per_launch": round(per_launch_bytes),
+                        "definition": "achieved = sum of algorithmic bytes of this kernel's launches in a step / sum of their HIP-event durations "
+                                      "(per-launch averages over all its shapes); per-shape rows: --dump-prof / profiles/",
+                        "hip_kernels_ms_per_step": round(total_ms / ps, 3), "instrumented_step_ms": round(prof_step_ms, 3),
+                        "whole_step_frac": round(sum(r_["bytes"] for r_ in agg.values()) / ps / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
         res = {
             "metric": "sequences/sec training ADNM-UNet 5->20x128x128", "value": round(world * args.batch * args.steps / dt, 3),
             "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -262,14 +350,21 @@ def main():
             "config": {"workload": f"ADNM-UNet create_ADNMUNet({args.in_frames},{args.out_frames},6) {args.size}x{args.size} full training step "
                                    "(fwd + enRainfallLoss + bwd + clip_grad_norm_ + AdamW), recipe parameters, synthetic radar frames in HBM",
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch, "frames": f"{args.in_frames}->{args.out_frames}",
-                       "parallelism": f"dp{world}" if world > 1 else "single", "launch": ("hipGraph replay" if args.graph else "eager") + (", two-stage backward with overlapped all-reduce" if trainer.staged else ""),
+                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "launch": ("hipGraph replay" if args.graph else "eager") + (
+                           f", {len(trainer.buckets)} gradient buckets all-reduced ({args.reduce_dtype}) beside backward" if world > 1 and overlap
+                           else (", one all-reduce after backward" if world > 1 else "")),
+                       "dist_backend": (backend + ("=RCCL" if backend == "nccl" else "")) if world > 1 else None,
+                       "protocol": f"{args.warmup} warm-up steps, median of {N_WINDOWS} windows of {args.steps} steps, barrier+sync at window edges, max over ranks",
                        "loss": round(loss_val, 6)},
+            "windows_ms_per_step": [round(1e3 * w / args.steps, 3) for w in windows],
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args, args.cpu_steps)
         else:
             res["cpu_baseline"] = None
+        res["families"] = families
         res["kernels"] = kernels
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -18,7 +18,10 @@
  *  - `dtype` selects the storage type of activations: ADNM_F32 (0) or ADNM_BF16 (1);
  *    parameters, statistics, reductions and workspaces are always fp32;
  *  - return value 0 = launched; negative = rejected (nothing launched), text via
- *    adnm_last_error() (thread-local).  No global mutable state: re-entrant per thread/stream.
+ *    adnm_last_error() (thread-local).  The compute entry points keep no global mutable state: they are re-entrant
+ *    per thread / stream / device (the reference's nn.DataParallel calls them from one thread per device).  The only
+ *    process-wide state is the opt-in profiler's record list (adnm_prof_*, mutex-guarded) and per-device "dynamic LDS
+ *    limit raised" flags (atomics; setting one twice is harmless).
  */
 #ifndef ADNM_HIP_H
 #define ADNM_HIP_H
@@ -293,6 +296,12 @@ int64_t adnm_adamw_ws_bytes(void);
 int adnm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float* state, float lr, float beta1,
                     float beta2, float eps, float weight_decay, float max_norm, void* ws, int64_t ws_bytes,
                     adnm_stream_t stream);
+
+/* Wire format of the data-parallel gradient all-reduce that replaces nn.DataParallel's reduce_add_coalesced (train.py:99-102;
+ * SURVEY.md §8e): dst[i] = (bf16)(scale * src[i]) before the collective, dst[i] = scale * (float)src[i] after it (scale = 1/world
+ * folds the average in).  n elements, both buffers 16-byte aligned. */
+int adnm_cast_f32_bf16(const void* src, void* dst, int64_t n, float scale, adnm_stream_t stream);
+int adnm_cast_bf16_f32(const void* src, void* dst, int64_t n, float scale, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- tall-skinny fp32 GEMMs on MFMA (K6)
  * The Linear / 1x1 projections of the full-resolution stages (ADNssd.py:309,461; model_untils.py:64,67,193,196,831;

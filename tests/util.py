@@ -36,21 +36,27 @@ def assert_close(a, b, tol, what="", atol=0.0):
 
 
 def check_update_deltas(z, names, deltas, lr=1e-3):
-    """The update itself, p_after - p_before, against the reference's: the first AdamW step moves every element by
-    -lr * g / (|g| + eps) - lr * wd * p, i.e. by ~lr in the direction of -sign(g).  Small tensors (<= 8 elements: the 360
-    scalar mixes) are compared element by element; large ones by the sum and the absolute sum of the update, where only
-    elements whose gradient is ~0 (|g| ~ eps = 1e-9 after clipping) may differ."""
+    """The update itself, p_after - p_before, against the reference's.  The first AdamW step moves every element by
+    -lr * g / (|g| + eps) - lr * wd * p: by ~lr in the direction of -sign(g), whatever |g| is.  So the MAGNITUDE of the update is
+    checked everywhere (it catches a missing / doubled / mis-scaled update), and its SIGN wherever the gradient is well above the
+    fp32 round-off of the reference itself (an element whose gradient is noise moves by +-lr at random on both sides):
+      * 1-element tensors (the 360 scalar mixes) whose |g| >= 2e-3 of the total norm: the value of the update;
+      * other tensors: the absolute sum (1 %), and the sum up to the flips of a few % of near-zero-gradient elements.
+    (Gradient directions themselves are pinned by the grad_probe check; the AdamW arithmetic by tests/test_trainer_gpu.py.)"""
     small = iter(torch.split(z["delta_small"].double(), [int(n) for n in z["delta_small_sizes"]]))
+    gn, gtot = z["grad_norms"].double(), float(z["grad_total_norm"])
+    checked_scalars = 0
     for i, (k, d) in enumerate(zip(names, deltas)):
         n = d.numel()
         d = d.flatten().cpu()
-        if n <= 8:
-            ref = next(small)
-            if float(z["grad_norms"][i]) < 0:
-                assert float(d.abs().max()) == 0.0, f"{k}: a parameter without gradient must not move"
-                continue
-            # a fully fledged step is lr; allow 2 % of it (|g| is never near eps for the live scalars)
+        ref = next(small) if n <= 8 else None
+        if float(gn[i]) < 0:
+            assert float(d.abs().max()) == 0.0, f"{k}: a parameter without gradient must not move"
+            continue
+        assert abs(float(d.abs().sum()) - float(z["delta_abs"][i])) <= 0.01 * lr * n + 1e-12, f"{k}: |update| sum {float(d.abs().sum())} vs {float(z['delta_abs'][i])}"
+        if n == 1 and float(gn[i]) >= 2e-3 * gtot:
+            checked_scalars += 1
             assert float((d - ref).abs().max()) <= 0.02 * lr, f"{k}: update {d.tolist()} vs reference {ref.tolist()}"
-        else:
-            assert abs(float(d.abs().sum()) - float(z["delta_abs"][i])) <= 0.01 * lr * n + 1e-12, f"{k}: |update| sum"
-            assert abs(float(d.sum()) - float(z["delta_sum"][i])) <= 0.02 * lr * n ** 0.5 + 0.002 * lr * n, f"{k}: update sum"
+        elif n > 1:
+            assert abs(float(d.sum()) - float(z["delta_sum"][i])) <= 3 * lr * n ** 0.5 + 0.05 * lr * n, f"{k}: update sum"
+    assert checked_scalars >= 100, checked_scalars
