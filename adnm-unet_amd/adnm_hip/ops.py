@@ -139,8 +139,10 @@ def k_rownorm_bwd(dy2, x2, w, b, scale, mu, rstd, mean, want_b, want_affine, dx_
     return dx, dw, db, dsc, dsh
 
 
-def k_ssd_fwd(x, Bm, Cm, dt_raw, dt_bias, A_log, D, B, L, H, P, N, G, y=None):
-    """x (M,H*P) row view, Bm/Cm (M,G*N) row views, dt_raw (M,H) row view; M = B*L."""
+def k_ssd_fwd(x, Bm, Cm, dt_raw, dt_bias, A_log, D, B, L, H, P, N, G, y=None, ln=None):
+    """x (M,H*P) row view, Bm/Cm (M,G*N) row views, dt_raw (M,H) row view; M = B*L.
+    ln = (weight, bias, out row view (M,H*P), eps): the mixer's LayerNorm (ADNssd.py:456) as the epilogue of pass 2 — only
+    when H*P == 64 (the token row is one head block); returns (y, kv, mu, rstd) then."""
     _need_gpu(x)
     dev = x.device
     M = B * L
@@ -154,9 +156,17 @@ def k_ssd_fwd(x, Bm, Cm, dt_raw, dt_bias, A_log, D, B, L, H, P, N, G, y=None):
     pc, ldc = _rows(Cm)
     pt, ldt = _rows(dt_raw)
     py, ldy = _rows(y)
+    if ln is not None:
+        lw, lb, yn, eps = ln
+        mu = torch.empty(M, dtype=torch.float32, device=dev)
+        rstd = torch.empty(M, dtype=torch.float32, device=dev)
+        pn, ldn = _rows(yn)
+        extra = (_p(_f32(lw)), _p(_f32(lb)), pn, ldn, mu.data_ptr(), rstd.data_ptr(), float(eps))
+    else:
+        extra = (None, None, None, 0, None, None, 0.0)
     lib.call("adnm_ssd_reduce_fwd", px, ldx, pb, ldb, pc, ldc, pt, ldt, 1, _p(_f32(dt_bias)), _p(_f32(A_log)), _p(_f32(D)), 1, py,
-             ldy, kv.data_ptr(), ws.data_ptr(), nb, B, L, H, P, N, G, _dt(x), _stream())
-    return y, kv
+             ldy, kv.data_ptr(), *extra, ws.data_ptr(), nb, B, L, H, P, N, G, _dt(x), _stream())
+    return (y, kv, mu, rstd) if ln is not None else (y, kv)
 
 
 def k_ssd_bwd(dy, x, Bm, Cm, dt_raw, dt_bias, A_log, D, kv, dx, dBm, dCm, ddt, B, L, H, P, N, G):
@@ -387,14 +397,18 @@ class CatMixFn(torch.autograd.Function):
         return v(dx), v(dr), v(df), s(a1, 0), s(a2, 1), s(a3 if f2 is not None else None, 2), s(a4 if f2 is not None else None, 3)
 
 
+def _unsupported(op, why):
+    raise RuntimeError(f"adnm_hip {op}: {why} (the HIP path has no PyTorch fallback)")
+
+
 def catmix(x, r, f, a1, a2, a3=None, a4=None):
-    """Head merge of Block / Attention / WTLayer; falls back to the plain expression for shapes the kernel does not take."""
+    """Head merge of Block / Attention / WTLayer: cat((a1 x, a2 r)) [+ cat((a3 f, a4 f))]."""
+    _need_gpu(x)
     d = x.shape[-1]
-    ok = (x.is_cuda and r.shape == x.shape and (f is None or f.shape == x.shape) and d % 4 == 0 and x.dtype in _DT
-          and all(a is None or a.numel() == 1 for a in (a1, a2, a3, a4)))
-    if not ok:
-        y = torch.cat((a1 * x, a2 * r), dim=-1)
-        return y if f is None else y + torch.cat((a3 * f, a4 * f), dim=-1)
+    if r.shape != x.shape or (f is not None and f.shape != x.shape):
+        _unsupported("catmix", f"operands must share one shape, got {tuple(x.shape)}, {tuple(r.shape)}" + (f", {tuple(f.shape)}" if f is not None else ""))
+    if d % 4 or x.dtype not in _DT or any(a is not None and a.numel() != 1 for a in (a1, a2, a3, a4)):
+        _unsupported("catmix", f"needs a channel count that is a multiple of 4 (got {d}), fp32/bf16 tokens and 1-element mixing parameters")
     return CatMixFn.apply(x, r, f, a1, a2, a3, a4)
 
 
@@ -600,15 +614,22 @@ class ADNMixerFn(torch.autograd.Function):
         k_dwconv_fwd(proj[:, :di], czw, czb, Bsz, H, W, di, 3, lib.ACT_SILU, y=cat[:, di:])
         xbc = k_dwconv_fwd(proj[:, di:di + cx], cw, cb, Bsz, H, W, cx, 3, lib.ACT_SILU)
         if scan_chunk == 0:   # linear_attn_duality=True: the global reduction (K1), both halves in one launch
-            y, kv = k_ssd_fwd(xbc[:, :di], xbc[:, di:di + 2 * N], xbc[:, di + 2 * N:], proj[:, di + cx:], dt_bias, A_log, D,
-                              Bsz, L, nh, P, N, 2)
+            if di == 64:   # the token row is one head block: LayerNorm(y) (ADNssd.py:456) rides in pass 2's epilogue (refiner mixers)
+                y, kv, mu, rstd = k_ssd_fwd(xbc[:, :di], xbc[:, di:di + 2 * N], xbc[:, di + 2 * N:], proj[:, di + cx:], dt_bias, A_log, D,
+                                            Bsz, L, nh, P, N, 2, ln=(ln_w, ln_b, cat[:, :di], 1e-5))
+            else:
+                y, kv = k_ssd_fwd(xbc[:, :di], xbc[:, di:di + 2 * N], xbc[:, di + 2 * N:], proj[:, di + cx:], dt_bias, A_log, D,
+                                  Bsz, L, nh, P, N, 2)
+                mu = None
         else:                 # chunked scan (K1b): even half forward in time, odd half backward (ADNssd.py:416-439)
             y = torch.empty((M, di), dtype=u.dtype, device=u.device)
             Ns = N // scan_groups
             kv = torch.stack([k_ssd_scan_fwd(xbc[:, e * P:di], 2 * P, xbc[:, di + e * N:di + (e + 1) * N], xbc[:, di + 2 * N + e * N:di + 2 * N + (e + 1) * N],
                                              proj[:, di + cx + e:], 2, dt_bias[e:], A_log[e:], D[e:], 2, y[:, e * P:], 2 * P, Bsz, L, nh // 2, P, Ns,
                                              scan_groups, scan_chunk, e == 1) for e in (0, 1)])
-        _, mu, rstd = k_rownorm_fwd(y, ln_w, ln_b, None, None, 1e-5, True, out=cat[:, :di])
+            mu = None
+        if mu is None:
+            _, mu, rstd = k_rownorm_fwd(y, ln_w, ln_b, None, None, 1e-5, True, out=cat[:, :di])
         out = k_linear(cat, w_out, None)
         ctx.save_for_backward(u2, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, proj, xbc, y, kv, mu, rstd, cat)
         ctx.dims = (Bsz, L, dm, H, W, P, N, di, cx, nh, scan_chunk, scan_groups)
@@ -708,11 +729,9 @@ class LinCombFn(torch.autograd.Function):
 def lincomb(xs, scalars, gamma=None):
     """xs: 1-3 same-shape token tensors; scalars: matching list of 1-element parameters (or None = 1)."""
     C = xs[0].shape[-1]
-    if C % 4 or C > 2048 or any(s is not None and s.numel() != 1 for s in scalars):
-        y = 0
-        for x, s in zip(xs, scalars):
-            y = y + (x if s is None else s * x)
-        return y if gamma is None else y * gamma
+    _need_gpu(xs[0])
+    if C % 4 or C > 2048 or not 1 <= len(xs) <= 3 or any(s is not None and s.numel() != 1 for s in scalars):
+        _unsupported("lincomb", f"needs 1-3 operands with 4 | C <= 2048 channels and 1-element scalars, got {len(xs)} operands, C={C}")
     return LinCombFn.apply(gamma, *xs, *scalars)
 
 
@@ -819,81 +838,60 @@ def maxpool(x, H, W, kh, kw, stride):
     return MaxPoolFn.apply(x, H, W, kh, kw, stride)
 
 
-# ------------------------------------------------------------------------------------------- tall-skinny GEMMs (K6)
-TS_MIN_ROWS = 2048  # below this the library GEMM is as good (and K,N are usually > 256 there anyway)
+# ------------------------------------------------------------------------------------------- Linear / 1x1 GEMMs (K6, K6b)
+# Static routing, the same in every process and on every rank: the tall-skinny kernel (csrc/tsgemm.hip) takes the full-resolution
+# projections (>= 2048 token rows, weight <= 8192 elements), the short-GEMM kernel (csrc/skgemm.hip) everything else.  There is
+# no library GEMM behind these: a shape neither kernel takes raises.
+TS_MIN_ROWS = 2048
+SK_NT, SK_NN, SK_TN = 0, 1, 2
 
 
 def ts_ok_nt(M, N, K, x):
-    return (x.is_cuda and x.dtype == torch.float32 and M >= TS_MIN_ROWS and lib.query("adnm_tsgemm_supported", M, N, K) == 1)
+    return (x.is_cuda and x.dtype == torch.float32 and M >= TS_MIN_ROWS and x.stride(0) % 4 == 0 and lib.query("adnm_tsgemm_supported", M, N, K) == 1)
 
 
 def ts_ok_tn(M, N, K, x):
     return (x.is_cuda and x.dtype == torch.float32 and M >= TS_MIN_ROWS and lib.query("adnm_tsgemm_tn_supported", M, N, K) == 1)
 
 
-SK_NT, SK_NN, SK_TN = 0, 1, 2
-SK_MAX_ROWS = 4096
-SK_FORCE = False      # tests: always take the kernel where the shape is supported
-_SK_CHOICE = {}       # (op, M, N, K, bias) -> True: skgemm, False: library — measured on first eager use
-
-
-def sk_ok(op, M, N, K, *tensors):
-    """Short-GEMM kernel (csrc/skgemm.hip) candidate: an fp32 Linear the tall-skinny kernel does not take."""
-    return ((SK_FORCE or M <= SK_MAX_ROWS) and all(t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1 and t.stride(0) % 4 == 0
-                                                   and t.data_ptr() % 16 == 0 for t in tensors)
-            and lib.query("adnm_skgemm_supported", op, M, N, K) == 1)
-
-
-def sk_pick(key, run_sk, run_lib):
-    """Measure, don't guess: rocBLAS / hipBLASLt pick excellent kernels for most of these shapes and pathological ones for a
-    few (one 256x256 macro tile for a 256x512x256 Linear: 123 us, ours 15).  The first EAGER use of a shape times both
-    (FlatTrainer's dry-run steps do that before the graph is captured); under capture an unseen shape goes to the library."""
-    if SK_FORCE:
-        return True
-    c = _SK_CHOICE.get(key)
-    if c is not None:
-        return c
-    if torch.cuda.is_current_stream_capturing():
-        return False
-    best = []
-    for fn in (run_sk, run_lib):
-        for _ in range(2):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            fn()
-        e1.record()
-        e1.synchronize()
-        best.append(e0.elapsed_time(e1))
-    _SK_CHOICE[key] = best[0] < 0.9 * best[1]   # the kernel has to win clearly
-    return _SK_CHOICE[key]
+def _sk_operand(t, what):
+    """skgemm reads 16-byte vectors along the contiguous axis of a row view."""
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError(f"adnm_hip linear: {what} must be an fp32 GPU tensor, got {t.dtype} on {t.device}")
+    if t.stride(-1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
+        t = t.contiguous()
+        if t.stride(0) % 4 or t.data_ptr() % 16:
+            raise RuntimeError(f"adnm_hip linear: {what} of shape {tuple(t.shape)} cannot be 16-byte aligned per row (last dim must be a multiple of 4)")
+    return t
 
 
 def _skgemm(op, a, b, bias, c, dbias, M, N, K):
+    if lib.query("adnm_skgemm_supported", op, M, N, K) != 1:
+        raise RuntimeError(f"adnm_hip linear: no kernel takes op={('NT', 'NN', 'TN')[op]} M={M} N={N} K={K} "
+                           "(NT needs K % 16 == 0; NN needs N % 16 == 0 and K % 4 == 0; TN needs N % 4 == 0 and K % 4 == 0)")
     nb = lib.query("adnm_skgemm_ws_bytes", op, M, N, K)
     ws = _ws(nb, a.device)
     lib.call("adnm_skgemm", op, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _p(bias), c.data_ptr(), c.stride(0), _p(dbias),
              ws.data_ptr(), nb, M, N, K, _stream())
 
 
+def _out_view_ok(out):
+    return out.stride(-1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0
+
+
 def k_linear(x2, w, bias, out=None):
-    """Y = X W^T (+bias) for row views X (M,K) [stride (ld,1)], W (N,K) contiguous: MFMA tall-skinny kernel when the shape
-    fits, the library GEMM otherwise."""
+    """Y = X W^T (+bias) for row views X (M,K) [stride (ld,1)], W (N,K) contiguous."""
     M, K = x2.shape
     N = w.shape[0]
-    if ts_ok_nt(M, N, K, x2) and x2.stride(0) % 4 == 0:
+    _need_gpu(x2)
+    if ts_ok_nt(M, N, K, x2):
         y = out if out is not None else torch.empty((M, N), dtype=x2.dtype, device=x2.device)
         lib.call("adnm_tsgemm_nt", x2.data_ptr(), x2.stride(0), w.data_ptr(), K, 1, _p(bias), y.data_ptr(), y.stride(0), M, N, K, _stream())
         return y
-    lib_nt = lambda: torch.mm(x2, w.t()) if bias is None else torch.addmm(bias, x2, w.t())
-    if sk_ok(SK_NT, M, N, K, x2, w) and (out is None or (out.stride(-1) == 1 and out.stride(0) % 4 == 0)) and N % 4 == 0:
-        y = out if out is not None else torch.empty((M, N), dtype=x2.dtype, device=x2.device)
-        if sk_pick((SK_NT, M, N, K, bias is not None), lambda: _skgemm(SK_NT, x2, w, bias, y, None, M, N, K), lib_nt):
-            _skgemm(SK_NT, x2, w, bias, y, None, M, N, K)
-            return y
-    y = lib_nt()
-    if out is not None:
+    x2, w = _sk_operand(x2, "input"), _sk_operand(w, "weight")
+    y = out if out is not None and _out_view_ok(out) else torch.empty((M, N), dtype=x2.dtype, device=x2.device)
+    _skgemm(SK_NT, x2, w, bias, y, None, M, N, K)
+    if out is not None and y is not out:
         out.copy_(y)
         return out
     return y
@@ -903,26 +901,25 @@ def k_linear_dx(dy2, w, out=None):
     """dX = dY W for dY (M,N) row view, W (N,K) contiguous."""
     M, N = dy2.shape
     K = w.shape[1]
-    if ts_ok_nt(M, K, N, dy2) and dy2.stride(0) % 4 == 0:
+    if ts_ok_nt(M, K, N, dy2):
         dx = out if out is not None else torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
         lib.call("adnm_tsgemm_nt", dy2.data_ptr(), dy2.stride(0), w.data_ptr(), 1, K, None, dx.data_ptr(), dx.stride(0), M, K, N, _stream())
         return dx
-    if sk_ok(SK_NN, M, N, K, dy2, w) and (out is None or (out.stride(-1) == 1 and out.stride(0) % 4 == 0)):
-        dx = out if out is not None else torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
-        if sk_pick((SK_NN, M, N, K, False), lambda: _skgemm(SK_NN, dy2, w, None, dx, None, M, N, K), lambda: torch.mm(dy2, w)):
-            _skgemm(SK_NN, dy2, w, None, dx, None, M, N, K)
-            return dx
-    dx = torch.mm(dy2, w)
-    if out is not None:
+    dy2, w = _sk_operand(dy2, "output gradient"), _sk_operand(w, "weight")
+    dx = out if out is not None and _out_view_ok(out) else torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
+    _skgemm(SK_NN, dy2, w, None, dx, None, M, N, K)
+    if out is not None and dx is not out:
         out.copy_(dx)
         return out
     return dx
 
 
 def colsum(t, out=None):
-    """sum over the rows of a 2-D fp32 matrix (bias gradient) with the deterministic fold kernel."""
-    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous()):
-        return t.sum(0) if out is None else torch.sum(t, 0, out=out)
+    """sum over the rows of a contiguous 2-D fp32 matrix (a bias gradient) with the deterministic fold kernel."""
+    _need_gpu(t)
+    if not (t.dtype == torch.float32 and t.dim() == 2):
+        raise RuntimeError(f"adnm_hip colsum: needs a 2-D fp32 tensor, got {t.dtype} {tuple(t.shape)}")
+    t = t if t.is_contiguous() else t.contiguous()
     if out is None:
         out = torch.empty(t.shape[1], dtype=torch.float32, device=t.device)
     lib.call("adnm_colsum", t.data_ptr(), out.data_ptr(), t.shape[0], t.shape[1], _stream())
@@ -942,13 +939,9 @@ def k_linear_dw(dy2, x2, want_bias, w_ptr=0, b_ptr=0):
         lib.call("adnm_tsgemm_tn", dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), dw.data_ptr(), _p(db), ws.data_ptr(), nb, M, N, K,
                  _stream())
         return dw, db
-    if sk_ok(SK_TN, M, N, K, dy2, x2):
-        if sk_pick((SK_TN, M, N, K, want_bias), lambda: _skgemm(SK_TN, dy2, x2, None, dw, db, M, N, K),
-                   lambda: (torch.mm(dy2.t(), x2), colsum(dy2) if want_bias else None)):
-            _skgemm(SK_TN, dy2, x2, None, dw, db, M, N, K)
-            return dw, db
-    torch.mm(dy2.t(), x2, out=dw)
-    return dw, (colsum(dy2, out=db) if want_bias else None)
+    dy2, x2 = _sk_operand(dy2, "output gradient"), _sk_operand(x2, "input")
+    _skgemm(SK_TN, dy2, x2, None, dw, db, M, N, K)
+    return dw, db
 
 
 class LinearFn(torch.autograd.Function):
@@ -980,10 +973,11 @@ class LinearFn(torch.autograd.Function):
 
 
 def linear(x, w, bias=None):
-    """nn.Linear on tokens: MFMA kernels (tall-skinny / short GEMM) where a shape fits, the library GEMM otherwise."""
-    if x.is_cuda and x.dtype == torch.float32 and w.dim() == 2:
-        return LinearFn.apply(x, w, bias)
-    return torch.nn.functional.linear(x, w, bias)
+    """nn.Linear on tokens: the MFMA kernels (tall-skinny / short GEMM); raises for anything they do not take."""
+    _need_gpu(x)
+    if x.dtype != torch.float32 or w.dim() != 2:
+        raise RuntimeError(f"adnm_hip linear: needs fp32 tokens and a 2-D weight, got {x.dtype}, weight {tuple(w.shape)}")
+    return LinearFn.apply(x, w, bias)
 
 
 # ------------------------------------------------------------------------------------------- K1b chunked scan
@@ -1071,9 +1065,10 @@ class IGateFn(torch.autograd.Function):
 
 
 def igate(x, enhance, threshold):
-    if x.is_cuda and x.numel() % 4 == 0 and x.dtype in _DT and enhance.dtype == torch.float32:
-        return IGateFn.apply(x, enhance, threshold)
-    return torch.nn.functional.silu(enhance * (x - threshold))
+    _need_gpu(x)
+    if x.numel() % 4 or x.dtype not in _DT or enhance.dtype != torch.float32:
+        _unsupported("igate", f"needs fp32/bf16 tokens with a multiple of 4 elements and fp32 scalars, got {x.dtype} x {x.numel()}")
+    return IGateFn.apply(x, enhance, threshold)
 
 
 class SkipGateFn(torch.autograd.Function):
@@ -1189,9 +1184,10 @@ class TokMeanTapFn(torch.autograd.Function):
 
 def tokmean_tap(x):
     """-> (alias of x, (B, C) mean over tokens).  Callers should hand the alias to x's later consumers."""
-    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] % 4 == 0:
-        return TokMeanTapFn.apply(x)
-    return x, x.mean(1)
+    _need_gpu(x)
+    if x.dtype != torch.float32 or x.dim() != 3 or x.shape[-1] % 4:
+        _unsupported("tokmean_tap", f"needs fp32 (B, L, C) tokens with 4 | C, got {x.dtype} {tuple(x.shape)}")
+    return TokMeanTapFn.apply(x)
 
 
 class Conv1d3Fn(torch.autograd.Function):
@@ -1221,9 +1217,10 @@ class Conv1d3Fn(torch.autograd.Function):
 
 
 def conv1d3(x, w, bias):
-    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[1] == 1 and w.numel() == 3 and x.shape[0] * x.shape[2] <= (1 << 20):
-        return Conv1d3Fn.apply(x, w, bias)
-    return torch.nn.functional.conv1d(x, w, bias, padding=1)
+    _need_gpu(x)
+    if x.dtype != torch.float32 or x.dim() != 3 or x.shape[1] != 1 or w.numel() != 3 or x.shape[0] * x.shape[2] > (1 << 20):
+        _unsupported("conv1d3", f"is nn.Conv1d(1, 1, 3, padding=1) on fp32 (B, 1, n) with B*n <= 2^20, got {x.dtype} {tuple(x.shape)}, weight {tuple(w.shape)}")
+    return Conv1d3Fn.apply(x, w, bias)
 
 
 class Attn4Fn(torch.autograd.Function):

@@ -16,7 +16,7 @@ void adnm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* adnm_last_error(void) { return g_err; }
-extern "C" int adnm_abi_version(void) { return 2; }   // 2: wlayout (dwconv), dres (rownorm_bwd), ldm (tokmean_bwd) arguments
+extern "C" int adnm_abi_version(void) { return 3; }   // 3: fused LayerNorm epilogue arguments of ssd_reduce_fwd, cast_* entry points
 
 // ---- profiler: OFF by default (one relaxed atomic load per launch).  When bench.py enables it, every kernel
 // launch of the library is bracketed by hipEventRecord on the stream it is launched on; adnm_prof_collect()

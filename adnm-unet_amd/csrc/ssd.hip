@@ -1,241 +1,316 @@
 // K1 — the SSD "linear-attention duality" reduction that every Mamba2 mixer of ADNM-UNet executes
 // (non_casual_linear_attn: ADNssd.py:252-299 single-group branch :278-284, Vssd.py:161-208 grouped :194-206),
-// with softplus(dt + dt_bias) (ADNssd.py:318) fused in:
+// with softplus(dt + dt_bias) (ADNssd.py:318) fused in and, where a token row fits one head block, the mixer's
+// LayerNorm(d_inner) (ADNssd.py:456) as the epilogue of pass 2:
 //
 //   w[b,l,h]    = softplus(dt_raw + dt_bias[h]) * exp(A_log[h])
 //   KV[b,h,n,p] = sum_l Bm[b,l,g,n] * x[b,l,h,p] * w[b,l,h]               (pass 1: global reduction over L)
 //   y[b,l,h,p]  = sum_n Cm[b,l,g,n] * KV[b,h,n,p] + D[h] * x[b,l,h,p]      (pass 2: streaming)      g = h % G
 //
-// There is no recurrence on this branch, so there is nothing to scan: it is a two-pass, HBM-bound reduction
-// (~2.3 FMA per byte).  Mapping: one lane per (token, head); the HB = min(64, pow2(H)) lanes of a token are
-// adjacent, so a token row is read as one contiguous 16*HB-byte segment and the shared Bm/Cm row is a
-// same-address broadcast.  Each lane keeps the N x P state of ITS head in registers (64 VGPRs at N=16, P=4)
-// for all the tokens it visits; no LDS in the forward inner loops.  Cross-lane sums over the tokens of a wave in
-// pass 1 are xor-shuffles; the backward pass keeps the states in LDS instead and gives a lane one (token, group), so
-// its sums over heads stay in registers (see ssd_bwd_kernel); cross-block sums go through
-// fp32 partials in the caller's workspace and a small deterministic second kernel — never atomics, so the
-// result is bitwise reproducible run to run.
+// There is no recurrence on this branch, so there is nothing to scan: both passes (and the backward pass) are HBM-bound
+// streams over the token rows whose arithmetic is three small dense contractions — exactly GEMM-shaped, so they run on
+// the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, an fmaf chain) and the vector ALU only applies w / D:
+//
+//   pass 1   KV_g[N x cols]  += Bm_g^T[N x 16 tok] . (x.w)[16 tok x cols]      (the reduction dimension is the token)
+//   pass 2   y[16 tok x cols] = Cm_g[16 tok x N]   . KV_g[N x cols]            (+ D x)
+//   backward t = Bm_g . dKV_g,  dCm_g = dy_g . KV_g^T,  dBm_g = (x.w)_g . dKV_g^T   (+ the per-token scalar chain to dt)
+//
+// Geometry: a workgroup = 4 waves on one batch item and one HEAD BLOCK = 64 consecutive x columns (16 heads of 4, or 8
+// of 8) = four 16-column MFMA blocks, each belonging to one B/C group.  A wave walks 16-token TILES: the tile's rows are
+// read from HBM with coalesced 16-byte loads (a whole 256-byte x row per 16 lanes), staged in the wave's own LDS slab
+// (no workgroup barrier in the loop), and the MFMA operands are read back from there in fragment order; results go the
+// same way back (LDS -> coalesced row stores).  KV / dKV of the head block live in registers as MFMA B operands for
+// the whole workgroup lifetime.  Cross-workgroup sums (pass 1 over token chunks; the per-head statistics of backward)
+// go through fp32 partials in the caller's workspace and a small deterministic fold — never atomics, so a step is
+// bitwise reproducible.  Deep maps (L <= 512) take one workgroup per (batch, head block): no partials, no fold.
 #include "adnm_common.h"
 
 namespace {
 
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
+constexpr int kTile = 16;         // tokens per wave tile = one MFMA block edge
+constexpr int kCols = 64;         // x columns per head block
+constexpr int kSX = kCols + 4;    // LDS row stride of a 64-column tile (+ one 16-byte access: conflict-free fragment reads)
 
-__host__ __device__ inline int heads_per_block(int64_t H) {
-  int l = 1;
-  while (l < 64 && l < H) l <<= 1;
-  return l;
+// column (inside the 64-column head block) of MFMA column j of column block c.  Column blocks are grouped by B/C
+// group: blocks [g*4/G, (g+1)*4/G) hold the heads hl = g + G*m of group g, head-major (u = m*P + p).
+template <int P, int G>
+__device__ __forceinline__ int memcol(int c, int j) {
+  constexpr int CPG = 4 / G;
+  const int g = c / CPG, u = 16 * (c % CPG) + j;
+  return (g + G * (u / P)) * P + (u % P);
+}
+// column of element u (0 .. 64/G-1) of group g in the same order
+template <int P, int G>
+__device__ __forceinline__ int groupcol(int g, int u) {
+  return (g + G * (u / P)) * P + (u % P);
 }
 
 struct Geo {
-  int hb;         // lanes (heads) per token inside a block
-  int slots;      // tokens in flight per block step
-  int nhb;        // head blocks (grid.y)
-  int tok1;       // tokens per block, reduction passes
-  int nchunk;     // blocks along L, reduction passes
-  int tok2;       // tokens per block, streaming passes
-  int nblk2;      // blocks along L, streaming passes
+  int nhb;      // head blocks (grid.y)
+  int tok;      // tokens per workgroup
+  int nchunk;   // workgroups along L
 };
-
-struct BwdGeo {
-  int nhb, tok, nblk;   // head blocks of kBwdHeadsHost heads, tokens per block, blocks along L
-};
-constexpr int kBwdHeadsHost = 16;
-inline BwdGeo make_bwd_geo(int64_t B, int64_t L, int64_t H, int64_t G) {
-  BwdGeo g;
-  g.nhb = (int)adnm_cdiv(H, kBwdHeadsHost);
-  const int64_t slots = kBlock / G;
-  int64_t per_lane = (B * L * g.nhb) / (slots * 1024);   // aim at ~1024 blocks, 1..8 tokens per lane
-  per_lane = per_lane < 1 ? 1 : (per_lane > 8 ? 8 : per_lane);
-  g.tok = (int)(slots * per_lane);
-  g.nblk = (int)adnm_cdiv(L, g.tok);
-  return g;
-}
-
-inline Geo make_geo(int64_t L, int64_t H, int64_t B = 4) {
+// tiles per wave: enough waves to fill the chip (>= 2048), at most 8 tiles per wave; small maps: one workgroup per (b, head block)
+inline Geo make_geo(int64_t B, int64_t L, int64_t H, int64_t P, bool reduction) {
   Geo g;
-  g.hb = heads_per_block(H);
-  g.slots = kBlock / g.hb;
-  g.nhb = (int)adnm_cdiv(H, g.hb);
-  // tokens a lane walks in the reduction passes: 16 on the big maps; on the deep 4x4 .. 16x16 maps fewer, so that the grid
-  // still has ~256 workgroups (a 16-step dependent load chain on 16 workgroups cost 18 us for a 64-token reduction)
-  int64_t per_lane = (B * L * g.nhb) / ((int64_t)g.slots * 256);
-  per_lane = per_lane < 2 ? 2 : (per_lane > 16 ? 16 : per_lane);
-  g.tok1 = g.slots * (int)per_lane;
-  g.nchunk = (int)adnm_cdiv(L, g.tok1);
-  g.tok2 = g.slots * 8;
-  g.nblk2 = (int)adnm_cdiv(L, g.tok2);
+  g.nhb = (int)adnm_cdiv(H * P, kCols);
+  const int64_t tiles = adnm_cdiv(L, kTile);
+  if (reduction && tiles <= 32) {   // no partials, no fold launch
+    g.tok = (int)(tiles * kTile);
+    g.nchunk = 1;
+    return g;
+  }
+  int64_t tpw = (B * g.nhb * tiles) / 2048;
+  tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
+  g.tok = (int)(kWaves * tpw * kTile);
+  g.nchunk = (int)adnm_cdiv(L, g.tok);
   return g;
 }
 
-template <typename T, int P>
-__device__ __forceinline__ void load_vec(const T* p, float (&v)[P]) {
+// ---- coalesced tile movers.  A 64-column tile: lane f = lane + 64 r (r < 4) owns columns 4q .. 4q+3 (q = lane & 15) of
+// token (lane >> 4) + 4 r: 16 lanes = one 256-byte row.  A KW-column tile (Bm / Cm rows): f = lane + 64 r over 16 * KW/4.
+template <typename T>
+__device__ __forceinline__ float4 ld_row4(const T* base, int64_t row, int64_t ld, int col, bool ok) {
+  return ok ? Io<T>::ld4(base + row * ld + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void lds_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 lds_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <typename T, int KW>
+__device__ __forceinline__ void stage_k_tile(const T* __restrict__ K, int64_t ldk, int64_t row0, int nvalid, float* sK, int lane) {
+  constexpr int SK = KW + 4, Q = KW / 4, TOT = kTile * Q, IT = (TOT + 63) / 64;
+  float4 v[IT];
 #pragma unroll
-  for (int i = 0; i < P; i += 4) {
-    float4 t = Io<T>::ld4(p + i);
-    v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+  for (int r = 0; r < IT; ++r) {
+    const int f = lane + 64 * r, t = f / Q, qq = f % Q;
+    v[r] = ld_row4<T>(K, row0 + t, ldk, 4 * qq, f < TOT && t < nvalid);
+  }
+#pragma unroll
+  for (int r = 0; r < IT; ++r) {
+    const int f = lane + 64 * r, t = f / Q, qq = f % Q;
+    if (f < TOT) lds_st4(sK + t * SK + 4 * qq, v[r]);
   }
 }
-template <typename T, int P>
-__device__ __forceinline__ void store_vec(T* p, const float (&v)[P]) {
-#pragma unroll
-  for (int i = 0; i < P; i += 4) Io<T>::st4(p + i, make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]));
-}
 
-// ------------------------------------------------------------------------------------------------
-// Reduction pass: part[b, chunk, h, n, p] = sum_{l in chunk} K[b,l,g,n] * V[b,l,h,p] * (WEIGHTED ? w : 1)
-// used for KV (K=Bm, V=x, weighted) and for dKV in backward (K=Cm, V=dy, unweighted).
-template <typename T, int P, int N, bool WEIGHTED>
-__global__ __launch_bounds__(kBlock) void ssd_outer_reduce_kernel(
-    const T* __restrict__ V, int64_t ldv, const T* __restrict__ K, int64_t ldk, const T* __restrict__ dt_raw,
-    int64_t lddt, int64_t dt_hs, const float* __restrict__ dt_bias, const float* __restrict__ A_log, int64_t p_hs,
-    float* __restrict__ part, int64_t L, int H, int G, int hb, int tok_per_block, int nchunk) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [hb][N*P]
-  const int hl = threadIdx.x & (hb - 1);
-  const int slot = threadIdx.x / hb;
-  const int slots = kBlock / hb;
-  const int h = blockIdx.y * hb + hl;
+// ================================================================================================ pass 1
+// out[b, chunk, h, n, p] = sum_{l in chunk} K[b,l,g,n] * V[b,l,h,p] * (WEIGHTED ? w[b,l,h] : 1)
+// used for KV (K = Bm, V = x, weighted) and for dKV in backward (K = Cm, V = dy, unweighted).
+template <typename T, int P, int N, int G, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock) void ssd_kv_kernel(const T* __restrict__ V, int64_t ldv, const T* __restrict__ K, int64_t ldk,
+                                                        const T* __restrict__ dt_raw, int64_t lddt, int64_t dt_hs,
+                                                        const float* __restrict__ dt_bias, const float* __restrict__ A_log, int64_t p_hs,
+                                                        float* __restrict__ out, int64_t out_bstride, int64_t out_cstride, int64_t L, int H,
+                                                        int tok_per_block) {
+  constexpr int KW = G * N, SK = KW + 4, HBK = kCols / P, CPG = 4 / G;
+  constexpr int kSlab = kTile * kSX + kTile * SK;   // floats per wave (>= 1024 / kWaves * ... : the reduction reuses 4 x 1024)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* sX = smem + wave * kSlab;
+  float* sK = sX + kTile * kSX;
+  const int b = blockIdx.z, hb0 = blockIdx.y * HBK, col0 = hb0 * P;
+  const int64_t l_begin = (int64_t)blockIdx.x * tok_per_block;
+  const int64_t l_end = l_begin + tok_per_block < L ? l_begin + tok_per_block : L;
+  const int q = lane & 15, hl = (4 * q) / P, h = hb0 + hl;
   const bool hv = h < H;
-  const int b = blockIdx.z;
-  const int64_t l0 = (int64_t)blockIdx.x * tok_per_block;
-  const int64_t l1 = (l0 + tok_per_block < L) ? l0 + tok_per_block : L;
-  float acc[N][P];
-#pragma unroll
-  for (int n = 0; n < N; ++n)
-#pragma unroll
-    for (int p = 0; p < P; ++p) acc[n][p] = 0.f;
   float a = 0.f, bias = 0.f;
   if (WEIGHTED && hv) {
     a = __expf(A_log[h * p_hs]);
     bias = dt_bias[h * p_hs];
   }
-  const int g = hv ? (h % G) : 0;
-  if (hv) {
-    for (int64_t l = l0 + slot; l < l1; l += slots) {
-      const int64_t row = (int64_t)b * L + l;
-      float v[P], k[N];
-      load_vec<T, P>(V + row * ldv + (int64_t)h * P, v);
-      load_vec<T, N>(K + row * ldk + g * N, k);
+  const int i15 = lane & 15, kk = lane >> 4;
+  int mc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) mc[c] = memcol<P, G>(c, i15);
+  f32x4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (int)((l_end - l_begin + kTile - 1) / kTile);
+  for (int tile = wave; tile < ntiles; tile += kWaves) {
+    const int64_t t0 = l_begin + (int64_t)tile * kTile;
+    const int nvalid = (int)(l_end - t0 < kTile ? l_end - t0 : kTile);
+    const int64_t row0 = (int64_t)b * L + t0;
+    float4 xv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = kk + 4 * r;
+      const bool ok = hv && t < nvalid;
+      xv[r] = ld_row4<T>(V, row0 + t, ldv, col0 + 4 * q, ok);
       if (WEIGHTED) {
-        const float w = softplusf_(Io<T>::ld(dt_raw + row * lddt + h * dt_hs) + bias) * a;
-#pragma unroll
-        for (int p = 0; p < P; ++p) v[p] *= w;
+        const float z = ok ? Io<T>::ld(dt_raw + (row0 + t) * lddt + (int64_t)h * dt_hs) + bias : 0.f;
+        const float w = ok ? softplusf_(z) * a : 0.f;
+        xv[r].x *= w; xv[r].y *= w; xv[r].z *= w; xv[r].w *= w;
       }
-#pragma unroll
-      for (int n = 0; n < N; ++n)
-#pragma unroll
-        for (int p = 0; p < P; ++p) acc[n][p] = fmaf(k[n], v[p], acc[n][p]);
     }
+    stage_k_tile<T, KW>(K, ldk, row0, nvalid, sK, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds_st4(sX + (kk + 4 * r) * kSX + 4 * q, xv[r]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int tok = 4 * s + kk;
+      float av[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) av[g] = i15 < N ? sK[tok * SK + g * N + i15] : 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c / CPG], sX[tok * kSX + mc[c]], acc[c], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
-  // fold the token slots that share a wave, then the waves of the block through LDS
+  // sum the 4 waves through LDS (fixed order), then one store of the head block's N x 64 state.  MFMA D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
+  __syncthreads();
+  float* red = smem;
 #pragma unroll
-  for (int n = 0; n < N; ++n)
+  for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int p = 0; p < P; ++p) acc[n][p] = wave_sum_from(acc[n][p], hb);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int wv = 1; wv < kWaves; ++wv) {
-    if (wave == wv && lane < hb) {
+    for (int r = 0; r < 4; ++r) red[wave * 1024 + (c * 4 + r) * 64 + lane] = acc[c][r];
+  __syncthreads();
+  float* dst = out + (int64_t)b * out_bstride + (int64_t)blockIdx.x * out_cstride;
 #pragma unroll
-      for (int n = 0; n < N; ++n)
-#pragma unroll
-        for (int p = 0; p < P; p += 4)
-          *reinterpret_cast<float4*>(smem + ((n * P + p) / 4 * hb + lane) * 4) =
-              make_float4(acc[n][p], acc[n][p + 1], acc[n][p + 2], acc[n][p + 3]);
-    }
-    __syncthreads();
-    if (wave == 0 && lane < hb) {
-#pragma unroll
-      for (int n = 0; n < N; ++n)
-#pragma unroll
-        for (int p = 0; p < P; p += 4) {
-          float4 t = *reinterpret_cast<const float4*>(smem + ((n * P + p) / 4 * hb + lane) * 4);
-          acc[n][p] += t.x; acc[n][p + 1] += t.y; acc[n][p + 2] += t.z; acc[n][p + 3] += t.w;
-        }
-    }
-    __syncthreads();
-  }
-  if (wave == 0 && lane < hb && hv) {
-    float* dst = part + (((int64_t)b * nchunk + blockIdx.x) * H + h) * (N * P);
-#pragma unroll
-    for (int n = 0; n < N; ++n)
-#pragma unroll
-      for (int p = 0; p < P; p += 4)
-        *reinterpret_cast<float4*>(dst + n * P + p) = make_float4(acc[n][p], acc[n][p + 1], acc[n][p + 2], acc[n][p + 3]);
+  for (int k = 0; k < 1024 / kBlock; ++k) {
+    const int e = threadIdx.x + kBlock * k;
+    const float v = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+    const int cr = e >> 6, ln = e & 63, c = cr >> 2, r = cr & 3;
+    const int n = (ln >> 4) * 4 + r, col = memcol<P, G>(c, ln & 15), hh = hb0 + col / P;
+    if (n < N && hh < H) dst[((int64_t)hh * N + n) * P + (col % P)] = v;
   }
 }
 
-// out[b, e] = sum_k part[b, k, e],  e in [0, E)
-__global__ __launch_bounds__(256) void ssd_fold_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                       int nk, int64_t E) {
+// out[b, e] = sum_k part[b, k, e],  e in [0, E): 4 k-slices per workgroup, 4 independent loads in flight per lane
+__global__ __launch_bounds__(256) void ssd_fold_kernel(const float* __restrict__ part, float* __restrict__ out, int nk, int64_t E) {
   __shared__ float sm[4][64];
   const int b = blockIdx.y;
   const int e_local = threadIdx.x & 63, ks = threadIdx.x >> 6;
   const int64_t e = (int64_t)blockIdx.x * 64 + e_local;
-  float t = 0.f;
-  if (e < E)
-    for (int k = ks; k < nk; k += 4) t += part[((int64_t)b * nk + k) * E + e];
-  sm[ks][e_local] = t;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  if (e < E) {
+    const float* p = part + (int64_t)b * nk * E + e;
+    int k = ks;
+    for (; k + 12 < nk; k += 16) {
+      t0 += p[(int64_t)k * E];
+      t1 += p[(int64_t)(k + 4) * E];
+      t2 += p[(int64_t)(k + 8) * E];
+      t3 += p[(int64_t)(k + 12) * E];
+    }
+    for (; k < nk; k += 4) t0 += p[(int64_t)k * E];
+  }
+  sm[ks][e_local] = (t0 + t1) + (t2 + t3);
   __syncthreads();
   if (ks == 0 && e < E) out[(int64_t)b * E + e] = (sm[0][e_local] + sm[1][e_local]) + (sm[2][e_local] + sm[3][e_local]);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Streaming pass: y = Cm . KV + D x
-template <typename T, int P, int N>
-__global__ __launch_bounds__(kBlock) void ssd_apply_kernel(const T* __restrict__ x, int64_t ldx,
-                                                           const T* __restrict__ Cm, int64_t ldc,
-                                                           const float* __restrict__ D, int64_t p_hs,
-                                                           const float* __restrict__ kv, T* __restrict__ y,
-                                                           int64_t ldy, int64_t L, int H, int G, int hb,
+// ================================================================================================ pass 2
+// y = Cm . KV + D x   (+ LayerNorm over the token row as the epilogue when the row is one head block: H*P == 64)
+template <typename T, int P, int N, int G, bool LN>
+__global__ __launch_bounds__(kBlock) void ssd_apply_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ Cm, int64_t ldc,
+                                                           const float* __restrict__ D, int64_t p_hs, const float* __restrict__ kv,
+                                                           T* __restrict__ y, int64_t ldy, const float* __restrict__ ln_w,
+                                                           const float* __restrict__ ln_b, T* __restrict__ yn, int64_t ldyn,
+                                                           float* __restrict__ mu, float* __restrict__ rstd, float eps, int64_t L, int H,
                                                            int tok_per_block) {
-  const int hl = threadIdx.x & (hb - 1);
-  const int slot = threadIdx.x / hb;
-  const int slots = kBlock / hb;
-  const int h = blockIdx.y * hb + hl;
-  if (h >= H) return;
-  const int b = blockIdx.z;
-  const int64_t l0 = (int64_t)blockIdx.x * tok_per_block;
-  const int64_t l1 = (l0 + tok_per_block < L) ? l0 + tok_per_block : L;
-  float s[N][P];
-  const float* src = kv + ((int64_t)b * H + h) * (N * P);
+  constexpr int KW = G * N, SK = KW + 4, HBK = kCols / P, CPG = 4 / G, NS = N / 4;
+  constexpr int kSlab = kTile * kSX + kTile * SK;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* sX = smem + wave * kSlab;
+  float* sC = sX + kTile * kSX;
+  const int b = blockIdx.z, hb0 = blockIdx.y * HBK, col0 = hb0 * P;
+  const int64_t l_begin = (int64_t)blockIdx.x * tok_per_block;
+  const int64_t l_end = l_begin + tok_per_block < L ? l_begin + tok_per_block : L;
+  const int q = lane & 15, i15 = lane & 15, kk = lane >> 4;
+  const bool cv = col0 + 4 * q < H * P;   // this lane's 4 columns exist
+  // KV as MFMA B operands: kvr[c][s] = KV[h(c, j)][n = kk*NS + s][p(c, j)]  (the k index is permuted identically on the A side)
+  float kvr[4][NS], Dh[4];
+  int mc[4];
 #pragma unroll
-  for (int n = 0; n < N; ++n)
+  for (int c = 0; c < 4; ++c) {
+    mc[c] = memcol<P, G>(c, i15);
+    const int hh = hb0 + mc[c] / P;
+    const bool ok = hh < H;
+    Dh[c] = ok ? D[hh * p_hs] : 0.f;
 #pragma unroll
-    for (int p = 0; p < P; p += 4) {
-      float4 t = *reinterpret_cast<const float4*>(src + n * P + p);
-      s[n][p] = t.x; s[n][p + 1] = t.y; s[n][p + 2] = t.z; s[n][p + 3] = t.w;
+    for (int s = 0; s < NS; ++s) kvr[c][s] = ok ? kv[(((int64_t)b * H + hh) * N + kk * NS + s) * P + (mc[c] % P)] : 0.f;
+  }
+  float4 lw = make_float4(0.f, 0.f, 0.f, 0.f), lb = lw;
+  if (LN) {
+    lw = *reinterpret_cast<const float4*>(ln_w + 4 * q);
+    lb = *reinterpret_cast<const float4*>(ln_b + 4 * q);
+  }
+  const int ntiles = (int)((l_end - l_begin + kTile - 1) / kTile);
+  for (int tile = wave; tile < ntiles; tile += kWaves) {
+    const int64_t t0 = l_begin + (int64_t)tile * kTile;
+    const int nvalid = (int)(l_end - t0 < kTile ? l_end - t0 : kTile);
+    const int64_t row0 = (int64_t)b * L + t0;
+    float4 xv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xv[r] = ld_row4<T>(x, row0 + kk + 4 * r, ldx, col0 + 4 * q, cv && kk + 4 * r < nvalid);
+    stage_k_tile<T, KW>(Cm, ldc, row0, nvalid, sC, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds_st4(sX + (kk + 4 * r) * kSX + 4 * q, xv[r]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // A[i = token][k]: lane (i, kk) holds Cm[token i][g*N + kk*NS + s] for step s — one 8- or 16-byte LDS read
+      float av[NS];
+      const float* ap = sC + i15 * SK + (c / CPG) * N + kk * NS;
+      if (NS == 4) {
+        const float4 t = lds_ld4(ap);
+        av[0] = t.x; av[1] = t.y; av[NS - 2] = t.z; av[NS - 1] = t.w;
+      } else {
+        av[0] = ap[0]; av[1] = ap[1];
+      }
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], kvr[c][s], acc, 0, 0, 0);
+      // D layout: row = token kk*4 + r, column j -> this lane's column mc[c]; the result replaces x in the slab
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* p = sX + (kk * 4 + r) * kSX + mc[c];
+        *p = fmaf(Dh[c], *p, acc[r]);
+      }
     }
-  const float Dh = D[h * p_hs];
-  const int g = h % G;
-  for (int64_t l = l0 + slot; l < l1; l += slots) {
-    const int64_t row = (int64_t)b * L + l;
-    float v[P], c[N], o[P];
-    load_vec<T, P>(x + row * ldx + (int64_t)h * P, v);
-    load_vec<T, N>(Cm + row * ldc + g * N, c);
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int p = 0; p < P; ++p) o[p] = Dh * v[p];
+    for (int r = 0; r < 4; ++r) {
+      const int t = kk + 4 * r;
+      const float4 v = lds_ld4(sX + t * kSX + 4 * q);
+      const bool ok = cv && t < nvalid;
+      if (ok) Io<T>::st4(y + (row0 + t) * ldy + col0 + 4 * q, v);
+      if (LN) {   // the 16 lanes of a token hold its whole row: statistics by xor-shuffles inside the 16-lane group
+        float s1 = (v.x + v.y) + (v.z + v.w);
 #pragma unroll
-    for (int n = 0; n < N; ++n)
+        for (int o = 1; o < 16; o <<= 1) s1 += __shfl_xor(s1, o, 64);
+        const float m = s1 * (1.0f / kCols);
+        const float dx0 = v.x - m, dx1 = v.y - m, dx2 = v.z - m, dx3 = v.w - m;
+        float s2 = (dx0 * dx0 + dx1 * dx1) + (dx2 * dx2 + dx3 * dx3);
 #pragma unroll
-      for (int p = 0; p < P; ++p) o[p] = fmaf(c[n], s[n][p], o[p]);
-    store_vec<T, P>(y + row * ldy + (int64_t)h * P, o);
+        for (int o = 1; o < 16; o <<= 1) s2 += __shfl_xor(s2, o, 64);
+        const float rs = rsqrtf(s2 * (1.0f / kCols) + eps);
+        if (ok) {
+          Io<T>::st4(yn + (row0 + t) * ldyn + 4 * q, make_float4(fmaf(dx0 * rs, lw.x, lb.x), fmaf(dx1 * rs, lw.y, lb.y), fmaf(dx2 * rs, lw.z, lb.z),
+                                                                fmaf(dx3 * rs, lw.w, lb.w)));
+          if (q == 0) {
+            mu[row0 + t] = m;
+            rstd[row0 + t] = rs;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Backward streaming pass.  Per (token, head):
+// ================================================================================================ backward
+// Per (token, head), with z = dt_raw + dt_bias, w = softplus(z) a:
 //   t[p]   = sum_n Bm[n] dKV[n][p]          dx[p] = D dy[p] + w t[p]
-//   dw     = sum_p t[p] x[p]                ddt_raw = dw * a * sigmoid(dt_raw + bias)
+//   dw     = sum_p t[p] x[p]                ddt_raw = dw * a * sigmoid(z)
 //   dCm[n] = sum_{h in g} sum_p dy[p] KV[n][p]        dBm[n] = sum_{h in g} w sum_p dKV[n][p] x[p]
 //   dD += sum_p dy x ;  ddt_bias += ddt_raw ;  dA_log += dw * w
-// Mapping: a block owns kBwdHeads heads of one batch item; their KV / dKV states sit in LDS (every lane of a group reads
-// the same address: a broadcast).  A lane owns one (token, group) and walks the heads of its group, so the sums over heads
-// that dBm / dCm need are plain register accumulations — the earlier (token, head)-per-lane version spent its time in the
-// 96 cross-lane shuffles per token that this removes.  hpart: per (b, token block) partial of [dD | ddt_bias | dA_log];
-// bcpart: per head-block partial of [dBm | dCm] rows when H spans several head blocks (else written straight out).
-constexpr int kBwdHeads = 16;
-
+// hpart: per (b, token block) partial of [dD | ddt_bias | dA_log]; bcpart: per head-block partial of [dBm | dCm] rows when
+// H spans several head blocks (else written straight out).
 template <typename T, int P, int N, int G>
 __global__ __launch_bounds__(kBlock) void ssd_bwd_kernel(
     const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x, int64_t ldx, const T* __restrict__ Bm, int64_t ldb,
@@ -243,116 +318,199 @@ __global__ __launch_bounds__(kBlock) void ssd_bwd_kernel(
     const float* __restrict__ D, int64_t p_hs, const float* __restrict__ kv, const float* __restrict__ dkv, T* __restrict__ dx,
     int64_t lddx, T* __restrict__ dBm, int64_t lddb, T* __restrict__ dCm, int64_t lddc, T* __restrict__ ddt_raw, int64_t ldddt,
     float* __restrict__ hpart, float* __restrict__ bcpart, int64_t L, int H, int tok_per_block, int nblk, int nhb) {
-  constexpr int HPL = kBwdHeads / G;      // heads per lane
-  constexpr int SST = N * P + 4;          // LDS floats per head: +4 keeps float4 alignment and staggers the banks of the G groups
-  __shared__ __attribute__((aligned(16))) float sS[kBwdHeads * SST];
-  __shared__ __attribute__((aligned(16))) float sD[kBwdHeads * SST];
-  __shared__ float sc[kBwdHeads][3];                  // exp(A_log), dt_bias, D
-  __shared__ float sred[kWaves][kBwdHeads * 3];
-  __shared__ float sacc[HPL * 3][kBlock];             // per-thread [dD, ddt_bias, dA_log] of each of its heads (column = thread: no conflicts)
-  const int b = blockIdx.z, h0 = blockIdx.y * kBwdHeads;
-  for (int i = threadIdx.x; i < kBwdHeads * N * P / 4; i += kBlock) {
-    const int hd = i / (N * P / 4), r = i % (N * P / 4);
-    float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
-    if (h0 + hd < H) {
-      u = *reinterpret_cast<const float4*>(kv + ((int64_t)b * H + h0 + hd) * (N * P) + r * 4);
-      v = *reinterpret_cast<const float4*>(dkv + ((int64_t)b * H + h0 + hd) * (N * P) + r * 4);
-    }
-    *reinterpret_cast<float4*>(sS + hd * SST + r * 4) = u;
-    *reinterpret_cast<float4*>(sD + hd * SST + r * 4) = v;
-  }
-  if (threadIdx.x < kBwdHeads) {
-    const int h = h0 + threadIdx.x;
-    const bool ok = h < H;
-    sc[threadIdx.x][0] = ok ? __expf(A_log[h * p_hs]) : 0.f;
-    sc[threadIdx.x][1] = ok ? dt_bias[h * p_hs] : 0.f;
-    sc[threadIdx.x][2] = ok ? D[h * p_hs] : 0.f;
-  }
-  __syncthreads();
-  const int g = threadIdx.x & (G - 1), slot = threadIdx.x / G;
-  constexpr int slots = kBlock / G;
-  const int64_t l0 = (int64_t)blockIdx.x * tok_per_block;
-  const int64_t l1 = (l0 + tok_per_block < L) ? l0 + tok_per_block : L;
-#pragma unroll
-  for (int j = 0; j < HPL * 3; ++j) sacc[j][threadIdx.x] = 0.f;
-  for (int64_t l = l0 + slot; l < l1; l += slots) {
-    const int64_t row = (int64_t)b * L + l;
-    float kb[N], dBv[N], dCv[N];
-    load_vec<T, N>(Bm + row * ldb + g * N, kb);
-#pragma unroll
-    for (int n = 0; n < N; ++n) dBv[n] = dCv[n] = 0.f;
-#pragma unroll 1
-    for (int j = 0; j < HPL; ++j) {   // not unrolled: keeps the live state at one head (the accumulators above live in LDS for that)
-      const int hl = g + G * j, h = h0 + hl;
-      if (h >= H) continue;
-      float v[P], gy[P], t[P], o[P];
-      load_vec<T, P>(x + row * ldx + (int64_t)h * P, v);
-      load_vec<T, P>(dy + row * lddy + (int64_t)h * P, gy);
-      const float a = sc[hl][0], z = Io<T>::ld(dt_raw + row * lddt + h * dt_hs) + sc[hl][1], Dh = sc[hl][2];
-      const float w = softplusf_(z) * a;
-      const float* S = sS + hl * SST;
-      const float* Dk = sD + hl * SST;
-      float dd = 0.f, dw = 0.f;
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        t[p] = 0.f;
-        dd = fmaf(gy[p], v[p], dd);
-      }
-#pragma unroll
-      for (int n = 0; n < N; ++n) {
-        float sv[P], dv[P];
-#pragma unroll
-        for (int p = 0; p < P; p += 4) {
-          const float4 s4 = *reinterpret_cast<const float4*>(S + n * P + p), d4 = *reinterpret_cast<const float4*>(Dk + n * P + p);
-          sv[p] = s4.x; sv[p + 1] = s4.y; sv[p + 2] = s4.z; sv[p + 3] = s4.w;
-          dv[p] = d4.x; dv[p + 1] = d4.y; dv[p + 2] = d4.z; dv[p + 3] = d4.w;
-        }
-        float cb = 0.f, cc = 0.f;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          t[p] = fmaf(kb[n], dv[p], t[p]);
-          cb = fmaf(dv[p], v[p], cb);
-          cc = fmaf(gy[p], sv[p], cc);
-        }
-        dBv[n] = fmaf(cb, w, dBv[n]);
-        dCv[n] += cc;
-      }
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        o[p] = fmaf(w, t[p], Dh * gy[p]);
-        dw = fmaf(t[p], v[p], dw);
-      }
-      store_vec<T, P>(dx + row * lddx + (int64_t)h * P, o);
-      const float dz = dw * a * sigmoidf_(z);
-      Io<T>::st(ddt_raw + row * ldddt + h * dt_hs, dz);
-      sacc[j * 3][threadIdx.x] += dd;
-      sacc[j * 3 + 1][threadIdx.x] += dz;
-      sacc[j * 3 + 2][threadIdx.x] += dw * w;
-    }
-    if (nhb == 1) {
-      store_vec<T, N>(dBm + row * lddb + g * N, dBv);
-      store_vec<T, N>(dCm + row * lddc + g * N, dCv);
-    } else {
-      float* dst = bcpart + (((int64_t)blockIdx.y * gridDim.z + b) * L + l) * (2 * G * N);
-#pragma unroll
-      for (int n = 0; n < N; n += 4) {
-        *reinterpret_cast<float4*>(dst + g * N + n) = make_float4(dBv[n], dBv[n + 1], dBv[n + 2], dBv[n + 3]);
-        *reinterpret_cast<float4*>(dst + G * N + g * N + n) = make_float4(dCv[n], dCv[n + 1], dCv[n + 2], dCv[n + 3]);
-      }
-    }
-  }
-  // per-head statistics: sum over the token slots of the wave (lanes of equal g), then over the waves through LDS
+  constexpr int KW = G * N, SK = KW + 4, HBK = kCols / P, CPG = 4 / G, NS = N / 4, GS = 16 / G;   // GS: k-steps over a group's 64/G columns
+  constexpr int kSlab = 2 * kTile * kSX + 3 * kTile * SK + 3 * kTile * HBK;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int j = 0; j < HPL; ++j)
+  float* sDY = smem + wave * kSlab;
+  float* sX = sDY + kTile * kSX;          // x, then dx in place
+  float* sB = sX + kTile * kSX;           // Bm rows
+  float* sdB = sB + kTile * SK;
+  float* sdC = sdB + kTile * SK;
+  float* sW = sdC + kTile * SK;           // w, a*sigmoid(z), ddt per (token, head of the block)
+  float* sS = sW + kTile * HBK;
+  float* sDdt = sS + kTile * HBK;
+  const int b = blockIdx.z, hb0 = blockIdx.y * HBK, col0 = hb0 * P;
+  const int64_t l_begin = (int64_t)blockIdx.x * tok_per_block;
+  const int64_t l_end = l_begin + tok_per_block < L ? l_begin + tok_per_block : L;
+  const int q = lane & 15, i15 = lane & 15, kk = lane >> 4;
+  const int hl_q = (4 * q) / P, h_q = hb0 + hl_q;
+  const bool hv = h_q < H;
+  const float a = hv ? __expf(A_log[h_q * p_hs]) : 0.f, bias = hv ? dt_bias[h_q * p_hs] : 0.f;
+  // register-resident MFMA B operands of the head block
+  float dkvT[4][NS], Dh[4];
+  int mc[4];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float v = wave_sum_from(sacc[j * 3 + k][threadIdx.x], G);
-      if (lane < G) sred[wave][(g + G * j) * 3 + k] = v;
+  for (int c = 0; c < 4; ++c) {
+    mc[c] = memcol<P, G>(c, i15);
+    const int hh = hb0 + mc[c] / P;
+    const bool ok = hh < H;
+    Dh[c] = ok ? D[hh * p_hs] : 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) dkvT[c][s] = ok ? dkv[(((int64_t)b * H + hh) * N + kk * NS + s) * P + (mc[c] % P)] : 0.f;
+  }
+  // B[k = column u = 4 s + kk of group g][j = n]: the transposes of KV / dKV
+  float kvC[G][GS], dkvB[G][GS];
+  int gc[G][GS];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int s = 0; s < GS; ++s) {
+      const int col = groupcol<P, G>(g, 4 * s + kk), hh = hb0 + col / P;
+      gc[g][s] = col;
+      const bool ok = hh < H && i15 < N;
+      const int64_t o = (((int64_t)b * H + hh) * N + i15) * P + (col % P);
+      kvC[g][s] = ok ? kv[o] : 0.f;
+      dkvB[g][s] = ok ? dkv[o] : 0.f;
     }
+  float stD[4] = {0.f, 0.f, 0.f, 0.f}, stB[4] = {0.f, 0.f, 0.f, 0.f}, stA[4] = {0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (int)((l_end - l_begin + kTile - 1) / kTile);
+  for (int tile = wave; tile < ntiles; tile += kWaves) {
+    const int64_t t0 = l_begin + (int64_t)tile * kTile;
+    const int nvalid = (int)(l_end - t0 < kTile ? l_end - t0 : kTile);
+    const int64_t row0 = (int64_t)b * L + t0;
+    float4 gv[4], xv[4];
+    float wv[4], sv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = kk + 4 * r;
+      const bool ok = hv && t < nvalid;
+      gv[r] = ld_row4<T>(dy, row0 + t, lddy, col0 + 4 * q, ok);
+      xv[r] = ld_row4<T>(x, row0 + t, ldx, col0 + 4 * q, ok);
+      const float z = ok ? Io<T>::ld(dt_raw + (row0 + t) * lddt + (int64_t)h_q * dt_hs) + bias : 0.f;
+      wv[r] = ok ? softplusf_(z) * a : 0.f;
+      sv[r] = ok ? a * sigmoidf_(z) : 0.f;
+    }
+    stage_k_tile<T, KW>(Bm, ldb, row0, nvalid, sB, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = kk + 4 * r;
+      lds_st4(sDY + t * kSX + 4 * q, gv[r]);
+      lds_st4(sX + t * kSX + 4 * q, xv[r]);
+      sW[t * HBK + hl_q] = wv[r];    // P = 8: two lanes of a head write the same value
+      sS[t * HBK + hl_q] = sv[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- dCm = dy_g . KV_g^T,  dBm = (x w)_g . dKV_g^T     (rows = tokens, columns = n)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      f32x4 aC = f32x4{0.f, 0.f, 0.f, 0.f}, aB = aC;
+#pragma unroll
+      for (int s = 0; s < GS; ++s) {
+        const int col = gc[g][s];
+        const float a1 = sDY[i15 * kSX + col];
+        const float a2 = sX[i15 * kSX + col] * sW[i15 * HBK + col / P];
+        aC = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, kvC[g][s], aC, 0, 0, 0);
+        aB = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, dkvB[g][s], aB, 0, 0, 0);
+      }
+      if (i15 < N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sdC[(kk * 4 + r) * SK + g * N + i15] = aC[r];
+          sdB[(kk * 4 + r) * SK + g * N + i15] = aB[r];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // every read of x above precedes its replacement by dx below
+    // ---- t = Bm_g . dKV_g ; dx, dw, ddt and the per-head statistics
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float av[NS];
+      const float* ap = sB + i15 * SK + (c / CPG) * N + kk * NS;
+      if (NS == 4) {
+        const float4 t = lds_ld4(ap);
+        av[0] = t.x; av[1] = t.y; av[NS - 2] = t.z; av[NS - 1] = t.w;
+      } else {
+        av[0] = ap[0]; av[1] = ap[1];
+      }
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], dkvT[c][s], acc, 0, 0, 0);
+      const int hl = mc[c] / P;
+      const bool first = (mc[c] % P) == 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tok = kk * 4 + r;
+        float* px = sX + tok * kSX + mc[c];
+        const float xval = *px, gy = sDY[tok * kSX + mc[c]], w = sW[tok * HBK + hl];
+        *px = fmaf(w, acc[r], Dh[c] * gy);
+        float dw = acc[r] * xval, dd = gy * xval;   // sums over the P columns of the head: adjacent lanes
+#pragma unroll
+        for (int o = 1; o < P; o <<= 1) {
+          dw += __shfl_xor(dw, o, 64);
+          dd += __shfl_xor(dd, o, 64);
+        }
+        const float dz = dw * sS[tok * HBK + hl];
+        if (first) {
+          sDdt[tok * HBK + hl] = dz;
+          stD[c] += dd;
+          stB[c] += dz;
+          stA[c] += dw * w;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- coalesced stores
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = kk + 4 * r;
+      if (hv && t < nvalid) Io<T>::st4(dx + (row0 + t) * lddx + col0 + 4 * q, lds_ld4(sX + t * kSX + 4 * q));
+    }
+    {
+      constexpr int IT = (kTile * HBK + 63) / 64;
+#pragma unroll
+      for (int r = 0; r < IT; ++r) {
+        const int f = lane + 64 * r, t = f / HBK, hh = f % HBK;
+        if (f < kTile * HBK && t < nvalid && hb0 + hh < H) Io<T>::st(ddt_raw + (row0 + t) * ldddt + (int64_t)(hb0 + hh) * dt_hs, sDdt[t * HBK + hh]);
+      }
+    }
+    {
+      constexpr int Q = KW / 4, TOT = kTile * Q, IT = (TOT + 63) / 64;
+#pragma unroll
+      for (int r = 0; r < IT; ++r) {
+        const int f = lane + 64 * r, t = f / Q, qq = f % Q;
+        if (f < TOT && t < nvalid) {
+          const float4 vb = lds_ld4(sdB + t * SK + 4 * qq), vc = lds_ld4(sdC + t * SK + 4 * qq);
+          if (nhb == 1) {
+            Io<T>::st4(dBm + (row0 + t) * lddb + 4 * qq, vb);
+            Io<T>::st4(dCm + (row0 + t) * lddc + 4 * qq, vc);
+          } else {
+            float* dst = bcpart + (((int64_t)blockIdx.y * gridDim.z + b) * L + (t0 + t)) * (2 * KW);
+            *reinterpret_cast<float4*>(dst + 4 * qq) = vb;
+            *reinterpret_cast<float4*>(dst + KW + 4 * qq) = vc;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // per-head statistics: lanes with (column % P == 0) hold this wave's sums for head mc[c]/P over their 4 token rows per tile;
+  // fold the 4 kk rows by shuffles, the waves through LDS, one partial row per workgroup
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    stD[c] += __shfl_xor(stD[c], 16, 64); stD[c] += __shfl_xor(stD[c], 32, 64);
+    stB[c] += __shfl_xor(stB[c], 16, 64); stB[c] += __shfl_xor(stB[c], 32, 64);
+    stA[c] += __shfl_xor(stA[c], 16, 64); stA[c] += __shfl_xor(stA[c], 32, 64);
+  }
   __syncthreads();
-  if (threadIdx.x < kBwdHeads * 3) {
-    const int hl = threadIdx.x / 3, k = threadIdx.x % 3, h = h0 + hl;
-    if (h < H) hpart[(((int64_t)b * nblk + blockIdx.x) * 3 + k) * H + h] = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+  float* sred = smem;   // [kWaves][3][HBK]
+  if (kk == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if ((mc[c] % P) == 0) {
+        const int hl = mc[c] / P;
+        sred[(wave * 3 + 0) * HBK + hl] = stD[c];
+        sred[(wave * 3 + 1) * HBK + hl] = stB[c];
+        sred[(wave * 3 + 2) * HBK + hl] = stA[c];
+      }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 * HBK) {
+    const int k = threadIdx.x / HBK, hl = threadIdx.x % HBK, hh = hb0 + hl;
+    if (hh < H) {
+      const float v = (sred[(0 * 3 + k) * HBK + hl] + sred[(1 * 3 + k) * HBK + hl]) + (sred[(2 * 3 + k) * HBK + hl] + sred[(3 * 3 + k) * HBK + hl]);
+      hpart[(((int64_t)b * nblk + blockIdx.x) * 3 + k) * H + hh] = v;
+    }
   }
 }
 
@@ -376,7 +534,7 @@ struct Ws {
 };
 
 Ws carve(void* ws, int64_t B, int64_t L, int64_t H, int64_t P, int64_t N, int64_t G) {
-  const Geo g = make_geo(L, H, B);
+  const Geo gr = make_geo(B, L, H, P, true), gs = make_geo(B, L, H, P, false);
   Ws w;
   int64_t off = 0;
   auto take = [&](int64_t nfloat) {
@@ -384,11 +542,10 @@ Ws carve(void* ws, int64_t B, int64_t L, int64_t H, int64_t P, int64_t N, int64_
     off += adnm_align(nfloat * 4, 256);
     return p;
   };
-  w.part = take(B * g.nchunk * H * N * P);
+  w.part = take(gr.nchunk > 1 ? B * gr.nchunk * H * N * P : 0);
   w.dkv = take(B * H * N * P);
-  const BwdGeo bg = make_bwd_geo(B, L, H, G);
-  w.hpart = take(B * bg.nblk * 3 * H);
-  w.bcpart = take(bg.nhb > 1 ? (int64_t)bg.nhb * B * L * 2 * G * N : 0);
+  w.hpart = take(B * gs.nchunk * 3 * H);
+  w.bcpart = take(gs.nhb > 1 ? (int64_t)gs.nhb * B * L * 2 * G * N : 0);
   w.bytes = off;
   return w;
 }
@@ -398,73 +555,92 @@ int check_common(const char* who, int64_t B, int64_t L, int64_t H, int64_t P, in
   ADNM_REQUIRE((P == 4 && (N == 8 || N == 16)) || (P == 8 && N == 8),
                "%s: (headdim P=%lld, states-per-group N=%lld) not in {(4,8),(4,16),(8,8)}", who, (long long)P, (long long)N);
   ADNM_REQUIRE(G == 1 || G == 2 || G == 4, "%s: groups G=%lld not in {1,2,4}", who, (long long)G);
-  ADNM_REQUIRE(B <= 65535 && adnm_cdiv(H, 64) <= 65535, "%s: grid too large", who);
+  ADNM_REQUIRE(B <= 65535 && adnm_cdiv(H * P, kCols) <= 65535, "%s: grid too large", who);
   ADNM_REQUIRE(dtype == ADNM_F32 || dtype == ADNM_BF16, "%s: bad dtype %d", who, dtype);
   return ADNM_OK;
 }
 
-// supported (headdim, state) pairs: N*P <= 64 keeps the per-lane state in registers
-#define DISPATCH_PN(FN, ...)                                \
-  do {                                                      \
-    if (P == 4 && N == 8) FN<T, 4, 8>(__VA_ARGS__);         \
-    else if (P == 4 && N == 16) FN<T, 4, 16>(__VA_ARGS__);  \
-    else FN<T, 8, 8>(__VA_ARGS__);                          \
+// (headdim, state, groups) instantiations: the MFMA column-block <-> group map needs them at compile time
+#define DISPATCH_PNG(FN, ...)                                                                                   \
+  do {                                                                                                          \
+    if (P == 4 && N == 8) { if (G == 1) FN<T, 4, 8, 1>(__VA_ARGS__); else if (G == 2) FN<T, 4, 8, 2>(__VA_ARGS__); else FN<T, 4, 8, 4>(__VA_ARGS__); }       \
+    else if (P == 4 && N == 16) { if (G == 1) FN<T, 4, 16, 1>(__VA_ARGS__); else if (G == 2) FN<T, 4, 16, 2>(__VA_ARGS__); else FN<T, 4, 16, 4>(__VA_ARGS__); } \
+    else { if (G == 1) FN<T, 8, 8, 1>(__VA_ARGS__); else if (G == 2) FN<T, 8, 8, 2>(__VA_ARGS__); else FN<T, 8, 8, 4>(__VA_ARGS__); }                        \
   } while (0)
 
-template <typename T, int P, int N>
-void run_outer(bool weighted, const void* V, int64_t ldv, const void* K, int64_t ldk, const void* dt_raw, int64_t lddt,
-               int64_t dt_hs, const float* dt_bias, const float* A_log, int64_t p_hs, float* part, float* out, int64_t B,
-               int64_t L, int64_t H, int64_t G, hipStream_t st) {
-  const Geo g = make_geo(L, H, B);
+template <typename T, int P, int N, int G>
+int run_kv(bool weighted, const void* V, int64_t ldv, const void* K, int64_t ldk, const void* dt_raw, int64_t lddt, int64_t dt_hs,
+           const float* dt_bias, const float* A_log, int64_t p_hs, float* part, float* out, int64_t B, int64_t L, int64_t H, hipStream_t st) {
+  const Geo g = make_geo(B, L, H, P, true);
   const dim3 grid(g.nchunk, g.nhb, (unsigned)B);
-  const size_t smem = (size_t)g.hb * N * P * sizeof(float);
-  if (weighted)
-    { ADNM_PROF("ssd_outer_reduce", st, (double)sizeof(T) * B * L * (H * P + G * N + H)); ssd_outer_reduce_kernel<T, P, N, true><<<grid, kBlock, smem, st>>>((const T*)V, ldv, (const T*)K, ldk, (const T*)dt_raw, lddt,
-                                                                       dt_hs, dt_bias, A_log, p_hs, part, L, (int)H, (int)G,
-                                                                       g.hb, g.tok1, g.nchunk); }
-  else
-    { ADNM_PROF("ssd_outer_reduce", st, (double)sizeof(T) * B * L * (H * P + G * N)); ssd_outer_reduce_kernel<T, P, N, false><<<grid, kBlock, smem, st>>>((const T*)V, ldv, (const T*)K, ldk, nullptr, 0, 0, nullptr,
-                                                                        nullptr, 0, part, L, (int)H, (int)G, g.hb, g.tok1,
-                                                                        g.nchunk); }
+  constexpr int KW = G * N, kSlab = kTile * kSX + kTile * (KW + 4);
+  const size_t smem = sizeof(float) * (size_t)(kWaves * kSlab > 4096 ? kWaves * kSlab : 4096);
   const int64_t E = H * N * P;
-  { ADNM_PROF("ssd_fold", st, 4.0 * B * E * (g.nchunk + 1)); ssd_fold_kernel<<<dim3((unsigned)adnm_cdiv(E, 64), (unsigned)B), 256, 0, st>>>(part, out, g.nchunk, E); }
-}
-
-template <typename T, int P, int N>
-void run_apply(const void* x, int64_t ldx, const void* Cm, int64_t ldc, const float* D, int64_t p_hs, const float* kv, void* y,
-               int64_t ldy, int64_t B, int64_t L, int64_t H, int64_t G, hipStream_t st) {
-  const Geo g = make_geo(L, H, B);
-  { ADNM_PROF("ssd_apply", st, (double)sizeof(T) * B * L * (2 * H * P + G * N)); ssd_apply_kernel<T, P, N><<<dim3(g.nblk2, g.nhb, (unsigned)B), kBlock, 0, st>>>((const T*)x, ldx, (const T*)Cm, ldc, D, p_hs, kv,
-                                                                                  (T*)y, ldy, L, (int)H, (int)G, g.hb, g.tok2); }
-}
-
-template <typename T, int P, int N>
-void run_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* Bm, int64_t ldb, const void* Cm, int64_t ldc,
-             const void* dt_raw, int64_t lddt, int64_t dt_hs, const float* dt_bias, const float* A_log, const float* D,
-             int64_t p_hs, const float* kv, const float* dkv, void* dx, int64_t lddx, void* dBm, int64_t lddb, void* dCm,
-             int64_t lddc, void* ddt_raw, int64_t ldddt, float* hpart, float* bcpart, float* ddt_bias, float* dA_log, float* dD,
-             int64_t B, int64_t L, int64_t H, int64_t G, hipStream_t st) {
-  (void)Cm;
-  (void)ldc;
-  const BwdGeo g = make_bwd_geo(B, L, H, G);
-  const dim3 grid(g.nblk, g.nhb, (unsigned)B);
-#define ADNM_SSD_BWD(GG)                                                                                                              \
-  ssd_bwd_kernel<T, P, N, GG><<<grid, kBlock, 0, st>>>((const T*)dy, lddy, (const T*)x, ldx, (const T*)Bm, ldb, (const T*)dt_raw, lddt, \
-                                                       dt_hs, dt_bias, A_log, D, p_hs, kv, dkv, (T*)dx, lddx, (T*)dBm, lddb, (T*)dCm,   \
-                                                       lddc, (T*)ddt_raw, ldddt, hpart, bcpart, L, (int)H, g.tok, g.nblk, g.nhb)
-  {
-    ADNM_PROF("ssd_bwd", st, (double)sizeof(T) * B * L * (3 * H * P + 4 * G * N + 2 * H));
-    if (G == 1) ADNM_SSD_BWD(1);
-    else if (G == 2) ADNM_SSD_BWD(2);
-    else ADNM_SSD_BWD(4);
+  float* dst = g.nchunk > 1 ? part : out;
+  const int64_t bs = g.nchunk > 1 ? (int64_t)g.nchunk * E : E, cs = g.nchunk > 1 ? E : 0;
+  if (weighted) {
+    ADNM_ALLOW_LDS((ssd_kv_kernel<T, P, N, G, true>), smem, "ssd_kv");
+    ADNM_PROF("ssd_kv", st, (double)sizeof(T) * B * L * (H * P + (double)g.nhb * G * N + H));
+    ssd_kv_kernel<T, P, N, G, true><<<grid, kBlock, smem, st>>>((const T*)V, ldv, (const T*)K, ldk, (const T*)dt_raw, lddt, dt_hs, dt_bias, A_log,
+                                                                p_hs, dst, bs, cs, L, (int)H, g.tok);
+  } else {
+    ADNM_ALLOW_LDS((ssd_kv_kernel<T, P, N, G, false>), smem, "ssd_dkv");
+    ADNM_PROF("ssd_dkv", st, (double)sizeof(T) * B * L * (H * P + (double)g.nhb * G * N));
+    ssd_kv_kernel<T, P, N, G, false><<<grid, kBlock, smem, st>>>((const T*)V, ldv, (const T*)K, ldk, nullptr, 0, 0, nullptr, nullptr, 0, dst, bs, cs, L,
+                                                                 (int)H, g.tok);
   }
-#undef ADNM_SSD_BWD
+  if (g.nchunk > 1) {
+    ADNM_PROF("ssd_fold", st, 4.0 * B * E * (g.nchunk + 1));
+    ssd_fold_kernel<<<dim3((unsigned)adnm_cdiv(E, 64), (unsigned)B), 256, 0, st>>>(part, out, g.nchunk, E);
+  }
+  return ADNM_OK;
+}
+
+template <typename T, int P, int N, int G>
+int run_apply(const void* x, int64_t ldx, const void* Cm, int64_t ldc, const float* D, int64_t p_hs, const float* kv, void* y, int64_t ldy,
+              const float* ln_w, const float* ln_b, void* yn, int64_t ldyn, float* mu, float* rstd, float eps, int64_t B, int64_t L, int64_t H,
+              hipStream_t st) {
+  const Geo g = make_geo(B, L, H, P, false);
+  constexpr int KW = G * N, kSlab = kTile * kSX + kTile * (KW + 4);
+  const size_t smem = sizeof(float) * (size_t)kWaves * kSlab;
+  const dim3 grid(g.nchunk, g.nhb, (unsigned)B);
+  if (yn) {
+    ADNM_ALLOW_LDS((ssd_apply_kernel<T, P, N, G, true>), smem, "ssd_apply_ln");
+    ADNM_PROF("ssd_apply_ln", st, (double)sizeof(T) * B * L * (3 * H * P + G * N) + 8.0 * B * L);
+    ssd_apply_kernel<T, P, N, G, true><<<grid, kBlock, smem, st>>>((const T*)x, ldx, (const T*)Cm, ldc, D, p_hs, kv, (T*)y, ldy, ln_w, ln_b, (T*)yn, ldyn,
+                                                                   mu, rstd, eps, L, (int)H, g.tok);
+  } else {
+    ADNM_ALLOW_LDS((ssd_apply_kernel<T, P, N, G, false>), smem, "ssd_apply");
+    ADNM_PROF("ssd_apply", st, (double)sizeof(T) * B * L * (2 * H * P + (double)g.nhb * G * N));
+    ssd_apply_kernel<T, P, N, G, false><<<grid, kBlock, smem, st>>>((const T*)x, ldx, (const T*)Cm, ldc, D, p_hs, kv, (T*)y, ldy, nullptr, nullptr, nullptr,
+                                                                    0, nullptr, nullptr, 0.f, L, (int)H, g.tok);
+  }
+  return ADNM_OK;
+}
+
+template <typename T, int P, int N, int G>
+int run_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* Bm, int64_t ldb, const void* dt_raw, int64_t lddt,
+            int64_t dt_hs, const float* dt_bias, const float* A_log, const float* D, int64_t p_hs, const float* kv, const float* dkv, void* dx,
+            int64_t lddx, void* dBm, int64_t lddb, void* dCm, int64_t lddc, void* ddt_raw, int64_t ldddt, float* hpart, float* bcpart,
+            float* ddt_bias, float* dA_log, float* dD, int64_t B, int64_t L, int64_t H, hipStream_t st) {
+  const Geo g = make_geo(B, L, H, P, false);
+  constexpr int KW = G * N, HBK = kCols / P, kSlab = 2 * kTile * kSX + 3 * kTile * (KW + 4) + 3 * kTile * HBK;
+  const size_t smem = sizeof(float) * (size_t)kWaves * kSlab;
+  const dim3 grid(g.nchunk, g.nhb, (unsigned)B);
+  {
+    ADNM_ALLOW_LDS((ssd_bwd_kernel<T, P, N, G>), smem, "ssd_bwd");
+    ADNM_PROF("ssd_bwd", st, (double)sizeof(T) * B * L * (3 * H * P + (double)g.nhb * 3 * G * N + 2 * H));
+    ssd_bwd_kernel<T, P, N, G><<<grid, kBlock, smem, st>>>((const T*)dy, lddy, (const T*)x, ldx, (const T*)Bm, ldb, (const T*)dt_raw, lddt, dt_hs, dt_bias,
+                                                           A_log, D, p_hs, kv, dkv, (T*)dx, lddx, (T*)dBm, lddb, (T*)dCm, lddc, (T*)ddt_raw, ldddt, hpart,
+                                                           bcpart, L, (int)H, g.tok, g.nchunk, g.nhb);
+  }
   if (g.nhb > 1) {
     const int64_t tot = B * L * 2 * G * N;
-    { ADNM_PROF("ssd_bc_fold", st, 4.0 * tot * g.nhb); ssd_bc_fold_kernel<T><<<(unsigned)adnm_cdiv(tot, 256), 256, 0, st>>>(bcpart, g.nhb, B * L, (int)(G * N), (T*)dBm, lddb, (T*)dCm,
-                                                                         lddc); }
+    ADNM_PROF("ssd_bc_fold", st, 4.0 * tot * g.nhb);
+    ssd_bc_fold_kernel<T><<<(unsigned)adnm_cdiv(tot, 256), 256, 0, st>>>(bcpart, g.nhb, B * L, (int)(G * N), (T*)dBm, lddb, (T*)dCm, lddc);
   }
-  adnm_launch_fold("ssd_head_fold", hpart, (int)(B * g.nblk), 3 * (int)H, {dD, (int)H}, {ddt_bias, (int)H}, {dA_log, (int)H}, {nullptr, 0}, st);
+  adnm_launch_fold("ssd_head_fold", hpart, (int)(B * g.nchunk), 3 * (int)H, {dD, (int)H}, {ddt_bias, (int)H}, {dA_log, (int)H}, {nullptr, 0}, st);
+  return ADNM_OK;
 }
 
 }  // namespace
@@ -477,6 +653,7 @@ extern "C" int64_t adnm_ssd_ws_bytes(int64_t B, int64_t L, int64_t H, int64_t P,
 extern "C" int adnm_ssd_reduce_fwd(const void* x, int64_t ldx, const void* Bm, int64_t ldb, const void* Cm, int64_t ldc,
                                    const void* dt_raw, int64_t lddt, int64_t dt_hstride, const float* dt_bias,
                                    const float* A_log, const float* D, int64_t p_hstride, void* y, int64_t ldy, float* kv,
+                                   const float* ln_w, const float* ln_b, void* yn, int64_t ldyn, float* ln_mu, float* ln_rstd, float ln_eps,
                                    void* ws, int64_t ws_bytes, int64_t B, int64_t L, int64_t H, int64_t P, int64_t N,
                                    int64_t G, int dtype, adnm_stream_t stream) {
   if (int rc = check_common("ssd_reduce_fwd", B, L, H, P, N, G, dtype)) return rc;
@@ -484,21 +661,30 @@ extern "C" int adnm_ssd_reduce_fwd(const void* x, int64_t ldx, const void* Bm, i
   ADNM_REQUIRE(ldx >= H * P && ldy >= H * P && ldb >= G * N && ldc >= G * N && lddt >= (H - 1) * dt_hstride + 1,
                "ssd_reduce_fwd: row strides smaller than the rows they address");
   ADNM_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0, "ssd_reduce_fwd: row strides must be multiples of 4");
+  if (yn) {
+    ADNM_REQUIRE(H * P == kCols, "ssd_reduce_fwd: the fused LayerNorm epilogue needs the token row to be one head block (H*P == 64), got %lld",
+                 (long long)(H * P));
+    ADNM_REQUIRE(ln_w && ln_b && ln_mu && ln_rstd && ldyn >= H * P && ldyn % 4 == 0, "ssd_reduce_fwd: incomplete LayerNorm arguments");
+  }
   const Ws w = carve(ws, B, L, H, P, N, G);
   if (!ws || ws_bytes < w.bytes) {
     adnm_set_error("ssd_reduce_fwd: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)w.bytes);
     return ADNM_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  int rc = ADNM_OK;
   if (dtype == ADNM_F32) {
     using T = float;
-    DISPATCH_PN(run_outer, true, x, ldx, Bm, ldb, dt_raw, lddt, dt_hstride, dt_bias, A_log, p_hstride, w.part, kv, B, L, H, G, st);
-    DISPATCH_PN(run_apply, x, ldx, Cm, ldc, D, p_hstride, kv, y, ldy, B, L, H, G, st);
+    DISPATCH_PNG(rc = run_kv, true, x, ldx, Bm, ldb, dt_raw, lddt, dt_hstride, dt_bias, A_log, p_hstride, w.part, kv, B, L, H, st);
+    if (rc) return rc;
+    DISPATCH_PNG(rc = run_apply, x, ldx, Cm, ldc, D, p_hstride, kv, y, ldy, ln_w, ln_b, yn, ldyn, ln_mu, ln_rstd, ln_eps, B, L, H, st);
   } else {
     using T = uint16_t;
-    DISPATCH_PN(run_outer, true, x, ldx, Bm, ldb, dt_raw, lddt, dt_hstride, dt_bias, A_log, p_hstride, w.part, kv, B, L, H, G, st);
-    DISPATCH_PN(run_apply, x, ldx, Cm, ldc, D, p_hstride, kv, y, ldy, B, L, H, G, st);
+    DISPATCH_PNG(rc = run_kv, true, x, ldx, Bm, ldb, dt_raw, lddt, dt_hstride, dt_bias, A_log, p_hstride, w.part, kv, B, L, H, st);
+    if (rc) return rc;
+    DISPATCH_PNG(rc = run_apply, x, ldx, Cm, ldc, D, p_hstride, kv, y, ldy, ln_w, ln_b, yn, ldyn, ln_mu, ln_rstd, ln_eps, B, L, H, st);
   }
+  if (rc) return rc;
   ADNM_CHECK_LAUNCH("ssd_reduce_fwd");
   return ADNM_OK;
 }
@@ -523,17 +709,21 @@ extern "C" int adnm_ssd_reduce_bwd(const void* dy, int64_t lddy, const void* x, 
     return ADNM_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  int rc = ADNM_OK;
   if (dtype == ADNM_F32) {
     using T = float;
-    DISPATCH_PN(run_outer, false, dy, lddy, Cm, ldc, nullptr, 0, 0, nullptr, nullptr, 0, w.part, w.dkv, B, L, H, G, st);
-    DISPATCH_PN(run_bwd, dy, lddy, x, ldx, Bm, ldb, Cm, ldc, dt_raw, lddt, dt_hstride, dt_bias, A_log, D, p_hstride, kv, w.dkv, dx,
-                lddx, dBm, lddb, dCm, lddc, ddt_raw, ldddt, w.hpart, w.bcpart, ddt_bias, dA_log, dD, B, L, H, G, st);
+    DISPATCH_PNG(rc = run_kv, false, dy, lddy, Cm, ldc, nullptr, 0, 0, nullptr, nullptr, 0, w.part, w.dkv, B, L, H, st);
+    if (rc) return rc;
+    DISPATCH_PNG(rc = run_bwd, dy, lddy, x, ldx, Bm, ldb, dt_raw, lddt, dt_hstride, dt_bias, A_log, D, p_hstride, kv, w.dkv, dx, lddx, dBm, lddb, dCm,
+                 lddc, ddt_raw, ldddt, w.hpart, w.bcpart, ddt_bias, dA_log, dD, B, L, H, st);
   } else {
     using T = uint16_t;
-    DISPATCH_PN(run_outer, false, dy, lddy, Cm, ldc, nullptr, 0, 0, nullptr, nullptr, 0, w.part, w.dkv, B, L, H, G, st);
-    DISPATCH_PN(run_bwd, dy, lddy, x, ldx, Bm, ldb, Cm, ldc, dt_raw, lddt, dt_hstride, dt_bias, A_log, D, p_hstride, kv, w.dkv, dx,
-                lddx, dBm, lddb, dCm, lddc, ddt_raw, ldddt, w.hpart, w.bcpart, ddt_bias, dA_log, dD, B, L, H, G, st);
+    DISPATCH_PNG(rc = run_kv, false, dy, lddy, Cm, ldc, nullptr, 0, 0, nullptr, nullptr, 0, w.part, w.dkv, B, L, H, st);
+    if (rc) return rc;
+    DISPATCH_PNG(rc = run_bwd, dy, lddy, x, ldx, Bm, ldb, dt_raw, lddt, dt_hstride, dt_bias, A_log, D, p_hstride, kv, w.dkv, dx, lddx, dBm, lddb, dCm,
+                 lddc, ddt_raw, ldddt, w.hpart, w.bcpart, ddt_bias, dA_log, dD, B, L, H, st);
   }
+  if (rc) return rc;
   ADNM_CHECK_LAUNCH("ssd_reduce_bwd");
   return ADNM_OK;
 }

@@ -290,7 +290,7 @@ class FeedForward(nn.Module):
     def forward_tokens(self, x, h, w):
         x = self.project_in.forward_tokens(x, h, w)
         x = self.dwconv.forward_tokens(x, h, w)
-        x = ops.gate(x) if x.shape[-1] % 8 == 0 else F.gelu(x[..., :x.shape[-1] // 2]) * torch.sigmoid(x[..., x.shape[-1] // 2:])
+        x = ops.gate(x)   # gelu(x1) * sigmoid(x2): the kernel rejects widths that are not multiples of 8
         return self.project_out.forward_tokens(x, h, w)
 
     def forward(self, x):
@@ -311,10 +311,7 @@ class ConvFFD(nn.Module):
         h, w = _hw(l)
         x = ops.linear(x, self.in_proj.weight, self.in_proj.bias)
         c = self.dw_conv.conv
-        if x.shape[-1] % 4 == 0:
-            x = ops.dwconv(x, c.weight, c.bias, h, w, lib.ACT_GELU)  # conv + GELU (model_untils.py:219-220)
-        else:
-            x = self.act(self.dw_conv.forward_tokens(x, h, w))
+        x = ops.dwconv(x, c.weight, c.bias, h, w, lib.ACT_GELU)  # conv + GELU (model_untils.py:219-220)
         return ops.linear(x, self.out_proj.weight, self.out_proj.bias)
 
 
@@ -395,9 +392,9 @@ class DownSample(nn.Module):
     def forward(self, x):
         b, l, d = x.shape
         h, w = _hw(l)
-        if d % 4 == 0 and 2 <= self.ratio <= 4:
-            return ops.maxpool(x, h, w, self.ratio, self.ratio, self.ratio)
-        return tokens_of(self.max_pool(nchw_view(x, h, w)))
+        if d % 4 or not 2 <= self.ratio <= 4:
+            raise RuntimeError(f"DownSample: the HIP max-pool takes 4 | channels and ratio 2..4, got dim {d}, ratio {self.ratio}")
+        return ops.maxpool(x, h, w, self.ratio, self.ratio, self.ratio)
 
 
 class UpSample(nn.Module):

@@ -231,6 +231,7 @@ def main():
     from models.ADNMUNet import create_ADNMUNet
     from models.loss import enRainfallLoss
     lib.load()
+    torch.backends.cuda.preferred_blas_library("hipblas")   # whatever plain library GEMM is left: rocBLAS (hipBLASLt's long-reduction picks are 6x slower here)
 
     model = create_ADNMUNet(args.in_frames, args.out_frames, 6, img_size=args.size)
     recipe.fill_parameters(model)  # identical replicas on every rank, same parameters as the parity fixtures

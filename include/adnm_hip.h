@@ -78,12 +78,17 @@ int adnm_rownorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, c
  * x:(B,L,H,P) row(token) stride ldx; Bm,Cm:(B,L,G*N) strides ldb,ldc; dt_raw:(B,L,H) stride lddt with
  * per-head element stride dt_hstride (2 for the even/odd head split of ADNssd.py:375-378);
  * dt_bias,A_log,D indexed [h*p_hstride] likewise.  y stride ldy.  kv:(B,H,N,P) fp32 (saved for backward).
- * (P,N) in {(4,8),(4,16),(8,8)} (per-lane N x P state lives in registers), G in {1,2,4}. */
+ * (P,N) in {(4,8),(4,16),(8,8)}, G in {1,2,4}.  The three contractions run on v_mfma_f32_16x16x4_f32 (exact fp32).
+ * Optional fused epilogue (yn != NULL; needs H*P == 64, i.e. the token row is one head block — the refiner mixers): the mixer's
+ * LayerNorm(d_inner) of ADNssd.py:456, yn = (y - mean) * rstd * ln_w + ln_b over the H*P columns of the row, written with row
+ * stride ldyn next to y itself; ln_mu, ln_rstd:(B*L) fp32 statistics saved for adnm_rownorm_bwd.  yn == NULL: the ln_* arguments
+ * are ignored. */
 int64_t adnm_ssd_ws_bytes(int64_t B, int64_t L, int64_t H, int64_t P, int64_t N, int64_t G);
 int adnm_ssd_reduce_fwd(const void* x, int64_t ldx, const void* Bm, int64_t ldb, const void* Cm, int64_t ldc,
                         const void* dt_raw, int64_t lddt, int64_t dt_hstride, const float* dt_bias,
                         const float* A_log, const float* D, int64_t p_hstride, void* y, int64_t ldy, float* kv,
-                        void* ws, int64_t ws_bytes, int64_t B, int64_t L, int64_t H, int64_t P, int64_t N,
+                        const float* ln_w, const float* ln_b, void* yn, int64_t ldyn, float* ln_mu, float* ln_rstd,
+                        float ln_eps, void* ws, int64_t ws_bytes, int64_t B, int64_t L, int64_t H, int64_t P, int64_t N,
                         int64_t G, int dtype, adnm_stream_t stream);
 /* gradients: dx,dBm,dCm,ddt_raw share the strides of their primals (they may alias slices of one
  * wide gradient buffer); ddt_bias,dA_log,dD:(H) contiguous fp32, OVERWRITTEN. */

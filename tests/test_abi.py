@@ -15,7 +15,7 @@ def test_header_parses_and_library_exports_every_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for name in protos:
         assert hasattr(so, name), f"{name} declared in include/adnm_hip.h but not exported"
-    assert lib.load().adnm_abi_version() == 2
+    assert lib.load().adnm_abi_version() == 3
 
 
 def test_ws_queries_are_pure_host_functions():
@@ -29,7 +29,7 @@ def test_argument_validation_happens_before_any_launch():
     # invalid shapes are rejected on the host with an error string, no GPU needed
     rc = lib.load().adnm_rownorm_fwd(1, 6, 1, None, None, None, 1, 6, None, 1, 4, 6, 1e-5, 0, 0, None)
     assert rc == -1 and "multiple of 4" in lib.last_error()
-    rc = lib.load().adnm_ssd_reduce_fwd(1, 64, 1, 16, 1, 16, 1, 16, 1, 1, 1, 1, 1, 1, 64, 1, 1, 0, 1, 4, 4, 16, 16, 1, 0, None)
+    rc = lib.load().adnm_ssd_reduce_fwd(1, 64, 1, 16, 1, 16, 1, 16, 1, 1, 1, 1, 1, 1, 64, 1, None, None, None, 0, None, None, 0.0, 1, 0, 1, 4, 4, 16, 16, 1, 0, None)
     assert rc == -1 and "not in" in lib.last_error()
 
 

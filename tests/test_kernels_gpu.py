@@ -502,8 +502,7 @@ def test_rownorm_tap(mean):
     (100, 48, 36, True),        # ragged tiles
     (4096, 128, 544, False),
 ])
-def test_skgemm_linear(M, K, N, bias, monkeypatch):
-    monkeypatch.setattr(ops, "SK_FORCE", True)   # exercise the kernel on every shape, not only where the timing routes to it
+def test_skgemm_linear(M, K, N, bias):
     x, w, cot = T(f"sk.x{M}{K}", (M, K)), T(f"sk.w{N}{K}", (N, K), 0.05), T(f"sk.c{M}{N}", (M, N))
     b = T(f"sk.b{N}", (N,)) if bias else None
     xo, wo, bo = leaf(x.double()), leaf(w.double()), (leaf(b.double()) if bias else None)
@@ -520,8 +519,7 @@ def test_skgemm_linear(M, K, N, bias, monkeypatch):
         assert_close(bg.grad, bo.grad, GRAD_TOL, "db")
 
 
-def test_skgemm_strided_operands(monkeypatch):
-    monkeypatch.setattr(ops, "SK_FORCE", True)
+def test_skgemm_strided_operands():
     """column slices of wider buffers as input and output (how the mixer calls it): no partials for the strided output."""
     M, K, N = 256, 512, 128
     big_in, big_out = T("sks.in", (M, K + 64)).to(DEV), torch.zeros((M, N + 32), device=DEV)
@@ -575,3 +573,26 @@ def test_attn4(B, L, heads):
     (yg * cot.to(DEV)).sum().backward()
     assert_close(yg, yo, OUT_TOL, "attention out")
     assert_close(qg.grad, qo.grad, GRAD_TOL, "dqkv")
+
+
+def test_unsupported_shapes_raise():
+    """The token ops have no PyTorch fallback: a shape a kernel does not take is an error, as a CPU tensor is."""
+    one = torch.ones((), device=DEV)
+    odd = torch.zeros(2, 8, 6, device=DEV)        # 6 channels: not a multiple of 4
+    with pytest.raises(RuntimeError, match="no PyTorch fallback"):
+        ops.catmix(odd, odd, None, one, one)
+    with pytest.raises(RuntimeError, match="no PyTorch fallback"):
+        ops.lincomb([odd, odd], [one, one])
+    with pytest.raises(RuntimeError, match="no PyTorch fallback"):
+        ops.igate(torch.zeros(3, device=DEV), one, one)
+    with pytest.raises(RuntimeError, match="no PyTorch fallback"):
+        ops.tokmean_tap(odd)
+    with pytest.raises(RuntimeError, match="no PyTorch fallback"):
+        ops.conv1d3(torch.zeros(2, 2, 8, device=DEV), torch.zeros(1, 1, 3, device=DEV), None)
+    with pytest.raises(RuntimeError, match="no kernel takes"):
+        ops.linear(torch.zeros(8, 10, device=DEV), torch.zeros(12, 10, device=DEV))      # K = 10: not a multiple of 16
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.linear(torch.zeros(8, 16), torch.zeros(12, 16))
+    from models.model_untils import DownSample
+    with pytest.raises(RuntimeError, match="max-pool"):
+        DownSample(dim=6)(torch.zeros(1, 16, 6, device=DEV))
