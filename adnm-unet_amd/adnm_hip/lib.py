@@ -25,7 +25,7 @@ def parse_header(path=HEADER):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"(const char\*|int64_t|int|void)\s+(adnm_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"(const char\*|void\*|int64_t|int|void)\s+(adnm_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         types = []
         if args and args != "void":

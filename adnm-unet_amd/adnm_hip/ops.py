@@ -86,6 +86,7 @@ class GradRegistry:
                 self._claimed[owner].clear()
 
     def take(self, ptr, shape, device, dtype=torch.float32):
+        second = False
         with self._lock:
             ent = self._dst.get(ptr)
             if ent is not None:
@@ -94,11 +95,100 @@ class GradRegistry:
                     self._claimed[owner].add(ptr)
                     # a fresh tensor object on the same memory: AccumulateGrad only keeps ("steals") a gradient nobody else references
                     return g.detach()
+                second = ptr in self._claimed[owner]
+        if second:   # autograd is about to add this contribution to the first one: the first must be complete
+            FOLDS.flush(device)
         return torch.empty(tuple(shape), dtype=dtype, device=device)
 
 
+class FoldRegistry:
+    """Deferred second-stage folds (include/adnm_hip.h: adnm_foldq_*).  A trainer enables it for its device; the *_bwd wrappers that
+    only produce PARAMETER gradients (or the single-consumer intermediates of the parameter-prep nodes) then bind the device's
+    queue around their library call, so their fold launches are queued instead of issued, and keep their partial workspaces alive
+    here.  flush() issues one launch per 16 queued folds; it is called before anything can read the results: at the head of the
+    parameter-prep backward nodes, on the second claim of a gradient slice (autograd is about to ADD to it), and by the trainer
+    after backward.  Disabled (the default, plain autograd use) every fold is launched where it is produced."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._q = {}   # device index -> {"h": queue handle, "keep": [...], "on": bool}
+
+    def enable(self, device, on=True):
+        import os
+        if os.environ.get("ADNM_FOLD_DEFER", "1") == "0":
+            on = False
+        with self._lock:
+            ent = self._q.get(device.index)
+            if ent is None:
+                ent = self._q[device.index] = {"h": lib.load().adnm_foldq_create(), "keep": [], "on": False}
+        if not on:
+            self.flush(device)
+        ent["on"] = bool(on)
+
+    def active(self, device, on=True):
+        """with FOLDS.active(dev): ... — deferral is on for the kernels launched inside (from any thread: autograd runs backward on
+        its own), the queue is flushed on the way out.  Scoped in time, so plain autograd users of the device are never deferred."""
+        return _Active(self, device, on)
+
+    def defer(self, device, *keep):
+        return _Deferred(self._q.get(device.index), keep, self._lock)
+
+    def flush(self, device):
+        ent = self._q.get(device.index)
+        if ent is None:
+            return
+        if lib.query("adnm_foldq_pending", ent["h"]) > 0:
+            with torch.cuda.device(device):
+                lib.call("adnm_foldq_flush", ent["h"], _stream())
+        with self._lock:
+            ent["keep"].clear()
+
+
+class _Active:
+    def __init__(self, reg, device, on):
+        self.reg, self.device, self.on = reg, device, on and device.type == "cuda"
+
+    def __enter__(self):
+        if self.on:
+            self.reg.enable(self.device, True)
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.reg.enable(self.device, False)   # flushes
+        return False
+
+
+class _Deferred:
+    def __init__(self, ent, keep, lock):
+        self.ent, self.keep, self.lock = (ent if ent is not None and ent["on"] else None), keep, lock
+
+    def __enter__(self):
+        if self.ent is not None:
+            lib.load().adnm_foldq_bind(self.ent["h"])
+        return self.ent is not None
+
+    def __exit__(self, *exc):
+        if self.ent is not None:
+            lib.load().adnm_foldq_bind(None)
+            with self.lock:
+                self.ent["keep"].extend(t for t in self.keep if t is not None)
+        return False
+
+
+FOLDS = FoldRegistry()
 GRADS = GradRegistry()
 grad_dst = GRADS.take
+
+
+class _NoDefer:
+    def __enter__(self):
+        return False
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NODEFER = _NoDefer()
 
 
 def _need_gpu(t):
@@ -120,22 +210,24 @@ def k_rownorm_fwd(x2, w, b, scale, shift, eps, mean, out=None):
     return y, mu, rstd
 
 
-def k_rownorm_bwd(dy2, x2, w, b, scale, mu, rstd, mean, want_b, want_affine, dx_out=None, dres=None):
+def k_rownorm_bwd(dy2, x2, w, b, scale, mu, rstd, mean, want_b, want_affine, dx_out=None, dres=None, shift=None, defer=False):
+    """defer: dw / db / dscale / dshift are parameter gradients (or prep intermediates) nobody reads before the next flush point."""
     M, d = x2.shape
     dev = x2.device
     dx = dx_out if dx_out is not None else torch.empty((M, d), dtype=x2.dtype, device=dev)
-    dw = torch.empty(d, dtype=torch.float32, device=dev)
-    db = torch.empty(d, dtype=torch.float32, device=dev) if want_b else None
-    dsc = torch.empty((), dtype=torch.float32, device=dev) if want_affine else None
-    dsh = torch.empty((), dtype=torch.float32, device=dev) if want_affine else None
+    dw = grad_dst(w.data_ptr(), (d,), dev)
+    db = grad_dst(b.data_ptr(), (d,), dev) if want_b else None
+    dsc = grad_dst(scale.data_ptr() if scale is not None else 0, (), dev) if want_affine else None
+    dsh = grad_dst(shift.data_ptr() if shift is not None else 0, (), dev) if want_affine else None
     nb = lib.query("adnm_rownorm_bwd_ws_bytes", M, d)
     ws = _ws(nb, dev)
     pdy, lddy = _rows(dy2)
     px, ldx = _rows(x2)
     pdx, lddx = _rows(dx)
     pres, ldres = _rows(dres) if dres is not None else (None, 0)
-    lib.call("adnm_rownorm_bwd", pdy, lddy, px, ldx, _p(w), _p(b), _p(scale), mu.data_ptr(), rstd.data_ptr(), pdx, lddx,
-             dw.data_ptr(), _p(db), _p(dsc), _p(dsh), pres, ldres, ws.data_ptr(), nb, M, d, int(mean), _dt(x2), _stream())
+    with FOLDS.defer(dev, ws, dw, db, dsc, dsh) if defer else _NODEFER:
+        lib.call("adnm_rownorm_bwd", pdy, lddy, px, ldx, _p(w), _p(b), _p(scale), mu.data_ptr(), rstd.data_ptr(), pdx, lddx,
+                 dw.data_ptr(), _p(db), _p(dsc), _p(dsh), pres, ldres, ws.data_ptr(), nb, M, d, int(mean), _dt(x2), _stream())
     return dx, dw, db, dsc, dsh
 
 
@@ -182,9 +274,10 @@ def k_ssd_bwd(dy, x, Bm, Cm, dt_raw, dt_bias, A_log, D, kv, dx, dBm, dCm, ddt, B
     g = []
     for t in (dx, dBm, dCm, ddt):
         g += list(_rows(t))
-    lib.call("adnm_ssd_reduce_bwd", a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], 1, _p(dt_bias), _p(A_log), _p(D), 1,
-             kv.data_ptr(), g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], dbias.data_ptr(), dA.data_ptr(), dD.data_ptr(),
-             ws.data_ptr(), nb, B, L, H, P, N, G, _dt(x), _stream())
+    with FOLDS.defer(dev, ws, dbias, dA, dD):   # the per-head statistics [dD | ddt_bias | dA_log] are parameter gradients
+        lib.call("adnm_ssd_reduce_bwd", a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], 1, _p(dt_bias), _p(A_log), _p(D), 1,
+                 kv.data_ptr(), g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], dbias.data_ptr(), dA.data_ptr(), dD.data_ptr(),
+                 ws.data_ptr(), nb, B, L, H, P, N, G, _dt(x), _stream())
     return dbias, dA, dD
 
 
@@ -212,8 +305,9 @@ def k_dwconv_bwd(dy, x, wt, bias, B, H, W, C, K, act, dx=None, want_bias=False, 
     pdy, lddy = _rows(dy)
     px, ldx = _rows(x)
     pdx, lddx = _rows(dx)
-    lib.call("adnm_dwconv_bwd", pdy, lddy, px, ldx, _p(wt), _p(bias), _p(dpre), pdx, lddx, _p(dwt), _p(db), ws.data_ptr(),
-             nb, B, H, W, C, K, K, act, int(chan_major), _dt(x), _stream())
+    with FOLDS.defer(dev, ws, dwt, db):   # taps / bias gradients: parameters, or prep intermediates flushed at the prep node
+        lib.call("adnm_dwconv_bwd", pdy, lddy, px, ldx, _p(wt), _p(bias), _p(dpre), pdx, lddx, _p(dwt), _p(db), ws.data_ptr(),
+                 nb, B, H, W, C, K, K, act, int(chan_major), _dt(x), _stream())
     return dx, dwt, db
 
 
@@ -300,7 +394,7 @@ class RowNormFn(torch.autograd.Function):
             x2 = x2.contiguous()
         y, mu, rstd = k_rownorm_fwd(x2, w, b, scale, shift, eps, mean)
         ctx.save_for_backward(x2, w, b, scale, mu, rstd)
-        ctx.mean, ctx.shp, ctx.has_shift = mean, shp, shift is not None
+        ctx.mean, ctx.shp, ctx.has_shift, ctx.shift = mean, shp, shift is not None, shift
         return y.view(shp)
 
     @staticmethod
@@ -310,7 +404,7 @@ class RowNormFn(torch.autograd.Function):
         if dy2.stride(-1) != 1:
             dy2 = dy2.contiguous()
         dx, dw, db, dsc, dsh = k_rownorm_bwd(dy2, x2, w, b, scale, mu, rstd, ctx.mean, b is not None,
-                                            scale is not None or ctx.has_shift)
+                                            scale is not None or ctx.has_shift, shift=ctx.shift, defer=True)
         return (dx.view(ctx.shp), dw, db, dsc if scale is not None else None, dsh if ctx.has_shift else None, None, None)
 
 
@@ -330,7 +424,7 @@ class RowNormTapFn(torch.autograd.Function):
             x2 = x2.contiguous()
         y, mu, rstd = k_rownorm_fwd(x2, w, b, scale, shift, eps, mean)
         ctx.save_for_backward(x2, w, b, scale, mu, rstd)
-        ctx.mean, ctx.shp, ctx.has_shift = mean, shp, shift is not None
+        ctx.mean, ctx.shp, ctx.has_shift, ctx.shift = mean, shp, shift is not None, shift
         ctx.set_materialize_grads(False)
         return y.view(shp), x
 
@@ -348,7 +442,7 @@ class RowNormTapFn(torch.autograd.Function):
             if dres.stride(-1) != 1:
                 dres = dres.contiguous()
         dx, dw, db, dsc, dsh = k_rownorm_bwd(dy2, x2, w, b, scale, mu, rstd, ctx.mean, b is not None,
-                                            scale is not None or ctx.has_shift, dres=dres)
+                                            scale is not None or ctx.has_shift, dres=dres, shift=ctx.shift, defer=True)
         return (dx.view(ctx.shp), dw, db, dsc if scale is not None else None, dsh if ctx.has_shift else None, None, None)
 
 
@@ -390,8 +484,9 @@ class CatMixFn(torch.autograd.Function):
         ws = _ws(nb, x2.device)
         (pg, ldg), (px, ldx), (pr, ldr) = _rows(g), _rows(x2), _rows(r2)
         pf, ldf = _rows(f2) if f2 is not None else (None, 0)
-        lib.call("adnm_catmix_bwd", pg, ldg, px, ldx, pr, ldr, pf, ldf, _p(a1), _p(a2), _p(a3), _p(a4), _p(dx), _p(dr), _p(df), da.data_ptr(),
-                 ws.data_ptr(), nb, M, d, _dt(g), _stream())
+        with FOLDS.defer(x2.device, ws, da):   # alpha1..4: one merge node per module
+            lib.call("adnm_catmix_bwd", pg, ldg, px, ldx, pr, ldr, pf, ldf, _p(a1), _p(a2), _p(a3), _p(a4), _p(dx), _p(dr), _p(df), da.data_ptr(),
+                     ws.data_ptr(), nb, M, d, _dt(g), _stream())
         v = lambda t: t.view(ctx.shp) if t is not None else None
         s = lambda a, i: da[i].view_as(a) if a is not None else None
         return v(dx), v(dr), v(df), s(a1, 0), s(a2, 1), s(a3 if f2 is not None else None, 2), s(a4 if f2 is not None else None, 3)
@@ -644,7 +739,7 @@ class ADNMixerFn(torch.autograd.Function):
         do = do if do.is_contiguous() else do.contiguous()
         dw_out, _ = k_linear_dw(do, cat, False)
         dcat = k_linear_dx(do, w_out)  # (M, 2di)
-        dy, dln_w, dln_b, _, _ = k_rownorm_bwd(dcat[:, :di], y, ln_w, ln_b, None, mu, rstd, True, True, False)
+        dy, dln_w, dln_b, _, _ = k_rownorm_bwd(dcat[:, :di], y, ln_w, ln_b, None, mu, rstd, True, True, False, defer=True)
         dproj = torch.empty_like(proj)
         dxbc = torch.empty_like(xbc)
         if scan_chunk == 0:
@@ -711,8 +806,9 @@ class LinCombFn(torch.autograd.Function):
         g = g if g.stride(-1) == 1 else g.contiguous()
         need_x = ctx.needs_input_grad[1:1 + n]
         dxs = [torch.empty((M, C), dtype=x2[0].dtype, device=dev) if need_x[i] else None for i in range(n)]
-        dss = [torch.empty_like(ss[i]) if ss[i] is not None else None for i in range(n)]
-        dgamma = torch.empty_like(gamma) if gamma is not None else None
+        # Block's beta1 / beta2 feed two mixes: the second claim of their slice flushes the queue before autograd adds (GRADS.take)
+        dss = [grad_dst(ss[i].data_ptr(), ss[i].shape, dev) if ss[i] is not None else None for i in range(n)]
+        dgamma = grad_dst(gamma.data_ptr(), gamma.shape, dev) if gamma is not None else None
         nb = lib.query("adnm_lincomb_bwd_ws_bytes", M, C)
         ws = _ws(nb, dev)
         xp = [_rows(t) for t in x2] + [(None, 0)] * (3 - n)
@@ -720,9 +816,10 @@ class LinCombFn(torch.autograd.Function):
         sp = [_p(s) for s in ss] + [None] * (3 - n)
         dsp = [_p(s) for s in dss] + [None] * (3 - n)
         pg, ldg = _rows(g)
-        lib.call("adnm_lincomb_bwd", pg, ldg, xp[0][0], xp[0][1], xp[1][0], xp[1][1], xp[2][0], xp[2][1], sp[0], sp[1], sp[2], _p(gamma),
-                 dxp[0][0], dxp[0][1], dxp[1][0], dxp[1][1], dxp[2][0], dxp[2][1], dsp[0], dsp[1], dsp[2], _p(dgamma), ws.data_ptr(), nb,
-                 M, C, _dt(g), _stream())
+        with FOLDS.defer(dev, ws, dgamma, *dss):
+            lib.call("adnm_lincomb_bwd", pg, ldg, xp[0][0], xp[0][1], xp[1][0], xp[1][1], xp[2][0], xp[2][1], sp[0], sp[1], sp[2], _p(gamma),
+                     dxp[0][0], dxp[0][1], dxp[1][0], dxp[1][1], dxp[2][0], dxp[2][1], dsp[0], dsp[1], dsp[2], _p(dgamma), ws.data_ptr(), nb,
+                     M, C, _dt(g), _stream())
         return (dgamma, *[d.view(shp) if d is not None else None for d in dxs], *dss)
 
 
@@ -756,12 +853,14 @@ class AdnPrepFn(torch.autograd.Function):
     def backward(ctx, *gouts):
         params = ctx.saved_tensors
         dm, di, gn, P = ctx.dims
+        FOLDS.flush(params[0].device)   # the incoming gradients are (deferred) fold results of the mixer's backward
         gouts = [g.contiguous() for g in gouts]
         dparams = [grad_dst(p.data_ptr(), p.shape, p.device, p.dtype) for p in params]
         nb = lib.query("adnm_adnprep_bwd_ws_bytes")
         ws = _ws(nb, params[0].device)
-        lib.call("adnm_adnprep_bwd", lib.ptr_table(params), lib.ptr_table(gouts), lib.ptr_table(dparams), dm, di, gn, P, ws.data_ptr(), nb,
-                 _stream())
+        with FOLDS.defer(params[0].device, ws, *gouts, *dparams):
+            lib.call("adnm_adnprep_bwd", lib.ptr_table(params), lib.ptr_table(gouts), lib.ptr_table(dparams), dm, di, gn, P, ws.data_ptr(), nb,
+                     _stream())
         return (None, None, None, None, *dparams)
 
 
@@ -793,6 +892,7 @@ class WtPrepFn(torch.autograd.Function):
         n = 1 + levels
         saved = ctx.saved_tensors
         bias, w, s = saved[0], saved[1:1 + n], saved[1 + n:]
+        FOLDS.flush(w[0].device)   # the incoming tap gradients are (deferred) fold results of the depthwise weight-gradient kernels
         gtaps = [g.contiguous() for g in gtaps]
         dw = [torch.empty_like(t) for t in w]
         ds = [torch.empty_like(t) for t in s]
@@ -865,14 +965,15 @@ def _sk_operand(t, what):
     return t
 
 
-def _skgemm(op, a, b, bias, c, dbias, M, N, K):
+def _skgemm(op, a, b, bias, c, dbias, M, N, K, defer=False):
     if lib.query("adnm_skgemm_supported", op, M, N, K) != 1:
         raise RuntimeError(f"adnm_hip linear: no kernel takes op={('NT', 'NN', 'TN')[op]} M={M} N={N} K={K} "
                            "(NT needs K % 16 == 0; NN needs N % 16 == 0 and K % 4 == 0; TN needs N % 4 == 0 and K % 4 == 0)")
     nb = lib.query("adnm_skgemm_ws_bytes", op, M, N, K)
     ws = _ws(nb, a.device)
-    lib.call("adnm_skgemm", op, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _p(bias), c.data_ptr(), c.stride(0), _p(dbias),
-             ws.data_ptr(), nb, M, N, K, _stream())
+    with FOLDS.defer(a.device, ws, c, dbias) if defer else _NODEFER:   # only the weight-gradient op (TN) may wait for its split-K fold
+        lib.call("adnm_skgemm", op, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _p(bias), c.data_ptr(), c.stride(0), _p(dbias),
+                 ws.data_ptr(), nb, M, N, K, _stream())
 
 
 def _out_view_ok(out):
@@ -936,11 +1037,12 @@ def k_linear_dw(dy2, x2, want_bias, w_ptr=0, b_ptr=0):
     if ts_ok_tn(M, N, K, x2):
         nb = lib.query("adnm_tsgemm_tn_ws_bytes", M, N, K)
         ws = _ws(nb, dev)
-        lib.call("adnm_tsgemm_tn", dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), dw.data_ptr(), _p(db), ws.data_ptr(), nb, M, N, K,
-                 _stream())
+        with FOLDS.defer(dev, ws, dw, db):
+            lib.call("adnm_tsgemm_tn", dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), dw.data_ptr(), _p(db), ws.data_ptr(), nb, M, N, K,
+                     _stream())
         return dw, db
     dy2, x2 = _sk_operand(dy2, "output gradient"), _sk_operand(x2, "input")
-    _skgemm(SK_TN, dy2, x2, None, dw, db, M, N, K)
+    _skgemm(SK_TN, dy2, x2, None, dw, db, M, N, K, defer=True)
     return dw, db
 
 
@@ -1099,8 +1201,9 @@ class SkipGateFn(torch.autograd.Function):
         dp = torch.empty(int(lib.query("adnm_skipgate_grad_floats", c)), dtype=torch.float32, device=x.device)
         nb = lib.query("adnm_skipgate_bwd_ws_bytes", b, h, w, c)
         ws = _ws(nb, x.device)
-        lib.call("adnm_skipgate_bwd", dout.data_ptr(), x.data_ptr(), lib.ptr_table(params), pooled.data_ptr(), conv.data_ptr(), dx.data_ptr(),
-                 dp.data_ptr(), ws.data_ptr(), nb, b, h, w, c, _stream())
+        with FOLDS.defer(x.device, ws, dp):   # every parameter of an EncoderToDecoder has this one node
+            lib.call("adnm_skipgate_bwd", dout.data_ptr(), x.data_ptr(), lib.ptr_table(params), pooled.data_ptr(), conv.data_ptr(), dx.data_ptr(),
+                     dp.data_ptr(), ws.data_ptr(), nb, b, h, w, c, _stream())
         o = [0]
 
         def take(n, like):

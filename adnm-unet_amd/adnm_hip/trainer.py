@@ -30,7 +30,7 @@ from . import lib, ops
 
 class FlatTrainer:
     def __init__(self, model, loss_fn, lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2, max_norm=0.0,
-                 process_group=None, use_graph=True, fused=True, overlap="auto", reduce_dtype="f32", stages=None):
+                 process_group=None, use_graph=True, fused=True, overlap="auto", reduce_dtype="f32", stages=None, defer_folds=True):
         """overlap: cut the backward at model.forward_stage1 / forward_stage2 (ADNM-UNet: encoder | decoder + refiner) and all-reduce
         the late stage's gradients while the early stage's backward runs.  "auto" = whenever there is more than one rank.
         `stages` is the older name of the same switch (True / False)."""
@@ -45,6 +45,7 @@ class FlatTrainer:
         self.staged = can_stage and (self.world > 1 if overlap == "auto" else bool(overlap))
         assert reduce_dtype in ("f32", "bf16")
         self.reduce_dtype = reduce_dtype
+        self.defer_folds = defer_folds
         self.used = None
         self.graph = self.graph2 = None
         self.buckets = []
@@ -55,8 +56,13 @@ class FlatTrainer:
         ops.GRADS.reset_claims(id(self))
         out = self.model(x)
         loss = self.loss_fn(out, tgt)
-        loss.backward()
+        with self._deferred():   # the second-stage folds of the parameter gradients: batched, flushed on the way out
+            loss.backward()
         return loss
+
+    def _deferred(self):
+        on = self.defer_folds and self.used is not None and self.flat_g.is_cuda
+        return ops.FOLDS.active(self.flat_g.device if self.used is not None else torch.device("cpu"), on)
 
     @torch.no_grad()
     def _flatten(self):
@@ -138,14 +144,16 @@ class FlatTrainer:
         # autograd.grad() was measured to cost ~290 extra device copies per step here)
         for t in uniq:
             t.grad = None
-        torch.autograd.backward(loss, inputs=self.late + uniq)
+        with self._deferred():
+            torch.autograd.backward(loss, inputs=self.late + uniq)
         self._carry = [(t, tw.grad) for t, tw in zip(origs, uniq) if tw.grad is not None]
         self._gather(0, len(self.late))
         return loss
 
     def _stage_b(self):
         ts, gs = [t for t, _ in self._carry], [g for _, g in self._carry]
-        torch.autograd.backward(ts, grad_tensors=gs, inputs=self.early)
+        with self._deferred():
+            torch.autograd.backward(ts, grad_tensors=gs, inputs=self.early)
         self._gather(len(self.late), len(self.used))
 
     def prepare(self, x, tgt):

@@ -89,17 +89,35 @@ extern "C" int64_t adnm_prof_collect(char* buf, int64_t buflen) {
 }
 
 // ---- shared cross-block fold of fp32 partial rows (second stage of every deterministic reduction in the library)
+// One launch folds up to kMaxFolds independent partial sets ("descriptors"): immediately (one descriptor) or, when the calling
+// thread has bound a caller-owned fold queue (adnm_foldq_*), later and together with the other queued sets — the parameter
+// gradients of a backward pass are not read before the optimiser, so their ~200 second-stage launches per step collapse
+// into a few.  The arithmetic per descriptor (slice / unroll order) is identical either way: results do not depend on batching.
 namespace {
-constexpr int kFoldCols = 64, kFoldSlices = 16;
+constexpr int kFoldCols = 64, kFoldSlices = 16, kMaxFolds = 16;
 struct FoldSegs {
   float* ptr[4];
   int end[4];
 };
-__global__ __launch_bounds__(kFoldCols* kFoldSlices) void fold_rows_kernel(const float* __restrict__ part, int rows, int n,
-                                                                           FoldSegs segs) {
+struct FoldDesc {
+  const float* part;
+  int rows, n;
+  FoldSegs segs;
+};
+struct MultiFold {
+  int count;
+  int blk_end[kMaxFolds];   // exclusive prefix of column-block counts
+  FoldDesc d[kMaxFolds];
+};
+__global__ __launch_bounds__(kFoldCols* kFoldSlices) void fold_rows_kernel(MultiFold mf) {
   __shared__ float sm[kFoldSlices][kFoldCols + 1];
+  int k = 0;
+  while (k + 1 < mf.count && (int)blockIdx.x >= mf.blk_end[k]) ++k;
+  const FoldDesc& fd = mf.d[k];
+  const float* __restrict__ part = fd.part;
+  const int rows = fd.rows, n = fd.n;
   const int cl = threadIdx.x & (kFoldCols - 1), sl = threadIdx.x / kFoldCols;
-  const int c = blockIdx.x * kFoldCols + cl;
+  const int c = ((int)blockIdx.x - (k ? mf.blk_end[k - 1] : 0)) * kFoldCols + cl;
   float acc = 0.f;
   if (c < n) {
     // independent loads: 8 in flight per lane, two accumulators (fixed order -> still deterministic)
@@ -120,32 +138,84 @@ __global__ __launch_bounds__(kFoldCols* kFoldSlices) void fold_rows_kernel(const
   if (sl == 0 && c < n) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < kFoldSlices; ++k) t += sm[k][cl];
+    for (int q = 0; q < kFoldSlices; ++q) t += sm[q][cl];
     int begin = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (c < segs.end[k]) {
-        if (segs.ptr[k]) segs.ptr[k][c - begin] = t;
+    for (int q = 0; q < 4; ++q) {
+      if (c < fd.segs.end[q]) {
+        if (fd.segs.ptr[q]) fd.segs.ptr[q][c - begin] = t;
         break;
       }
-      begin = segs.end[k];
+      begin = fd.segs.end[q];
     }
+  }
+}
+
+struct FoldQueue {
+  std::vector<FoldDesc> pending;
+  std::vector<const char*> names;
+};
+thread_local FoldQueue* tls_foldq = nullptr;
+
+void launch_folds(const FoldDesc* d, const char* const* names, int count, hipStream_t st) {
+  for (int i0 = 0; i0 < count; i0 += kMaxFolds) {
+    MultiFold mf;
+    const int m = count - i0 < kMaxFolds ? count - i0 : kMaxFolds;
+    mf.count = m;
+    int blocks = 0;
+    double bytes = 0;
+    for (int k = 0; k < m; ++k) {
+      mf.d[k] = d[i0 + k];
+      blocks += (int)adnm_cdiv(d[i0 + k].n, kFoldCols);
+      mf.blk_end[k] = blocks;
+      bytes += 4.0 * ((double)d[i0 + k].rows + 1) * d[i0 + k].n;
+    }
+    for (int k = m; k < kMaxFolds; ++k) mf.blk_end[k] = blocks;
+    ADNM_PROF(m == 1 ? names[i0] : "fold_batch", st, bytes);
+    fold_rows_kernel<<<(unsigned)blocks, kFoldCols * kFoldSlices, 0, st>>>(mf);
   }
 }
 }  // namespace
 
 void adnm_launch_fold(const char* prof_name, const float* part, int rows, int n, AdnmFoldSeg s0, AdnmFoldSeg s1, AdnmFoldSeg s2,
                       AdnmFoldSeg s3, hipStream_t st) {
-  FoldSegs f;
+  FoldDesc fd;
+  fd.part = part, fd.rows = rows, fd.n = n;
   const AdnmFoldSeg in[4] = {s0, s1, s2, s3};
   int end = 0;
   for (int k = 0; k < 4; ++k) {
     end += in[k].len;
-    f.ptr[k] = in[k].ptr;
-    f.end[k] = end;
+    fd.segs.ptr[k] = in[k].ptr;
+    fd.segs.end[k] = end;
   }
-  ADNM_PROF(prof_name, st, 4.0 * ((double)rows + 1) * n);
-  fold_rows_kernel<<<(unsigned)adnm_cdiv(n, kFoldCols), kFoldCols * kFoldSlices, 0, st>>>(part, rows, n, f);
+  if (tls_foldq) {   // deferred: the caller keeps `part` and the destinations alive until adnm_foldq_flush
+    tls_foldq->pending.push_back(fd);
+    tls_foldq->names.push_back(prof_name);
+    return;
+  }
+  launch_folds(&fd, &prof_name, 1, st);
+}
+
+extern "C" void* adnm_foldq_create(void) { return new FoldQueue(); }
+extern "C" int adnm_foldq_destroy(void* q) {
+  if (tls_foldq == q) tls_foldq = nullptr;
+  delete (FoldQueue*)q;
+  return ADNM_OK;
+}
+extern "C" int adnm_foldq_bind(void* q) {
+  tls_foldq = (FoldQueue*)q;
+  return ADNM_OK;
+}
+extern "C" int64_t adnm_foldq_pending(void* q) { return q ? (int64_t)((FoldQueue*)q)->pending.size() : 0; }
+extern "C" int adnm_foldq_flush(void* q, adnm_stream_t stream) {
+  ADNM_REQUIRE(q, "foldq_flush: null queue");
+  FoldQueue* fq = (FoldQueue*)q;
+  if (fq->pending.empty()) return ADNM_OK;
+  launch_folds(fq->pending.data(), fq->names.data(), (int)fq->pending.size(), (hipStream_t)stream);
+  fq->pending.clear();
+  fq->names.clear();
+  ADNM_CHECK_LAUNCH("foldq_flush");
+  return ADNM_OK;
 }
 
 // Column sums of a contiguous (rows, n) fp32 matrix with the deterministic fold kernel: the bias gradient of a Linear whose

@@ -309,6 +309,10 @@ __global__ __launch_bounds__(kBlock) void ssd_apply_kernel(const T* __restrict__
 //   dw     = sum_p t[p] x[p]                ddt_raw = dw * a * sigmoid(z)
 //   dCm[n] = sum_{h in g} sum_p dy[p] KV[n][p]        dBm[n] = sum_{h in g} w sum_p dKV[n][p] x[p]
 //   dD += sum_p dy x ;  ddt_bias += ddt_raw ;  dA_log += dw * w
+// All three contractions are computed TRANSPOSED (rows = columns / states, MFMA columns = the 16 tokens of the tile), so a
+// lane (token j = lane & 15, kk = lane >> 4) ends up with FOUR CONSECUTIVE memory columns of its token in every accumulator:
+// t, x, dy of one (token, head) meet in one lane as float4s (no cross-lane sums for P = 4), and dBm / dCm / dx leave as 16-byte
+// pieces.  LDS is only the transposer between the coalesced row layout of the global loads / stores and that fragment layout.
 // hpart: per (b, token block) partial of [dD | ddt_bias | dA_log]; bcpart: per head-block partial of [dBm | dCm] rows when
 // H spans several head blocks (else written straight out).
 template <typename T, int P, int N, int G>
@@ -318,139 +322,143 @@ __global__ __launch_bounds__(kBlock) void ssd_bwd_kernel(
     const float* __restrict__ D, int64_t p_hs, const float* __restrict__ kv, const float* __restrict__ dkv, T* __restrict__ dx,
     int64_t lddx, T* __restrict__ dBm, int64_t lddb, T* __restrict__ dCm, int64_t lddc, T* __restrict__ ddt_raw, int64_t ldddt,
     float* __restrict__ hpart, float* __restrict__ bcpart, int64_t L, int H, int tok_per_block, int nblk, int nhb) {
-  constexpr int KW = G * N, SK = KW + 4, HBK = kCols / P, CPG = 4 / G, NS = N / 4, GS = 16 / G;   // GS: k-steps over a group's 64/G columns
-  constexpr int kSlab = 2 * kTile * kSX + 3 * kTile * SK + 3 * kTile * HBK;
+  constexpr int KW = G * N, HBK = kCols / P, CPG = 4 / G, NS = N / 4, LPH = P / 4;   // LPH: kk-lanes that share a head
+  constexpr int kSlab = 2 * kTile * kSX + 2 * kTile * HBK;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* sDY = smem + wave * kSlab;
   float* sX = sDY + kTile * kSX;          // x, then dx in place
-  float* sB = sX + kTile * kSX;           // Bm rows
-  float* sdB = sB + kTile * SK;
-  float* sdC = sdB + kTile * SK;
-  float* sW = sdC + kTile * SK;           // w, a*sigmoid(z), ddt per (token, head of the block)
-  float* sS = sW + kTile * HBK;
-  float* sDdt = sS + kTile * HBK;
+  float* sW = sX + kTile * kSX;           // w per (token, head of the block)
+  float* sS = sW + kTile * HBK;           // a * sigmoid(z), then ddt_raw in place
   const int b = blockIdx.z, hb0 = blockIdx.y * HBK, col0 = hb0 * P;
   const int64_t l_begin = (int64_t)blockIdx.x * tok_per_block;
   const int64_t l_end = l_begin + tok_per_block < L ? l_begin + tok_per_block : L;
-  const int q = lane & 15, i15 = lane & 15, kk = lane >> 4;
+  const int q = lane & 15, j = lane & 15, kk = lane >> 4;
   const int hl_q = (4 * q) / P, h_q = hb0 + hl_q;
   const bool hv = h_q < H;
   const float a = hv ? __expf(A_log[h_q * p_hs]) : 0.f, bias = hv ? dt_bias[h_q * p_hs] : 0.f;
-  // register-resident MFMA B operands of the head block
-  float dkvT[4][NS], Dh[4];
-  int mc[4];
+  // fragment-layout constants of this lane: column block c -> its 4 consecutive columns cb[c] .. cb[c]+3 of head hf[c]
+  int cb[4], hf[4];
+  float Dh[4];
+  bool hok[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    mc[c] = memcol<P, G>(c, i15);
-    const int hh = hb0 + mc[c] / P;
-    const bool ok = hh < H;
-    Dh[c] = ok ? D[hh * p_hs] : 0.f;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) dkvT[c][s] = ok ? dkv[(((int64_t)b * H + hh) * N + kk * NS + s) * P + (mc[c] % P)] : 0.f;
+    cb[c] = memcol<P, G>(c, 4 * kk);
+    hf[c] = cb[c] / P;
+    hok[c] = hb0 + hf[c] < H;
+    Dh[c] = hok[c] ? D[(hb0 + hf[c]) * p_hs] : 0.f;
   }
-  // B[k = column u = 4 s + kk of group g][j = n]: the transposes of KV / dKV
-  float kvC[G][GS], dkvB[G][GS];
-  int gc[G][GS];
+  // register-resident MFMA A operands.  dkvA[c][s] = dKV[h(c, i)][n = kk*NS + s][p(c, i)]  (rows i = the block's 16 columns, k = n);
+  // kvC / dkvB[c][e] = (d)KV[head of column memcol(c, 4 kk + e)][n = i][its p]              (rows i = n, k = the group's columns)
+  float dkvA[4][NS], kvC[4][4], dkvB[4][4];
 #pragma unroll
-  for (int g = 0; g < G; ++g)
+  for (int c = 0; c < 4; ++c) {
+    const int col = memcol<P, G>(c, j), hh = hb0 + col / P;
 #pragma unroll
-    for (int s = 0; s < GS; ++s) {
-      const int col = groupcol<P, G>(g, 4 * s + kk), hh = hb0 + col / P;
-      gc[g][s] = col;
-      const bool ok = hh < H && i15 < N;
-      const int64_t o = (((int64_t)b * H + hh) * N + i15) * P + (col % P);
-      kvC[g][s] = ok ? kv[o] : 0.f;
-      dkvB[g][s] = ok ? dkv[o] : 0.f;
+    for (int s = 0; s < NS; ++s) dkvA[c][s] = hh < H ? dkv[(((int64_t)b * H + hh) * N + kk * NS + s) * P + (col % P)] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int col2 = cb[c] + e;
+      const bool ok = hok[c] && j < N;
+      const int64_t o = (((int64_t)b * H + hb0 + hf[c]) * N + j) * P + (col2 % P);
+      kvC[c][e] = ok ? kv[o] : 0.f;
+      dkvB[c][e] = ok ? dkv[o] : 0.f;
     }
+  }
   float stD[4] = {0.f, 0.f, 0.f, 0.f}, stB[4] = {0.f, 0.f, 0.f, 0.f}, stA[4] = {0.f, 0.f, 0.f, 0.f};
   const int ntiles = (int)((l_end - l_begin + kTile - 1) / kTile);
   for (int tile = wave; tile < ntiles; tile += kWaves) {
     const int64_t t0 = l_begin + (int64_t)tile * kTile;
     const int nvalid = (int)(l_end - t0 < kTile ? l_end - t0 : kTile);
     const int64_t row0 = (int64_t)b * L + t0;
-    float4 gv[4], xv[4];
-    float wv[4], sv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int t = kk + 4 * r;
-      const bool ok = hv && t < nvalid;
-      gv[r] = ld_row4<T>(dy, row0 + t, lddy, col0 + 4 * q, ok);
-      xv[r] = ld_row4<T>(x, row0 + t, ldx, col0 + 4 * q, ok);
-      const float z = ok ? Io<T>::ld(dt_raw + (row0 + t) * lddt + (int64_t)h_q * dt_hs) + bias : 0.f;
-      wv[r] = ok ? softplusf_(z) * a : 0.f;
-      sv[r] = ok ? a * sigmoidf_(z) : 0.f;
-    }
-    stage_k_tile<T, KW>(Bm, ldb, row0, nvalid, sB, lane);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int t = kk + 4 * r;
-      lds_st4(sDY + t * kSX + 4 * q, gv[r]);
-      lds_st4(sX + t * kSX + 4 * q, xv[r]);
-      sW[t * HBK + hl_q] = wv[r];    // P = 8: two lanes of a head write the same value
-      sS[t * HBK + hl_q] = sv[r];
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- dCm = dy_g . KV_g^T,  dBm = (x w)_g . dKV_g^T     (rows = tokens, columns = n)
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      f32x4 aC = f32x4{0.f, 0.f, 0.f, 0.f}, aB = aC;
-#pragma unroll
-      for (int s = 0; s < GS; ++s) {
-        const int col = gc[g][s];
-        const float a1 = sDY[i15 * kSX + col];
-        const float a2 = sX[i15 * kSX + col] * sW[i15 * HBK + col / P];
-        aC = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, kvC[g][s], aC, 0, 0, 0);
-        aB = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, dkvB[g][s], aB, 0, 0, 0);
-      }
-      if (i15 < N) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sdC[(kk * 4 + r) * SK + g * N + i15] = aC[r];
-          sdB[(kk * 4 + r) * SK + g * N + i15] = aB[r];
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();   // every read of x above precedes its replacement by dx below
-    // ---- t = Bm_g . dKV_g ; dx, dw, ddt and the per-head statistics
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float av[NS];
-      const float* ap = sB + i15 * SK + (c / CPG) * N + kk * NS;
-      if (NS == 4) {
-        const float4 t = lds_ld4(ap);
-        av[0] = t.x; av[1] = t.y; av[NS - 2] = t.z; av[NS - 1] = t.w;
-      } else {
-        av[0] = ap[0]; av[1] = ap[1];
-      }
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < NS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], dkvT[c][s], acc, 0, 0, 0);
-      const int hl = mc[c] / P;
-      const bool first = (mc[c] % P) == 0;
+    {   // coalesced row-layout loads -> LDS (the transposer)
+      float4 gv[4], xv[4];
+      float wv[4], sv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int tok = kk * 4 + r;
-        float* px = sX + tok * kSX + mc[c];
-        const float xval = *px, gy = sDY[tok * kSX + mc[c]], w = sW[tok * HBK + hl];
-        *px = fmaf(w, acc[r], Dh[c] * gy);
-        float dw = acc[r] * xval, dd = gy * xval;   // sums over the P columns of the head: adjacent lanes
+        const int t = kk + 4 * r;
+        const bool ok = hv && t < nvalid;
+        gv[r] = ld_row4<T>(dy, row0 + t, lddy, col0 + 4 * q, ok);
+        xv[r] = ld_row4<T>(x, row0 + t, ldx, col0 + 4 * q, ok);
+        const float z = ok ? Io<T>::ld(dt_raw + (row0 + t) * lddt + (int64_t)h_q * dt_hs) + bias : 0.f;
+        wv[r] = ok ? softplusf_(z) * a : 0.f;
+        sv[r] = ok ? a * sigmoidf_(z) : 0.f;
+      }
 #pragma unroll
-        for (int o = 1; o < P; o <<= 1) {
-          dw += __shfl_xor(dw, o, 64);
-          dd += __shfl_xor(dd, o, 64);
-        }
-        const float dz = dw * sS[tok * HBK + hl];
-        if (first) {
-          sDdt[tok * HBK + hl] = dz;
-          stD[c] += dd;
-          stB[c] += dz;
-          stA[c] += dw * w;
+      for (int r = 0; r < 4; ++r) {
+        const int t = kk + 4 * r;
+        lds_st4(sDY + t * kSX + 4 * q, gv[r]);
+        lds_st4(sX + t * kSX + 4 * q, xv[r]);
+        sW[t * HBK + hl_q] = wv[r];    // P = 8: the two lanes of a head write the same value
+        sS[t * HBK + hl_q] = sv[r];
+      }
+    }
+    // Bm of token j in fragment order: n = kk*NS + s (the permutation dkvA uses)
+    float bf[G][NS];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const T* bp = Bm + (row0 + j) * ldb + g * N + kk * NS;
+      if (NS == 4) {
+        const float4 t = j < nvalid ? Io<T>::ld4(bp) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bf[g][0] = t.x; bf[g][1] = t.y; bf[g][NS - 2] = t.z; bf[g][NS - 1] = t.w;
+      } else {
+        bf[g][0] = j < nvalid ? Io<T>::ld(bp) : 0.f;
+        bf[g][1] = j < nvalid ? Io<T>::ld(bp + 1) : 0.f;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    f32x4 aC[G], aB[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) aC[g] = aB[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 gf = lds_ld4(sDY + j * kSX + cb[c]), xf = lds_ld4(sX + j * kSX + cb[c]);
+      const float wf = sW[j * HBK + hf[c]], sf = sS[j * HBK + hf[c]];
+      const float ge[4] = {gf.x, gf.y, gf.z, gf.w}, xe[4] = {xf.x, xf.y, xf.z, xf.w};
+      // dCm^T += KV_g . dy_g^T,  dBm^T += dKV_g . (x w)_g^T     (rows = n, columns = tokens; k = this block's 16 columns)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        aC[c / CPG] = __builtin_amdgcn_mfma_f32_16x16x4f32(kvC[c][e], ge[e], aC[c / CPG], 0, 0, 0);
+        aB[c / CPG] = __builtin_amdgcn_mfma_f32_16x16x4f32(dkvB[c][e], xe[e] * wf, aB[c / CPG], 0, 0, 0);
+      }
+      // t^T = dKV_c^T . Bm_g^T     (rows = the block's columns, columns = tokens): reg r <-> column cb[c] + r
+      f32x4 tt = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) tt = __builtin_amdgcn_mfma_f32_16x16x4f32(dkvA[c][s], bf[c / CPG][s], tt, 0, 0, 0);
+      float dw = (tt[0] * xe[0] + tt[1] * xe[1]) + (tt[2] * xe[2] + tt[3] * xe[3]);
+      float dd = (ge[0] * xe[0] + ge[1] * xe[1]) + (ge[2] * xe[2] + ge[3] * xe[3]);
+#pragma unroll
+      for (int o = 1; o < LPH; o <<= 1) {   // P = 8: a head's 8 columns sit in two kk-lanes
+        dw += __shfl_xor(dw, 16 * o, 64);
+        dd += __shfl_xor(dd, 16 * o, 64);
+      }
+      const float dz = dw * sf;
+      lds_st4(sX + j * kSX + cb[c], make_float4(fmaf(wf, tt[0], Dh[c] * ge[0]), fmaf(wf, tt[1], Dh[c] * ge[1]), fmaf(wf, tt[2], Dh[c] * ge[2]),
+                                                fmaf(wf, tt[3], Dh[c] * ge[3])));
+      if ((cb[c] % P) == 0) {   // one lane per (token, head)
+        sS[j * HBK + hf[c]] = dz;
+        stD[c] += dd;
+        stB[c] += dz;
+        stA[c] += dw * wf;
+      }
+    }
+    // dBm / dCm rows: lane (token j, kk) holds n = 4 kk .. 4 kk + 3 of every group
+    if (j < nvalid && 4 * kk < N) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float4 vb = make_float4(aB[g][0], aB[g][1], aB[g][2], aB[g][3]), vc = make_float4(aC[g][0], aC[g][1], aC[g][2], aC[g][3]);
+        if (nhb == 1) {
+          Io<T>::st4(dBm + (row0 + j) * lddb + g * N + 4 * kk, vb);
+          Io<T>::st4(dCm + (row0 + j) * lddc + g * N + 4 * kk, vc);
+        } else {
+          float* dst = bcpart + (((int64_t)blockIdx.y * gridDim.z + b) * L + (t0 + j)) * (2 * KW);
+          *reinterpret_cast<float4*>(dst + g * N + 4 * kk) = vb;
+          *reinterpret_cast<float4*>(dst + KW + g * N + 4 * kk) = vc;
         }
       }
     }
     __builtin_amdgcn_wave_barrier();
-    // ---- coalesced stores
+    // coalesced stores of dx rows and of ddt_raw
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int t = kk + 4 * r;
@@ -461,47 +469,31 @@ __global__ __launch_bounds__(kBlock) void ssd_bwd_kernel(
 #pragma unroll
       for (int r = 0; r < IT; ++r) {
         const int f = lane + 64 * r, t = f / HBK, hh = f % HBK;
-        if (f < kTile * HBK && t < nvalid && hb0 + hh < H) Io<T>::st(ddt_raw + (row0 + t) * ldddt + (int64_t)(hb0 + hh) * dt_hs, sDdt[t * HBK + hh]);
-      }
-    }
-    {
-      constexpr int Q = KW / 4, TOT = kTile * Q, IT = (TOT + 63) / 64;
-#pragma unroll
-      for (int r = 0; r < IT; ++r) {
-        const int f = lane + 64 * r, t = f / Q, qq = f % Q;
-        if (f < TOT && t < nvalid) {
-          const float4 vb = lds_ld4(sdB + t * SK + 4 * qq), vc = lds_ld4(sdC + t * SK + 4 * qq);
-          if (nhb == 1) {
-            Io<T>::st4(dBm + (row0 + t) * lddb + 4 * qq, vb);
-            Io<T>::st4(dCm + (row0 + t) * lddc + 4 * qq, vc);
-          } else {
-            float* dst = bcpart + (((int64_t)blockIdx.y * gridDim.z + b) * L + (t0 + t)) * (2 * KW);
-            *reinterpret_cast<float4*>(dst + 4 * qq) = vb;
-            *reinterpret_cast<float4*>(dst + KW + 4 * qq) = vc;
-          }
-        }
+        if (f < kTile * HBK && t < nvalid && hb0 + hh < H) Io<T>::st(ddt_raw + (row0 + t) * ldddt + (int64_t)(hb0 + hh) * dt_hs, sS[t * HBK + hh]);
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
-  // per-head statistics: lanes with (column % P == 0) hold this wave's sums for head mc[c]/P over their 4 token rows per tile;
-  // fold the 4 kk rows by shuffles, the waves through LDS, one partial row per workgroup
+  // per-head statistics: the lane with (first column of the head) holds the sums of its token column j over the wave's tiles;
+  // fold the 16 tokens by shuffles, the waves through LDS, one partial row per workgroup
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    stD[c] += __shfl_xor(stD[c], 16, 64); stD[c] += __shfl_xor(stD[c], 32, 64);
-    stB[c] += __shfl_xor(stB[c], 16, 64); stB[c] += __shfl_xor(stB[c], 32, 64);
-    stA[c] += __shfl_xor(stA[c], 16, 64); stA[c] += __shfl_xor(stA[c], 32, 64);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      stD[c] += __shfl_xor(stD[c], o, 64);
+      stB[c] += __shfl_xor(stB[c], o, 64);
+      stA[c] += __shfl_xor(stA[c], o, 64);
+    }
   }
   __syncthreads();
   float* sred = smem;   // [kWaves][3][HBK]
-  if (kk == 0) {
+  if (j == 0) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      if ((mc[c] % P) == 0) {
-        const int hl = mc[c] / P;
-        sred[(wave * 3 + 0) * HBK + hl] = stD[c];
-        sred[(wave * 3 + 1) * HBK + hl] = stB[c];
-        sred[(wave * 3 + 2) * HBK + hl] = stA[c];
+      if ((cb[c] % P) == 0) {
+        sred[(wave * 3 + 0) * HBK + hf[c]] = stD[c];
+        sred[(wave * 3 + 1) * HBK + hf[c]] = stB[c];
+        sred[(wave * 3 + 2) * HBK + hf[c]] = stA[c];
       }
   }
   __syncthreads();
@@ -624,7 +616,7 @@ int run_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void
             int64_t lddx, void* dBm, int64_t lddb, void* dCm, int64_t lddc, void* ddt_raw, int64_t ldddt, float* hpart, float* bcpart,
             float* ddt_bias, float* dA_log, float* dD, int64_t B, int64_t L, int64_t H, hipStream_t st) {
   const Geo g = make_geo(B, L, H, P, false);
-  constexpr int KW = G * N, HBK = kCols / P, kSlab = 2 * kTile * kSX + 3 * kTile * (KW + 4) + 3 * kTile * HBK;
+  constexpr int HBK = kCols / P, kSlab = 2 * kTile * kSX + 2 * kTile * HBK;
   const size_t smem = sizeof(float) * (size_t)kWaves * kSlab;
   const dim3 grid(g.nchunk, g.nhb, (unsigned)B);
   {

@@ -49,6 +49,19 @@ int adnm_abi_version(void);
 int adnm_prof_enable(int on);
 int64_t adnm_prof_collect(char* buf, int64_t buflen);
 
+/* Deferred second-stage folds.  Every cross-workgroup reduction of the library is "fp32 partials + a deterministic fold launch".
+ * For parameter gradients (nothing reads them before clip_grad_norm_ / the optimiser, train.py:140-144) the caller may batch
+ * those fold launches: create a queue, bind it on the calling thread around *_bwd entry points (their folds are then QUEUED, the
+ * partial workspaces and destinations must stay alive), and flush it — one launch per 16 queued folds — before anything reads
+ * the results.  Unbound (the default) every fold is launched at once.  The queue is a caller-owned host object; the binding is
+ * thread-local (like adnm_last_error), so concurrent threads / devices do not see each other's queues.  Results are bitwise
+ * the same either way. */
+void* adnm_foldq_create(void);
+int adnm_foldq_destroy(void* q);
+int adnm_foldq_bind(void* q); /* NULL unbinds */
+int64_t adnm_foldq_pending(void* q);
+int adnm_foldq_flush(void* q, adnm_stream_t stream);
+
 /* ---------------------------------------------------------------- row norms (K2, K7)
  * y = scale * ( xhat * w + b ) + shift,  xhat = (x - mu) * rstd
  *   RMSNorm   (mamba_ssm RMSNorm bound at ADNMUNet.py:278, used ADNMUNet.py:149,155): subtract_mean=0, b=NULL

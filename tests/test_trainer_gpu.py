@@ -106,3 +106,32 @@ def test_benchmarked_workload_step_vs_reference_fixture():
     names = [str(n) for n in z["names"]]
     assert names == [k for k, _ in model.named_parameters()]
     check_update_deltas(z, names, [p.detach().double() - b for p, b in zip(model.parameters(), before)])
+
+
+def test_deferred_folds_are_bitwise_neutral():
+    """Batching the second-stage fold launches of the parameter gradients (ops.FOLDS / adnm_foldq_*) must not change a bit of the
+    step: same partials, same fold arithmetic, only fewer launches — including Block.beta1/beta2, which receive two contributions."""
+    from models.ADNMUNet import create_ADNMUNet
+    from models.loss import enRainfallLoss
+    frames = recipe.radar_batch(1, 25, 64, name="defer").to(DEV)
+    x, tgt = frames[:, :5].contiguous(), frames[:, 5:].contiguous()
+    flats = []
+    for defer in (False, True):
+        model = create_ADNMUNet(5, 20, 6, img_size=64)
+        recipe.fill_parameters(model)
+        model = model.to(DEV).train()
+        tr = FlatTrainer(model, enRainfallLoss(0.57, 0.25, gamma=0.0), max_norm=0.025, use_graph=False, defer_folds=defer)
+        tr.prepare(x, tgt)
+        from adnm_hip import lib
+        lib.query("adnm_prof_enable", 1)
+        tr._run_eager(x, tgt)
+        torch.cuda.synchronize()
+        lib.query("adnm_prof_enable", 0)
+        import ctypes
+        buf = ctypes.create_string_buffer(1 << 20)
+        lib.query("adnm_prof_collect", buf, len(buf))
+        nfold = sum(int(l.split("\t")[1]) for l in buf.value.decode().splitlines() if "fold" in l.split("\t")[0])
+        flats.append((tr.flat_g.clone(), nfold))
+        del tr
+    assert torch.equal(flats[0][0], flats[1][0])
+    assert flats[1][1] < 0.5 * flats[0][1], (flats[0][1], flats[1][1])
