@@ -96,8 +96,9 @@ class GradRegistry:
                     # a fresh tensor object on the same memory: AccumulateGrad only keeps ("steals") a gradient nobody else references
                     return g.detach()
                 second = ptr in self._claimed[owner]
-        if second:   # autograd is about to add this contribution to the first one: the first must be complete
+        if second:   # autograd is about to ADD this contribution to the first one: both must be complete when it does
             FOLDS.flush(device)
+            FOLDS.hold(device)   # ... so the producer of this one must not defer its fold either
         return torch.empty(tuple(shape), dtype=dtype, device=device)
 
 
@@ -130,8 +131,17 @@ class FoldRegistry:
         its own), the queue is flushed on the way out.  Scoped in time, so plain autograd users of the device are never deferred."""
         return _Active(self, device, on)
 
+    def hold(self, device):
+        """The next defer() on this device (the call that asked for the gradient slice just refused) runs undeferred."""
+        ent = self._q.get(device.index)
+        if ent is not None:
+            ent["hold"] = True
+
     def defer(self, device, *keep):
-        return _Deferred(self._q.get(device.index), keep, self._lock)
+        ent = self._q.get(device.index)
+        if ent is not None and ent.pop("hold", False):
+            ent = None
+        return _Deferred(ent, keep, self._lock)
 
     def flush(self, device):
         ent = self._q.get(device.index)
@@ -968,7 +978,7 @@ def _sk_operand(t, what):
 def _skgemm(op, a, b, bias, c, dbias, M, N, K, defer=False):
     if lib.query("adnm_skgemm_supported", op, M, N, K) != 1:
         raise RuntimeError(f"adnm_hip linear: no kernel takes op={('NT', 'NN', 'TN')[op]} M={M} N={N} K={K} "
-                           "(NT needs K % 16 == 0; NN needs N % 16 == 0 and K % 4 == 0; TN needs N % 4 == 0 and K % 4 == 0)")
+                           "(every op needs N % 4 == 0 and K % 4 == 0)")
     nb = lib.query("adnm_skgemm_ws_bytes", op, M, N, K)
     ws = _ws(nb, a.device)
     with FOLDS.defer(a.device, ws, c, dbias) if defer else _NODEFER:   # only the weight-gradient op (TN) may wait for its split-K fold

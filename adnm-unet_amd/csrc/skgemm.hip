@@ -63,11 +63,14 @@ __global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
   // so nothing in here waits for a load and all 8 stay in flight under the previous chunk's MFMAs.
   auto fetch = [&](int c, float (&av)[kT][4], float (&bv)[kT][4]) {
     const int r0 = c * 16;
+    // operands contiguous along the reduction: a ragged last chunk (R % 16 != 0; R % 4 == 0) re-reads a valid quad; its products are
+    // zeroed on the A side when they are used
+    const int rq4 = r0 + 4 * kk < p.R ? r0 + 4 * kk : 0;
     if (A_RC) {
 #pragma unroll
       for (int t = 0; t < kT; ++t) {
         const int row = i0 + 16 * t + l15, rc = row < p.I ? row : p.I - 1;
-        const float4 v = *reinterpret_cast<const float4*>(p.A + (int64_t)rc * p.sa_i + r0 + 4 * kk);
+        const float4 v = *reinterpret_cast<const float4*>(p.A + (int64_t)rc * p.sa_i + rq4);
         av[t][0] = v.x; av[t][1] = v.y; av[t][2] = v.z; av[t][3] = v.w;
       }
     } else {
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
 #pragma unroll
       for (int t = 0; t < kT; ++t) {
         const int col = j0 + 16 * t + l15, cc = col < p.J ? col : p.J - 1;
-        const float4 v = *reinterpret_cast<const float4*>(p.B + (int64_t)cc * p.sb_j + r0 + 4 * kk);
+        const float4 v = *reinterpret_cast<const float4*>(p.B + (int64_t)cc * p.sb_j + rq4);
         bv[t][0] = v.x; bv[t][1] = v.y; bv[t][2] = v.z; bv[t][3] = v.w;
       }
     } else {
@@ -107,10 +110,10 @@ __global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
   // scheduling barriers keep the compiler from sinking them below), so HBM latency hides under the matrix pipe
   float a0[kT][4], b0[kT][4], a1[kT][4], b1[kT][4];
   auto compute = [&](int c, float (&av)[kT][4], const float (&bv)[kT][4]) {
-    if (!A_RC && c * 16 + 16 > p.R) {   // reduction tail (wave-uniform branch)
+    if (c * 16 + 16 > p.R) {   // reduction tail (wave-uniform branch): zero the A side, the B side may hold anything finite
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (c * 16 + 4 * kk + e >= p.R) av[0][e] = av[1][e] = av[2][e] = av[3][e] = 0.f;
+        if (c * 16 + 4 * kk + (A_RC ? 0 : e) >= p.R) av[0][e] = av[1][e] = av[2][e] = av[3][e] = 0.f;
     }
     if (!A_RC && p.bsum) {
 #pragma unroll
@@ -244,8 +247,8 @@ Plan make_plan(int64_t I, int64_t J, int64_t R, bool direct) {
 
 int shape_ok(int op, int64_t M, int64_t N, int64_t K) {
   if (M < 1 || N < 4 || K < 4 || M > 65536 || N > 16384 || K > 16384) return 0;
-  if (op == ADNM_SKGEMM_NT) return K % 16 == 0;
-  if (op == ADNM_SKGEMM_NN) return N % 16 == 0 && K % 4 == 0;
+  if (op == ADNM_SKGEMM_NT) return K % 4 == 0;
+  if (op == ADNM_SKGEMM_NN) return N % 4 == 0 && K % 4 == 0;
   if (op == ADNM_SKGEMM_TN) return N % 4 == 0 && K % 4 == 0;
   return 0;
 }

@@ -258,8 +258,8 @@ int adnm_colsum(const float* x, float* out, int64_t rows, int64_t n, adnm_stream
  * nn.Linear with M <= 65536 token rows and up to 16384 features: Mamba2.in_proj/out_proj (ADNssd.py:309,461),
  * FeedForward.project_in/out (model_untils.py:193,196), Mlp (:64,67), ConvFFD (:217,221), Block.out_proj (ADNMUNet.py:163),
  * StandardAttention.to_qkv/to_out (ADNssd.py:33-34), Channel_Att_Bridge.att* (model_untils.py:744-750).  fp32, row-major:
- *   ADNM_SKGEMM_NT: c[M,N] = a[M,K] . b[N,K]^T (+ bias[N])           forward          K % 16 == 0
- *   ADNM_SKGEMM_NN: c[M,K] = a[M,N] . b[N,K]                         input gradient   N % 16 == 0, K % 4 == 0
+ *   ADNM_SKGEMM_NT: c[M,N] = a[M,K] . b[N,K]^T (+ bias[N])           forward          K % 4 == 0
+ *   ADNM_SKGEMM_NN: c[M,K] = a[M,N] . b[N,K]                         input gradient   N % 4 == 0, K % 4 == 0
  *   ADNM_SKGEMM_TN: c[N,K] = a[M,N]^T . b[M,K]; dbias[N] = sum_m a   weight gradient  N % 4 == 0, K % 4 == 0
  * lda / ldb / ldc: row strides in elements (multiples of 4); bias only with NT, dbias only with TN; c / dbias OVERWRITTEN. */
 #define ADNM_SKGEMM_NT 0

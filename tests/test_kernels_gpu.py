@@ -500,6 +500,8 @@ def test_rownorm_tap(mean):
     (1024, 256, 1216, True),    # no split: direct stores
     (4, 2144, 256, True),       # Channel_Att_Bridge.att*: 4 rows
     (100, 48, 36, True),        # ragged tiles
+    (300, 20, 64, False),       # ragged reduction (K = 20: a chunk of 16 and a quad) forward, ragged N in the input gradient
+    (128, 40, 24, True),
     (4096, 128, 544, False),
 ])
 def test_skgemm_linear(M, K, N, bias):
@@ -589,8 +591,8 @@ def test_unsupported_shapes_raise():
         ops.tokmean_tap(odd)
     with pytest.raises(RuntimeError, match="no PyTorch fallback"):
         ops.conv1d3(torch.zeros(2, 2, 8, device=DEV), torch.zeros(1, 1, 3, device=DEV), None)
-    with pytest.raises(RuntimeError, match="no kernel takes"):
-        ops.linear(torch.zeros(8, 10, device=DEV), torch.zeros(12, 10, device=DEV))      # K = 10: not a multiple of 16
+    with pytest.raises(RuntimeError, match="adnm_hip linear"):
+        ops.linear(torch.zeros(8, 10, device=DEV), torch.zeros(12, 10, device=DEV))      # K = 10: not a multiple of 4
     with pytest.raises(RuntimeError, match="GPU only"):
         ops.linear(torch.zeros(8, 16), torch.zeros(12, 16))
     from models.model_untils import DownSample
