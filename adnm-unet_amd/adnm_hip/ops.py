@@ -1092,6 +1092,75 @@ def linear(x, w, bias=None):
     return LinearFn.apply(x, w, bias)
 
 
+# ------------------------------------------------------------------------------------------- dense 3x3 conv (K5)
+def _conv3_wstrides(w):
+    """(ws_n, ws_tap, ws_k) of a (Cout, Cin, 3, 3) weight in either memory layout the kernel reads in place."""
+    sn, sk, skh, skw = w.stride()
+    if skh != 3 * skw:
+        return None
+    return sn, skw, sk
+
+
+class Conv3Fn(torch.autograd.Function):
+    """nn.Conv2d(k=3, s=1, p=1) [+ bias] [+ GELU] on (B, H*W, Cin) tokens (csrc/conv3.hip): implicit GEMM on MFMA, bias and
+    activation in the epilogue; the pre-activation is saved for backward exactly as autograd saves it for a separate GELU."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, H, W, act):
+        B, L, K = x.shape
+        N = w.shape[0]
+        _need_gpu(x)
+        if x.dtype != torch.float32 or w.dtype != torch.float32 or tuple(w.shape[1:]) != (K, 3, 3) or L != H * W:
+            _unsupported("conv3", f"needs fp32 (B, H*W, Cin) tokens and a (Cout, Cin, 3, 3) fp32 weight, got {x.dtype} {tuple(x.shape)}, {tuple(w.shape)}")
+        x2 = x.reshape(B * L, K)
+        x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
+        ws_ = _conv3_wstrides(w)
+        if ws_ is None:
+            w = w.contiguous()
+            ws_ = _conv3_wstrides(w)
+        dev = x.device
+        y = torch.empty((B * L, N), dtype=torch.float32, device=dev)
+        pre = torch.empty((B * L, N), dtype=torch.float32, device=dev) if act != lib.ACT_NONE else None
+        nb = lib.query("adnm_conv3_ws_bytes", B, H, W, K, N)
+        wsb = _ws(nb, dev)
+        lib.call("adnm_conv3_fwd", x2.data_ptr(), x2.stride(0), w.data_ptr(), ws_[0], ws_[1], ws_[2], _p(bias), y.data_ptr(), N, _p(pre), N,
+                 wsb.data_ptr(), nb, B, H, W, K, N, act, _stream())
+        ctx.save_for_backward(x2, w, pre)
+        ctx.meta = (B, H, W, K, N, act, ws_, bias.data_ptr() if bias is not None else 0, bias is not None)
+        return y.view(B, L, N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, pre = ctx.saved_tensors
+        B, H, W, K, N, act, ws_, b_ptr, has_bias = ctx.meta
+        dev = x2.device
+        dy2 = dy.reshape(B * H * W, N)
+        dy2 = dy2 if dy2.stride(-1) == 1 else dy2.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((B * H * W, K), dtype=torch.float32, device=dev)
+            nb = lib.query("adnm_conv3_ws_bytes", B, H, W, N, K)
+            wsb = _ws(nb, dev)
+            lib.call("adnm_conv3_dgrad", dy2.data_ptr(), dy2.stride(0), _p(pre), N, act, w.data_ptr(), ws_[0], ws_[1], ws_[2], dx.data_ptr(), K,
+                     wsb.data_ptr(), nb, B, H, W, K, N, _stream())
+            dx = dx.view(B, H * W, K)
+        # the weight gradient is produced in (Cout, 3, 3, Cin) memory order: the flat trainer's channels-last slice takes it as it lies
+        g = grad_dst(w.data_ptr(), (N, K, 3, 3), dev)
+        if not g.permute(0, 2, 3, 1).is_contiguous():
+            g = torch.empty((N, 3, 3, K), dtype=torch.float32, device=dev).permute(0, 3, 1, 2)
+        db = grad_dst(b_ptr, (N,), dev) if has_bias else None
+        nb = lib.query("adnm_conv3_wgrad_ws_bytes", B, H, W, K, N)
+        wsb = _ws(nb, dev)
+        with FOLDS.defer(dev, wsb, g, db):
+            lib.call("adnm_conv3_wgrad", dy2.data_ptr(), dy2.stride(0), _p(pre), N, act, x2.data_ptr(), x2.stride(0), g.data_ptr(), _p(db),
+                     wsb.data_ptr(), nb, B, H, W, K, N, _stream())
+        return dx, g, db, None, None, None
+
+
+def conv3(x, w, bias, H, W, act=lib.ACT_NONE):
+    return Conv3Fn.apply(x, w, bias, H, W, act)
+
+
 # ------------------------------------------------------------------------------------------- K1b chunked scan
 def k_ssd_scan_fwd(x, xhs, Bm, Cm, dt, dths, dt_bias, A_log, D, phs, y, yhs, B, L, H, P, N, G, chunk, reverse):
     """x / y: row views whose element (row, h, p) sits at [row, h*hs + p]; Bm, Cm (M, G*N) row views; dt (M, .) row view."""

@@ -2,8 +2,8 @@
 // Reference call sites: PatchEmbed.conv2 5->32 (model_untils.py:259-273), WTLayer.conv 32->64 / 64->128 / 256->64 / 128->32 /
 // 64->32 (:376-387), OutProj.conv[0] 32->64 and conv2 20->20 (:818-849) — nn.Conv2d(k=3, s=1, p=1) [+ bias] [+ GELU].
 //
-//   forward   out[p, n]  = act( sum_{tap, k} in[p + tap, k] * W[n, tap, k] + bias[n] )        p = pixel, n = Cout, k = Cin
-//   dgrad     din[p, k]  = sum_{tap, n} dpre[p - tap, n] * W[n, tap, k]                       dpre = dout * act'(pre)
+//   forward   out[p, n]   = act( sum_{tap, k} in[p + tap, k] * W[n, tap, k] + bias[n] )       p = pixel, n = Cout, k = Cin
+//   dgrad     din[p, k]   = sum_{tap, n} dpre[p - tap, n] * W[n, tap, k]                      dpre = dout * act'(pre)
 //   wgrad     dW[n,tap,k] = sum_p dpre[p, n] * in[p + tap, k],   dbias[n] = sum_p dpre[p, n]
 //
 // One gather-GEMM kernel serves forward and dgrad (dgrad = the same conv over dpre with the weight read through swapped
@@ -26,8 +26,8 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kBlock = 256, kWaves = 4;
 constexpr int CK = 16, CKP = CK + 4;   // channels per staged chunk, LDS pitch of a pixel
-constexpr int MB = 2;                  // pixel blocks per wave (forward / dgrad)
-constexpr int kMaxNB = 4;              // output-channel blocks per workgroup (64 channels)
+constexpr int MB = 2;                  // pixel blocks per wave
+constexpr int kTilePix = kWaves * MB * 16;
 
 struct Geo {
   int TW, RB, TH;      // pixel-block width, rows per pixel block, tile rows
@@ -47,31 +47,463 @@ inline Geo make_geo(int64_t B, int64_t H, int64_t W) {
 struct ConvArgs {
   const float* in;  int64_t ldin;     // (B*H*W, K) pixel rows
   const float* in2; int64_t ldin2;    // dgrad: pre-activation of the forward output; the staged value is in * act'(in2)
-  int act;                            // forward: epilogue activation; dgrad: the activation whose derivative multiplies `in`
   const float* w; int64_t sn, st, sk; int flip;   // W(n, tap, k) = w[n*sn + (flip ? 8-tap : tap)*st + k*sk]
   const float* bias;
   float* out; int64_t ldo;            // act(acc + bias)
   float* pre; int64_t ldpre;          // acc + bias (saved for backward), or NULL
   float* part;                        // nsplit > 1: partials [z][B*H*W][N]
   int B, H, W, K, N, nsplit, chunks_per_split;
-  int TW, RB, TH;
+  int TW, RB, TH, VR, tiles_x;
+  int vec_in, vec_w, vec_out;         // 16-byte access is legal for the input rows / the weight's reduction axis / the output rows
 };
 
-template <int ACT>
-__device__ __forceinline__ float stage_val(float v, float p) { return ACT == ADNM_ACT_NONE ? v : v * act_grad<ACT>(p); }
+// pixel row of tall-image position (v, x), or -1 outside the images
+__device__ __forceinline__ int64_t pixel_of(int v, int x, int B, int H, int W, int VR) {
+  if (v < 0 || v >= VR || x < 0 || x >= W) return -1;
+  const int b = v / (H + 1), y = v - b * (H + 1);
+  return y < H ? ((int64_t)b * H + y) * W + x : -1;
+}
 
-// ---- stage the (TH+2) x (TW+2) input tile of channels [c0, c0+16) of the tall image into LDS (zeros outside)
+// ---- stage the (TH+2) x (TW+2) tile of channels [c0, c0+16) of (in [* act'(in2)]) into LDS, zeros outside
 template <int ACT>
-__device__ __forceinline__ void stage_tile(const ConvArgs& a, float* sIn, int v0, int x0, int c0) {
-  const int TWp = a.TW + 2, PT = (a.TH + 2) * TWp;
-  const bool quad_ok = (a.K & 3) == 0;
+__device__ __forceinline__ void stage_tile(const float* __restrict__ in, int64_t ldin, const float* __restrict__ in2, int64_t ldin2, bool vec,
+                                           int K, int B, int H, int W, int VR, int TW, int TH, float* sIn, int v0, int x0, int c0) {
+  const int TWp = TW + 2, PT = (TH + 2) * TWp;
   for (int it = threadIdx.x; it < PT * 4; it += kBlock) {
-    const int pix = it >> 2, q = it & 3, r = pix / TWp, c = pix - r * TWp;
-    const int v = v0 - 1 + r, x = x0 - 1 + c, ch = c0 + 4 * q;
-    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (v >= 0 && v < a.VR_dummy_guard_never_used()) {}
-    (void)val;
+    const int pix = it >> 2, q = it & 3, r = pix / TWp, c = pix - r * TWp, ch = c0 + 4 * q;
+    const int64_t p = pixel_of(v0 - 1 + r, x0 - 1 + c, B, H, W, VR);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p >= 0 && ch < K) {
+      if (vec && ch + 3 < K) {
+        const float4 t = *reinterpret_cast<const float4*>(in + p * ldin + ch);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        if (ACT != ADNM_ACT_NONE) {
+          const float4 u = *reinterpret_cast<const float4*>(in2 + p * ldin2 + ch);
+          v[0] *= act_grad<ACT>(u.x); v[1] *= act_grad<ACT>(u.y); v[2] *= act_grad<ACT>(u.z); v[3] *= act_grad<ACT>(u.w);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (ch + e < K) {
+            v[e] = in[p * ldin + ch + e];
+            if (ACT != ADNM_ACT_NONE) v[e] *= act_grad<ACT>(in2[p * ldin2 + ch + e]);
+          }
+      }
+    }
+    *reinterpret_cast<float4*>(sIn + pix * CKP + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
+// ================================================================================================ forward / dgrad
+template <int NB, int ACT_IN, int ACT_OUT>
+__global__ __launch_bounds__(kBlock) void conv3_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sIn[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, kk = lane >> 4;
+  const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+  const int x0 = tx * a.TW, v0 = ty * a.TH, n0 = blockIdx.y * NB * 16;
+  const int TWp = a.TW + 2;
+  const int dyj = j / a.TW, dxj = j - dyj * a.TW;
+  int base[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) base[mb] = (((wave * MB + mb) * a.RB + dyj) * TWp + dxj) * CKP + 4 * kk;
+  f32x4 acc[NB][MB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nchunks = (a.K + CK - 1) / CK;
+  const int cbeg = blockIdx.z * a.chunks_per_split;
+  const int cend = cbeg + a.chunks_per_split < nchunks ? cbeg + a.chunks_per_split : nchunks;
+  for (int c = cbeg; c < cend; ++c) {
+    __syncthreads();
+    stage_tile<ACT_IN>(a.in, a.ldin, a.in2, a.ldin2, a.vec_in != 0, a.K, a.B, a.H, a.W, a.VR, a.TW, a.TH, sIn, v0, x0, c * CK);
+    __syncthreads();
+    const int k0 = c * CK + 4 * kk;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = ((tap / 3) * TWp + (tap % 3)) * CKP;
+      const int64_t wt = (int64_t)(a.flip ? 8 - tap : tap) * a.st;
+      float wa[NB][4];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + nb * 16 + j;
+        wa[nb][0] = wa[nb][1] = wa[nb][2] = wa[nb][3] = 0.f;
+        if (n < a.N && k0 < a.K) {
+          const float* wp = a.w + (int64_t)n * a.sn + wt + (int64_t)k0 * a.sk;
+          if (a.vec_w && k0 + 3 < a.K) {
+            const float4 t = *reinterpret_cast<const float4*>(wp);
+            wa[nb][0] = t.x; wa[nb][1] = t.y; wa[nb][2] = t.z; wa[nb][3] = t.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (k0 + e < a.K) wa[nb][e] = wp[(int64_t)e * a.sk];
+          }
+        }
+      }
+      float xb[MB][4];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const float4 t = *reinterpret_cast<const float4*>(sIn + base[mb] + toff);
+        xb[mb][0] = t.x; xb[mb][1] = t.y; xb[mb][2] = t.z; xb[mb][3] = t.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb][e], xb[mb][e], acc[nb][mb], 0, 0, 0);
+    }
+  }
+  // epilogue.  D layout: row = channel (kk*4 + reg) of the block, column = pixel j
+  const int64_t M = (int64_t)a.B * a.H * a.W;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int64_t p = pixel_of(v0 + (wave * MB + mb) * a.RB + dyj, x0 + dxj, a.B, a.H, a.W, a.VR);
+    if (p < 0) continue;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = n0 + nb * 16 + 4 * kk;
+      if (n >= a.N) continue;
+      float v[4] = {acc[nb][mb][0], acc[nb][mb][1], acc[nb][mb][2], acc[nb][mb][3]};
+      if (a.nsplit > 1) {   // N % 4 == 0 is required for split runs (host-checked)
+        *reinterpret_cast<float4*>(a.part + ((int64_t)blockIdx.z * M + p) * a.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (a.bias && n + r < a.N) v[r] += a.bias[n + r];
+      if (a.vec_out && n + 3 < a.N) {
+        if (a.pre) *reinterpret_cast<float4*>(a.pre + p * a.ldpre + n) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(a.out + p * a.ldo + n) = make_float4(act_fwd<ACT_OUT>(v[0]), act_fwd<ACT_OUT>(v[1]), act_fwd<ACT_OUT>(v[2]), act_fwd<ACT_OUT>(v[3]));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < a.N) {
+            if (a.pre) a.pre[p * a.ldpre + n + r] = v[r];
+            a.out[p * a.ldo + n + r] = act_fwd<ACT_OUT>(v[r]);
+          }
+      }
+    }
+  }
+}
+
+// split runs: out = act(sum_z part[z] + bias) (+ pre), one float4 per thread
+template <int ACT_OUT>
+__global__ __launch_bounds__(256) void conv3_join_kernel(const float* __restrict__ part, int nsplit, int64_t M, int N, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int64_t ldo, float* __restrict__ pre, int64_t ldpre) {
+  const int nq = N >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * nq) return;
+  const int64_t p = i / nq;
+  const int n = (int)(i - p * nq) * 4;
+  float4 s = *reinterpret_cast<const float4*>(part + p * N + n);
+  for (int z = 1; z < nsplit; ++z) {
+    const float4 t = *reinterpret_cast<const float4*>(part + ((int64_t)z * M + p) * N + n);
+    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  }
+  if (bias) { s.x += bias[n]; s.y += bias[n + 1]; s.z += bias[n + 2]; s.w += bias[n + 3]; }
+  if (pre) *reinterpret_cast<float4*>(pre + p * ldpre + n) = s;
+  *reinterpret_cast<float4*>(out + p * ldo + n) = make_float4(act_fwd<ACT_OUT>(s.x), act_fwd<ACT_OUT>(s.y), act_fwd<ACT_OUT>(s.z), act_fwd<ACT_OUT>(s.w));
+}
+
+// ================================================================================================ wgrad
+struct WgArgs {
+  const float* dout; int64_t lddo;    // (M, N)
+  const float* pre;  int64_t ldpre;   // pre-activation of the forward output (ACT != NONE)
+  const float* in;   int64_t ldin;    // (M, K)
+  float* part; int64_t rowlen;        // partial rows [gridDim.x * 4][N*9*K (+ N)]
+  int want_bias;
+  int B, H, W, K, N, ntiles;
+  int TW, RB, TH, VR, tiles_x;
+  int vec_in, vec_do;
+};
+
+template <int NB, int ACT>
+__global__ __launch_bounds__(kBlock) void conv3_wgrad_kernel(WgArgs a) {
+  constexpr int DP = NB * 16 + 16;   // pitch of a dpre pixel row: (DP mod 32) == 16 -> conflict-free A-operand reads
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int TWp = a.TW + 2;
+  float* sIn = smem;
+  float* sD = smem + (a.TH + 2) * TWp * CKP;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, kk = lane >> 4;
+  const int c0 = blockIdx.y * CK, n0 = blockIdx.z * NB * 16;
+  f32x4 acc[9][NB];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[t][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x, x0 = tx * a.TW, v0 = ty * a.TH;
+    __syncthreads();
+    stage_tile<ADNM_ACT_NONE>(a.in, a.ldin, nullptr, 0, a.vec_in != 0, a.K, a.B, a.H, a.W, a.VR, a.TW, a.TH, sIn, v0, x0, c0);
+    // dpre tile: pixel block pb (0..7), pixel jj of it -> row pb*16 + jj; NB*16 channels from n0
+    for (int it = threadIdx.x; it < kTilePix * NB * 4; it += kBlock) {
+      const int pxl = it / (NB * 4), q = it - pxl * (NB * 4), n = n0 + 4 * q;
+      const int pb = pxl >> 4, jj = pxl & 15, dy_ = jj / a.TW, dx_ = jj - dy_ * a.TW;
+      const int64_t p = pixel_of(v0 + pb * a.RB + dy_, x0 + dx_, a.B, a.H, a.W, a.VR);
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p >= 0 && n < a.N) {
+        if (a.vec_do && n + 3 < a.N) {
+          const float4 t = *reinterpret_cast<const float4*>(a.dout + p * a.lddo + n);
+          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+          if (ACT != ADNM_ACT_NONE) {
+            const float4 u = *reinterpret_cast<const float4*>(a.pre + p * a.ldpre + n);
+            v[0] *= act_grad<ACT>(u.x); v[1] *= act_grad<ACT>(u.y); v[2] *= act_grad<ACT>(u.z); v[3] *= act_grad<ACT>(u.w);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < a.N) {
+              v[e] = a.dout[p * a.lddo + n + e];
+              if (ACT != ADNM_ACT_NONE) v[e] *= act_grad<ACT>(a.pre[p * a.ldpre + n + e]);
+            }
+        }
+      }
+      *reinterpret_cast<float4*>(sD + pxl * DP + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pbw = 0; pbw < MB; ++pbw) {
+      const int pb = wave * MB + pbw;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int jj = 4 * s + kk, pxl = pb * 16 + jj, dy_ = jj / a.TW, dx_ = jj - dy_ * a.TW;
+        float av[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) av[nb] = sD[pxl * DP + nb * 16 + j];   // A[i = channel][k = pixel]
+        const float* bp = sIn + ((pb * a.RB + dy_) * TWp + dx_) * CKP + j;      // B[k = pixel][j = input channel], tap (0,0)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const float bv = bp[((tap / 3) * TWp + (tap % 3)) * CKP];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[tap][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nb], bv, acc[tap][nb], 0, 0, 0);
+        }
+      }
+    }
+    if (a.want_bias && blockIdx.y == 0 && lane < NB * 16) {
+#pragma unroll 8
+      for (int p = 0; p < MB * 16; ++p) bsum += sD[(wave * MB * 16 + p) * DP + lane];
+    }
+  }
+  // this wave's partial row: element (n, tap, k) at (n*9 + tap)*K + k ; D layout: row = channel kk*4 + reg, column = input channel j
+  float* dst = a.part + ((int64_t)blockIdx.x * kWaves + wave) * a.rowlen;
+  const int k = c0 + j;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + nb * 16 + kk * 4 + r;
+        if (n < a.N && k < a.K) dst[((int64_t)n * 9 + tap) * a.K + k] = acc[tap][nb][r];
+      }
+  if (a.want_bias && blockIdx.y == 0 && lane < NB * 16 && n0 + lane < a.N) dst[(int64_t)a.N * 9 * a.K + n0 + lane] = bsum;
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+int check_shape(const char* who, int64_t B, int64_t H, int64_t W, int64_t K, int64_t N) {
+  ADNM_REQUIRE(B > 0 && H > 0 && W > 0 && K > 0 && N > 0, "%s: empty shape", who);
+  ADNM_REQUIRE(B * (H + 1) < (1ll << 30) && B * H * W < (1ll << 31) && K <= 65536 && N <= 65536, "%s: shape too large", who);
+  return ADNM_OK;
+}
+
+struct Split {
+  int nb, ngroups, nsplit, cps;
+};
+inline Split plan_split(const Geo& g, int64_t K, int64_t N) {
+  Split s;
+  s.nb = N > 32 ? 4 : (N > 16 ? 2 : 1);
+  s.ngroups = (int)adnm_cdiv(N, s.nb * 16);
+  const int nchunks = (int)adnm_cdiv(K, CK);
+  const int64_t blocks = (int64_t)g.tiles_x * g.tiles_y * s.ngroups;
+  int want = 1;
+  if (blocks < 256 && nchunks >= 4 && N % 4 == 0) {   // deep maps: few pixels, long reductions
+    want = (int)adnm_cdiv(512, blocks);
+    if (want > nchunks / 2) want = nchunks / 2;
+    if (want > 16) want = 16;
+    if (want < 1) want = 1;
+  }
+  s.cps = (int)adnm_cdiv(nchunks, want);
+  s.nsplit = (int)adnm_cdiv(nchunks, s.cps);
+  return s;
+}
+
+template <int ACT_IN, int ACT_OUT>
+int launch_conv(const ConvArgs& a, const Geo& g, const Split& s, hipStream_t st, const char* prof, double bytes) {
+  const size_t smem = sizeof(float) * (size_t)(g.TH + 2) * (g.TW + 2) * CKP;
+  const dim3 grid((unsigned)(g.tiles_x * g.tiles_y), (unsigned)s.ngroups, (unsigned)s.nsplit);
+  ADNM_PROF(prof, st, bytes);
+  if (s.nb == 4) conv3_kernel<4, ACT_IN, ACT_OUT><<<grid, kBlock, smem, st>>>(a);
+  else if (s.nb == 2) conv3_kernel<2, ACT_IN, ACT_OUT><<<grid, kBlock, smem, st>>>(a);
+  else conv3_kernel<1, ACT_IN, ACT_OUT><<<grid, kBlock, smem, st>>>(a);
+  return ADNM_OK;
+}
+
+void fill_geo(ConvArgs& a, const Geo& g) { a.TW = g.TW, a.RB = g.RB, a.TH = g.TH, a.VR = g.VR, a.tiles_x = g.tiles_x; }
+
 }  // namespace
+
+extern "C" int64_t adnm_conv3_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t K, int64_t N) {
+  if (B <= 0 || H <= 0 || W <= 0 || K <= 0 || N <= 0) return 0;
+  const Geo g = make_geo(B, H, W);
+  const Split s = plan_split(g, K, N);
+  return s.nsplit > 1 ? (int64_t)s.nsplit * B * H * W * N * (int64_t)sizeof(float) : 16;
+}
+
+// out = act(conv3x3(in, w) + bias); pre (optional) receives the value before the activation.
+// w element (n, ky, kx, k) at w[n*ws_n + (ky*3+kx)*ws_tap + k*ws_k] — both nn.Conv2d's (Cout,Cin,3,3) layout (ws_n=9K, ws_tap=1, ws_k=9)
+// and the channels-last one (Cout,3,3,Cin) (ws_n=9K, ws_tap=K, ws_k=1) are read in place.
+extern "C" int adnm_conv3_fwd(const float* in, int64_t ldin, const float* w, int64_t ws_n, int64_t ws_tap, int64_t ws_k, const float* bias,
+                              float* out, int64_t ldo, float* pre, int64_t ldpre, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W,
+                              int64_t K, int64_t N, int act, adnm_stream_t stream) {
+  if (int rc = check_shape("conv3_fwd", B, H, W, K, N)) return rc;
+  ADNM_REQUIRE(in && w && out, "conv3_fwd: null pointer");
+  ADNM_REQUIRE(ldin >= K && ldo >= N && (!pre || ldpre >= N), "conv3_fwd: row strides smaller than the rows");
+  ADNM_REQUIRE(act == ADNM_ACT_NONE || act == ADNM_ACT_GELU, "conv3_fwd: activation %d not in {none, gelu}", act);
+  const Geo g = make_geo(B, H, W);
+  const Split s = plan_split(g, K, N);
+  if (s.nsplit > 1 && (!ws || ws_bytes < adnm_conv3_ws_bytes(B, H, W, K, N))) {
+    adnm_set_error("conv3_fwd: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_conv3_ws_bytes(B, H, W, K, N));
+    return ADNM_EWORKSPACE;
+  }
+  ConvArgs a{};
+  a.in = in, a.ldin = ldin, a.in2 = nullptr, a.ldin2 = 0;
+  a.w = w, a.sn = ws_n, a.st = ws_tap, a.sk = ws_k, a.flip = 0;
+  a.bias = bias, a.out = out, a.ldo = ldo, a.pre = pre, a.ldpre = ldpre, a.part = (float*)ws;
+  a.B = (int)B, a.H = (int)H, a.W = (int)W, a.K = (int)K, a.N = (int)N, a.nsplit = s.nsplit, a.chunks_per_split = s.cps;
+  fill_geo(a, g);
+  a.vec_in = al16(in) && ldin % 4 == 0 && K % 4 == 0;
+  a.vec_w = ws_k == 1 && al16(w) && ws_n % 4 == 0 && ws_tap % 4 == 0 && K % 4 == 0;
+  a.vec_out = al16(out) && ldo % 4 == 0 && N % 4 == 0 && (!pre || (al16(pre) && ldpre % 4 == 0));
+  hipStream_t st = (hipStream_t)stream;
+  const double bytes = 4.0 * ((double)B * H * W * (K + N * (pre ? 2 : 1)) + 9.0 * K * N);
+  if (act == ADNM_ACT_GELU && s.nsplit == 1) launch_conv<ADNM_ACT_NONE, ADNM_ACT_GELU>(a, g, s, st, "conv3_fwd", bytes);
+  else launch_conv<ADNM_ACT_NONE, ADNM_ACT_NONE>(a, g, s, st, "conv3_fwd", bytes);
+  ADNM_CHECK_LAUNCH("conv3_fwd");
+  if (s.nsplit > 1) {
+    const int64_t M = B * H * W, nthreads = M * (N / 4);
+    ADNM_PROF("conv3_join", st, 4.0 * M * N * (s.nsplit + 1 + (pre ? 1 : 0)));
+    if (act == ADNM_ACT_GELU)
+      conv3_join_kernel<ADNM_ACT_GELU><<<(unsigned)adnm_cdiv(nthreads, 256), 256, 0, st>>>((const float*)ws, s.nsplit, M, (int)N, bias, out, ldo, pre, ldpre);
+    else
+      conv3_join_kernel<ADNM_ACT_NONE><<<(unsigned)adnm_cdiv(nthreads, 256), 256, 0, st>>>((const float*)ws, s.nsplit, M, (int)N, bias, out, ldo, pre, ldpre);
+    ADNM_CHECK_LAUNCH("conv3_join");
+  }
+  return ADNM_OK;
+}
+
+// din = conv3x3^T(dout * act'(pre), w): the input gradient of adnm_conv3_fwd (K = Cin, N = Cout of the forward conv, same w strides).
+extern "C" int adnm_conv3_dgrad(const float* dout, int64_t lddo, const float* pre, int64_t ldpre, int act, const float* w, int64_t ws_n,
+                                int64_t ws_tap, int64_t ws_k, float* din, int64_t lddin, void* ws, int64_t ws_bytes, int64_t B, int64_t H,
+                                int64_t W, int64_t K, int64_t N, adnm_stream_t stream) {
+  if (int rc = check_shape("conv3_dgrad", B, H, W, K, N)) return rc;
+  ADNM_REQUIRE(dout && w && din, "conv3_dgrad: null pointer");
+  ADNM_REQUIRE(act == ADNM_ACT_NONE || (act == ADNM_ACT_GELU && pre), "conv3_dgrad: activation %d needs the saved pre-activation", act);
+  ADNM_REQUIRE(lddo >= N && lddin >= K && (!pre || ldpre >= N), "conv3_dgrad: row strides smaller than the rows");
+  const Geo g = make_geo(B, H, W);
+  const Split s = plan_split(g, N, K);   // reduction over the forward's output channels, K columns out
+  if (s.nsplit > 1 && (!ws || ws_bytes < adnm_conv3_ws_bytes(B, H, W, N, K))) {
+    adnm_set_error("conv3_dgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_conv3_ws_bytes(B, H, W, N, K));
+    return ADNM_EWORKSPACE;
+  }
+  ConvArgs a{};
+  a.in = dout, a.ldin = lddo, a.in2 = pre, a.ldin2 = ldpre;
+  a.w = w, a.sn = ws_k, a.st = ws_tap, a.sk = ws_n, a.flip = 1;   // W'(k, tap, n) = W(n, 8 - tap, k)
+  a.bias = nullptr, a.out = din, a.ldo = lddin, a.pre = nullptr, a.ldpre = 0, a.part = (float*)ws;
+  a.B = (int)B, a.H = (int)H, a.W = (int)W, a.K = (int)N, a.N = (int)K, a.nsplit = s.nsplit, a.chunks_per_split = s.cps;
+  fill_geo(a, g);
+  a.vec_in = al16(dout) && lddo % 4 == 0 && N % 4 == 0 && (!pre || (al16(pre) && ldpre % 4 == 0));
+  a.vec_w = a.sk == 1 && al16(w) && a.sn % 4 == 0 && a.st % 4 == 0 && N % 4 == 0;
+  a.vec_out = al16(din) && lddin % 4 == 0 && K % 4 == 0;
+  hipStream_t st = (hipStream_t)stream;
+  const double bytes = 4.0 * ((double)B * H * W * (K + N * (act != ADNM_ACT_NONE ? 2 : 1)) + 9.0 * K * N);
+  if (act == ADNM_ACT_GELU) launch_conv<ADNM_ACT_GELU, ADNM_ACT_NONE>(a, g, s, st, "conv3_dgrad", bytes);
+  else launch_conv<ADNM_ACT_NONE, ADNM_ACT_NONE>(a, g, s, st, "conv3_dgrad", bytes);
+  ADNM_CHECK_LAUNCH("conv3_dgrad");
+  if (s.nsplit > 1) {
+    const int64_t M = B * H * W, nthreads = M * (K / 4);
+    ADNM_PROF("conv3_join", st, 4.0 * M * K * (s.nsplit + 1));
+    conv3_join_kernel<ADNM_ACT_NONE><<<(unsigned)adnm_cdiv(nthreads, 256), 256, 0, st>>>((const float*)ws, s.nsplit, M, (int)K, nullptr, din, lddin, nullptr, 0);
+    ADNM_CHECK_LAUNCH("conv3_join");
+  }
+  return ADNM_OK;
+}
+
+namespace {
+struct WgPlan {
+  int nb, cogroups, cichunks, rows;
+  int64_t rowlen;
+};
+inline WgPlan plan_wgrad(const Geo& g, int64_t K, int64_t N, bool bias) {
+  WgPlan p;
+  p.nb = N > 32 ? 4 : (N > 16 ? 2 : 1);
+  p.cogroups = (int)adnm_cdiv(N, p.nb * 16);
+  p.cichunks = (int)adnm_cdiv(K, CK);
+  p.rowlen = N * 9 * K + (bias ? N : 0);
+  const int64_t ntiles = (int64_t)g.tiles_x * g.tiles_y;
+  int64_t r = adnm_cdiv(512, (int64_t)p.cichunks * p.cogroups);              // ~512 workgroups
+  const int64_t by_mem = (int64_t)(8 << 20) / (p.rowlen * 4 * kWaves);     // partials capped at ~8 MB
+  if (r > by_mem) r = by_mem;
+  if (r > ntiles) r = ntiles;
+  if (r > 64) r = 64;
+  p.rows = (int)(r < 1 ? 1 : r);
+  return p;
+}
+}  // namespace
+
+extern "C" int64_t adnm_conv3_wgrad_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t K, int64_t N) {
+  if (B <= 0 || H <= 0 || W <= 0 || K <= 0 || N <= 0) return 0;
+  const WgPlan p = plan_wgrad(make_geo(B, H, W), K, N, true);
+  return (int64_t)p.rows * kWaves * p.rowlen * (int64_t)sizeof(float);
+}
+
+// dw[n][tap][k] (contiguous, = the channels-last weight layout) and dbias[n] (optional) of adnm_conv3_fwd.  OVERWRITES both.
+extern "C" int adnm_conv3_wgrad(const float* dout, int64_t lddo, const float* pre, int64_t ldpre, int act, const float* in, int64_t ldin,
+                                float* dw, float* dbias, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W, int64_t K, int64_t N,
+                                adnm_stream_t stream) {
+  if (int rc = check_shape("conv3_wgrad", B, H, W, K, N)) return rc;
+  ADNM_REQUIRE(dout && in && dw, "conv3_wgrad: null pointer");
+  ADNM_REQUIRE(act == ADNM_ACT_NONE || (act == ADNM_ACT_GELU && pre), "conv3_wgrad: activation %d needs the saved pre-activation", act);
+  ADNM_REQUIRE(lddo >= N && ldin >= K && (!pre || ldpre >= N), "conv3_wgrad: row strides smaller than the rows");
+  ADNM_REQUIRE(N * 9 * K + N < (1ll << 31), "conv3_wgrad: weight too large");
+  const Geo g = make_geo(B, H, W);
+  const WgPlan p = plan_wgrad(g, K, N, dbias != nullptr);
+  if (!ws || ws_bytes < (int64_t)p.rows * kWaves * p.rowlen * 4) {
+    adnm_set_error("conv3_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)((int64_t)p.rows * kWaves * p.rowlen * 4));
+    return ADNM_EWORKSPACE;
+  }
+  WgArgs a{};
+  a.dout = dout, a.lddo = lddo, a.pre = pre, a.ldpre = ldpre, a.in = in, a.ldin = ldin;
+  a.part = (float*)ws, a.rowlen = p.rowlen, a.want_bias = dbias != nullptr;
+  a.B = (int)B, a.H = (int)H, a.W = (int)W, a.K = (int)K, a.N = (int)N, a.ntiles = g.tiles_x * g.tiles_y;
+  a.TW = g.TW, a.RB = g.RB, a.TH = g.TH, a.VR = g.VR, a.tiles_x = g.tiles_x;
+  a.vec_in = al16(in) && ldin % 4 == 0 && K % 4 == 0;
+  a.vec_do = al16(dout) && lddo % 4 == 0 && N % 4 == 0 && (!pre || (al16(pre) && ldpre % 4 == 0));
+  hipStream_t st = (hipStream_t)stream;
+  const size_t smem = sizeof(float) * ((size_t)(g.TH + 2) * (g.TW + 2) * CKP + (size_t)kTilePix * (p.nb * 16 + 16));
+  const dim3 grid((unsigned)p.rows, (unsigned)p.cichunks, (unsigned)p.cogroups);
+  {
+    ADNM_PROF("conv3_wgrad", st, 4.0 * ((double)B * H * W * (K + N * (act != ADNM_ACT_NONE ? 2 : 1)) + 9.0 * K * N));
+#define WG(NBV)                                                                                                   \
+  do {                                                                                                            \
+    if (act == ADNM_ACT_GELU) {                                                                                   \
+      ADNM_ALLOW_LDS((conv3_wgrad_kernel<NBV, ADNM_ACT_GELU>), smem, "conv3_wgrad");                              \
+      conv3_wgrad_kernel<NBV, ADNM_ACT_GELU><<<grid, kBlock, smem, st>>>(a);                                      \
+    } else {                                                                                                      \
+      ADNM_ALLOW_LDS((conv3_wgrad_kernel<NBV, ADNM_ACT_NONE>), smem, "conv3_wgrad");                              \
+      conv3_wgrad_kernel<NBV, ADNM_ACT_NONE><<<grid, kBlock, smem, st>>>(a);                                      \
+    }                                                                                                             \
+  } while (0)
+    if (p.nb == 4) WG(4);
+    else if (p.nb == 2) WG(2);
+    else WG(1);
+#undef WG
+  }
+  ADNM_CHECK_LAUNCH("conv3_wgrad");
+  adnm_launch_fold("conv3_wgrad_fold", (const float*)ws, p.rows * kWaves, (int)p.rowlen, {dw, (int)(N * 9 * K)}, {dbias, dbias ? (int)N : 0}, {nullptr, 0},
+                   {nullptr, 0}, st);
+  ADNM_CHECK_LAUNCH("conv3_wgrad_fold");
+  return ADNM_OK;
+}

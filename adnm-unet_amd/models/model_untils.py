@@ -155,6 +155,11 @@ class Conv2dLayer(nn.Module):
         return (c.groups == c.in_channels == c.out_channels and k[0] == k[1] and k[0] in (3, 5) and c.stride == (1, 1)
                 and c.dilation == (1, 1) and c.padding in ((k[0] // 2, k[0] // 2), 'same') and c.in_channels % 4 == 0)
 
+    def _is_dense3(self):
+        c = self.conv
+        return (c.kernel_size == (3, 3) and c.groups == 1 and c.stride == (1, 1) and c.dilation == (1, 1) and c.padding in ((1, 1), 'same')
+                and c.padding_mode == 'zeros')
+
     def _is_pointwise(self):
         c = self.conv
         return c.kernel_size == (1, 1) and c.groups == 1 and c.stride == (1, 1) and c.padding in ((0, 0), 'same', 'valid')
@@ -172,8 +177,12 @@ class Conv2dLayer(nn.Module):
             x = ops.dwconv(x, self.conv.weight, self.conv.bias, h, w, lib.ACT_NONE)
         elif self._is_pointwise():
             x = ops.linear(x, self.conv.weight.reshape(self.conv.out_channels, -1), self.conv.bias)
+        elif self._is_dense3():   # implicit-GEMM MFMA conv, bias + GELU in its epilogue
+            fuse = not self.norm and code in (lib.ACT_NONE, lib.ACT_GELU)
+            x = ops.conv3(x, self.conv.weight, self.conv.bias, h, w, code if fuse else lib.ACT_NONE)
+            fused_act = fuse
         else:
-            x = tokens_of(self.conv(nchw_view(x, h, w)))
+            raise RuntimeError(f"Conv2dLayer: no HIP kernel for {self.conv} on tokens (depthwise 3x3/5x5, 1x1 and dense 3x3 'same' convs are implemented)")
         if self.norm:
             x, fused_act = self._norm_tokens(x, h, w, code)
         if self.act and not fused_act:

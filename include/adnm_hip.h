@@ -315,6 +315,29 @@ int adnm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, flo
                     float beta2, float eps, float weight_decay, float max_norm, void* ws, int64_t ws_bytes,
                     adnm_stream_t stream);
 
+/* ---------------------------------------------------------------- dense 3x3 'same' convolution, NHWC, on MFMA (K5)
+ * nn.Conv2d(k=3, s=1, p=1) [+ bias] [+ GELU] of the U-Net conv stack: PatchEmbed.conv2 (model_untils.py:259-273), WTLayer.conv
+ * (:376-387), OutProj.conv[0] / conv2 (:818-849).  Implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32).
+ *   in:(B*H*W, K) pixel rows (row stride ldin), out:(B*H*W, N) (ldo); K = Cin, N = Cout (any sizes; 16-byte paths need % 4).
+ *   w element (n, ky, kx, k) at w[n*ws_n + (ky*3+kx)*ws_tap + k*ws_k]: nn.Conv2d's own (Cout,Cin,3,3) layout is
+ *   (ws_n, ws_tap, ws_k) = (9K, 1, 9), the channels-last one (Cout,3,3,Cin) is (9K, K, 1) — both are read in place.
+ *   act: ADNM_ACT_NONE | ADNM_ACT_GELU applied in the epilogue; pre (optional, row stride ldpre) receives conv + bias BEFORE the
+ *   activation — the tensor autograd would have saved for the reference's separate GELU; dgrad / wgrad take it back.
+ *   dgrad: din = conv^T(dout * act'(pre));  wgrad: dw[n][tap][k] contiguous (= the channels-last weight layout), dbias optional;
+ *   both OVERWRITE.  Workspaces: split-K partials of the deep maps (fwd / dgrad: adnm_conv3_ws_bytes with the (K, N) of THAT
+ *   launch's reduction / output), per-wave partial rows (wgrad). */
+int64_t adnm_conv3_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t K, int64_t N);
+int adnm_conv3_fwd(const float* in, int64_t ldin, const float* w, int64_t ws_n, int64_t ws_tap, int64_t ws_k, const float* bias,
+                   float* out, int64_t ldo, float* pre, int64_t ldpre, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W,
+                   int64_t K, int64_t N, int act, adnm_stream_t stream);
+int adnm_conv3_dgrad(const float* dout, int64_t lddo, const float* pre, int64_t ldpre, int act, const float* w, int64_t ws_n,
+                     int64_t ws_tap, int64_t ws_k, float* din, int64_t lddin, void* ws, int64_t ws_bytes, int64_t B, int64_t H,
+                     int64_t W, int64_t K, int64_t N, adnm_stream_t stream);
+int64_t adnm_conv3_wgrad_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t K, int64_t N);
+int adnm_conv3_wgrad(const float* dout, int64_t lddo, const float* pre, int64_t ldpre, int act, const float* in, int64_t ldin,
+                     float* dw, float* dbias, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W, int64_t K, int64_t N,
+                     adnm_stream_t stream);
+
 /* Wire format of the data-parallel gradient all-reduce that replaces nn.DataParallel's reduce_add_coalesced (train.py:99-102;
  * SURVEY.md §8e): dst[i] = (bf16)(scale * src[i]) before the collective, dst[i] = scale * (float)src[i] after it (scale = 1/world
  * folds the average in).  n elements, both buffers 16-byte aligned. */

@@ -598,3 +598,37 @@ def test_unsupported_shapes_raise():
     from models.model_untils import DownSample
     with pytest.raises(RuntimeError, match="max-pool"):
         DownSample(dim=6)(torch.zeros(1, 16, 6, device=DEV))
+
+
+# ------------------------------------------------------------------------------------------- dense 3x3 conv (K5)
+@pytest.mark.parametrize("B,H,W,K,N,act,bias,cl", [
+    (2, 16, 16, 5, 32, lib.ACT_GELU, False, False),     # PatchEmbed.conv2: ragged Cin, nn.Conv2d weight layout
+    (4, 128, 128, 64, 32, lib.ACT_GELU, True, True),    # config-2 decoder6 conv, channels-last weight (the flat trainer's layout)
+    (2, 8, 8, 256, 64, lib.ACT_GELU, True, True),       # deep map: split-K partials + join
+    (1, 4, 4, 64, 128, lib.ACT_NONE, True, False),      # 4x4 map: a pixel block is 4 rows x 4 columns
+    (2, 12, 12, 16, 24, lib.ACT_GELU, True, False),     # width not a multiple of the tile
+    (1, 64, 64, 20, 20, lib.ACT_NONE, False, True),     # OutProj.conv2: 20 -> 20
+    (2, 7, 9, 8, 12, lib.ACT_GELU, True, False),        # odd sizes
+    (1, 32, 32, 32, 200, lib.ACT_NONE, True, True),     # several output-channel groups
+])
+def test_conv3(B, H, W, K, N, act, bias, cl):
+    x, w, cot = T(f"c3.x{H}{K}", (B, H * W, K)), T(f"c3.w{N}{K}", (N, K, 3, 3), 0.2), T(f"c3.c{H}{N}", (B, H * W, N))
+    b = T(f"c3.b{N}", (N,)) if bias else None
+    xo, wo, bo = leaf(x.double()), leaf(w.double()), (leaf(b.double()) if bias else None)
+    yo = F.conv2d(xo.view(B, H, W, K).permute(0, 3, 1, 2), wo, bo, padding=1)
+    if act == lib.ACT_GELU:
+        yo = F.gelu(yo)
+    yo = yo.permute(0, 2, 3, 1).reshape(B, H * W, N)
+    (yo * cot.double()).sum().backward()
+    xg, bg = leaf(x, DEV), (leaf(b, DEV) if bias else None)
+    wg = w.to(DEV)
+    if cl:   # (Cout, 3, 3, Cin) memory order behind the logical (Cout, Cin, 3, 3) shape
+        wg = wg.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    wg = wg.detach().requires_grad_(True)
+    yg = ops.conv3(xg, wg, bg, H, W, act)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, OUT_TOL, "y")
+    assert_close(xg.grad, xo.grad, GRAD_TOL, "dx")
+    assert_close(wg.grad, wo.grad, GRAD_TOL, "dw")
+    if bias:
+        assert_close(bg.grad, bo.grad, GRAD_TOL, "db")
