@@ -225,7 +225,10 @@ struct Plan {
 };
 // ~2048 waves when the reduction is long enough (>= 1 chunk = 64 MFMAs per wave): up to 8 waves of a block share a tile
 // (summed in LDS), further slices go through partials kept below ~2 MB.  direct: the output cannot take partials.
-Plan make_plan(int64_t I, int64_t J, int64_t R, bool direct) {
+// critical: the result is consumed by the next launch (NT forward, NN input gradient), so the fold of a cross-workgroup split
+// sits on the critical path (~6.5 us of launch + kernel): split only when one workgroup per tile would take longer than that
+// saves (a wave issues a 16-step chunk in ~0.85 us).  The weight-gradient op's fold is batched and deferred: it always splits.
+Plan make_plan(int64_t I, int64_t J, int64_t R, bool direct, bool critical) {
   Plan pl;
   pl.tiles_i = (int)adnm_cdiv(I, 64);
   pl.tiles_j = (int)adnm_cdiv(J, 64);
@@ -239,6 +242,7 @@ Plan make_plan(int64_t I, int64_t J, int64_t R, bool direct) {
   int64_t nbs = adnm_cdiv(want, pl.wpt);
   const int64_t by_mem = (int64_t)(2 << 20) / (I * J * 4);
   if (nbs > by_mem) nbs = by_mem;
+  if (critical && 0.85 * pl.nchunks / pl.wpt <= 13.0) nbs = 1;
   if (nbs < 1 || direct) nbs = 1;
   pl.cpw = (int)adnm_cdiv(pl.nchunks, nbs * pl.wpt);
   pl.nbs = (int)adnm_cdiv(adnm_cdiv(pl.nchunks, pl.cpw), pl.wpt);
@@ -265,7 +269,7 @@ extern "C" int64_t adnm_skgemm_ws_bytes(int op, int64_t M, int64_t N, int64_t K)
   if (!shape_ok(op, M, N, K)) return -1;
   int64_t I, J, R;
   dims(op, M, N, K, &I, &J, &R);
-  const Plan pl = make_plan(I, J, R, false);
+  const Plan pl = make_plan(I, J, R, false, op != ADNM_SKGEMM_TN);
   return pl.nbs > 1 ? (int64_t)pl.nbs * (I * J + I) * (int64_t)sizeof(float) : 16;
 }
 
@@ -279,7 +283,7 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   ADNM_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= (op == ADNM_SKGEMM_NT ? K : N) && ldb >= K, "skgemm: bad operand row strides");
   ADNM_REQUIRE(!(bias && op != ADNM_SKGEMM_NT) && !(dbias && op != ADNM_SKGEMM_TN), "skgemm: bias only with NT, dbias only with TN");
   ADNM_REQUIRE(((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) % 16 == 0, "skgemm: operands must be 16-byte aligned");
-  const Plan pl = make_plan(I, J, R, ldc != J);   // a strided output (column slice of a wider buffer) takes no partials
+  const Plan pl = make_plan(I, J, R, ldc != J, op != ADNM_SKGEMM_TN);   // a strided output (column slice of a wider buffer) takes no partials
   const bool split = pl.nbs > 1;
   if (split && (!ws || ws_bytes < adnm_skgemm_ws_bytes(op, M, N, K))) {
     adnm_set_error("skgemm: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_skgemm_ws_bytes(op, M, N, K));

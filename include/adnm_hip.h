@@ -338,6 +338,18 @@ int adnm_conv3_wgrad(const float* dout, int64_t lddo, const float* pre, int64_t 
                      float* dw, float* dbias, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W, int64_t K, int64_t N,
                      adnm_stream_t stream);
 
+/* ---------------------------------------------------------------- stride-2 transposed conv of UpSample (K9)
+ * nn.ConvTranspose2d(C, C, k=3, s=2, p=1, output_padding=1) (model_untils.py:120-158,490-520) = one GEMM over the input pixels
+ * (cols[B*H*W, 9C] = X . Wf, adnm_skgemm op NN on the weight as it lies) + these two data-movement kernels:
+ *   col2im: out[b, oy, ox, :] = bias + the taps of cols whose parity matches (oy, ox) (1, 2, 2 or 4 of them: the 4 phases);
+ *   im2col: dcols[(b,iy,ix), tap, :] = dout[b, 2iy-1+ky, 2ix-1+kx, :] (0 outside): then dX = dcols . Wf^T (op NT), dWf = X^T . dcols (op TN).
+ * Column (tap, c) of a cols row sits at tap*col_tap_stride + c*col_c_stride: (C, 1) for the (Cin, 3, 3, Cout) weight order,
+ * (1, 9) for nn.ConvTranspose2d's own (Cin, Cout, 3, 3).  out / dout: (B*2H*2W, C) pixel rows. */
+int adnm_convt_col2im(const float* cols, int64_t ldc, int64_t col_tap_stride, int64_t col_c_stride, const float* bias, float* out,
+                      int64_t ldo, int64_t B, int64_t H, int64_t W, int64_t C, adnm_stream_t stream);
+int adnm_convt_im2col(const float* dout, int64_t lddo, float* dcols, int64_t ldc, int64_t col_tap_stride, int64_t col_c_stride,
+                      int64_t B, int64_t H, int64_t W, int64_t C, adnm_stream_t stream);
+
 /* Wire format of the data-parallel gradient all-reduce that replaces nn.DataParallel's reduce_add_coalesced (train.py:99-102;
  * SURVEY.md §8e): dst[i] = (bf16)(scale * src[i]) before the collective, dst[i] = scale * (float)src[i] after it (scale = 1/world
  * folds the average in).  n elements, both buffers 16-byte aligned. */
