@@ -138,6 +138,8 @@ class FoldRegistry:
             ent["hold"] = True
 
     def defer(self, device, *keep):
+        """keep: the partial WORKSPACES (and other inputs of the queued folds) — never the destinations: a gradient tensor that
+        something else references is not adopted by autograd's AccumulateGrad but cloned on the spot, i.e. before the fold ran."""
         ent = self._q.get(device.index)
         if ent is not None and ent.pop("hold", False):
             ent = None
@@ -235,7 +237,7 @@ def k_rownorm_bwd(dy2, x2, w, b, scale, mu, rstd, mean, want_b, want_affine, dx_
     px, ldx = _rows(x2)
     pdx, lddx = _rows(dx)
     pres, ldres = _rows(dres) if dres is not None else (None, 0)
-    with FOLDS.defer(dev, ws, dw, db, dsc, dsh) if defer else _NODEFER:
+    with FOLDS.defer(dev, ws) if defer else _NODEFER:
         lib.call("adnm_rownorm_bwd", pdy, lddy, px, ldx, _p(w), _p(b), _p(scale), mu.data_ptr(), rstd.data_ptr(), pdx, lddx,
                  dw.data_ptr(), _p(db), _p(dsc), _p(dsh), pres, ldres, ws.data_ptr(), nb, M, d, int(mean), _dt(x2), _stream())
     return dx, dw, db, dsc, dsh
@@ -284,7 +286,7 @@ def k_ssd_bwd(dy, x, Bm, Cm, dt_raw, dt_bias, A_log, D, kv, dx, dBm, dCm, ddt, B
     g = []
     for t in (dx, dBm, dCm, ddt):
         g += list(_rows(t))
-    with FOLDS.defer(dev, ws, dbias, dA, dD):   # the per-head statistics [dD | ddt_bias | dA_log] are parameter gradients
+    with FOLDS.defer(dev, ws):   # the per-head statistics [dD | ddt_bias | dA_log] are parameter gradients
         lib.call("adnm_ssd_reduce_bwd", a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], 1, _p(dt_bias), _p(A_log), _p(D), 1,
                  kv.data_ptr(), g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], dbias.data_ptr(), dA.data_ptr(), dD.data_ptr(),
                  ws.data_ptr(), nb, B, L, H, P, N, G, _dt(x), _stream())
@@ -315,7 +317,7 @@ def k_dwconv_bwd(dy, x, wt, bias, B, H, W, C, K, act, dx=None, want_bias=False, 
     pdy, lddy = _rows(dy)
     px, ldx = _rows(x)
     pdx, lddx = _rows(dx)
-    with FOLDS.defer(dev, ws, dwt, db):   # taps / bias gradients: parameters, or prep intermediates flushed at the prep node
+    with FOLDS.defer(dev, ws):   # taps / bias gradients: parameters, or prep intermediates flushed at the prep node
         lib.call("adnm_dwconv_bwd", pdy, lddy, px, ldx, _p(wt), _p(bias), _p(dpre), pdx, lddx, _p(dwt), _p(db), ws.data_ptr(),
                  nb, B, H, W, C, K, K, act, int(chan_major), _dt(x), _stream())
     return dx, dwt, db
@@ -494,7 +496,7 @@ class CatMixFn(torch.autograd.Function):
         ws = _ws(nb, x2.device)
         (pg, ldg), (px, ldx), (pr, ldr) = _rows(g), _rows(x2), _rows(r2)
         pf, ldf = _rows(f2) if f2 is not None else (None, 0)
-        with FOLDS.defer(x2.device, ws, da):   # alpha1..4: one merge node per module
+        with FOLDS.defer(x2.device, ws):   # alpha1..4: one merge node per module
             lib.call("adnm_catmix_bwd", pg, ldg, px, ldx, pr, ldr, pf, ldf, _p(a1), _p(a2), _p(a3), _p(a4), _p(dx), _p(dr), _p(df), da.data_ptr(),
                      ws.data_ptr(), nb, M, d, _dt(g), _stream())
         v = lambda t: t.view(ctx.shp) if t is not None else None
@@ -826,7 +828,7 @@ class LinCombFn(torch.autograd.Function):
         sp = [_p(s) for s in ss] + [None] * (3 - n)
         dsp = [_p(s) for s in dss] + [None] * (3 - n)
         pg, ldg = _rows(g)
-        with FOLDS.defer(dev, ws, dgamma, *dss):
+        with FOLDS.defer(dev, ws):
             lib.call("adnm_lincomb_bwd", pg, ldg, xp[0][0], xp[0][1], xp[1][0], xp[1][1], xp[2][0], xp[2][1], sp[0], sp[1], sp[2], _p(gamma),
                      dxp[0][0], dxp[0][1], dxp[1][0], dxp[1][1], dxp[2][0], dxp[2][1], dsp[0], dsp[1], dsp[2], _p(dgamma), ws.data_ptr(), nb,
                      M, C, _dt(g), _stream())
@@ -868,7 +870,7 @@ class AdnPrepFn(torch.autograd.Function):
         dparams = [grad_dst(p.data_ptr(), p.shape, p.device, p.dtype) for p in params]
         nb = lib.query("adnm_adnprep_bwd_ws_bytes")
         ws = _ws(nb, params[0].device)
-        with FOLDS.defer(params[0].device, ws, *gouts, *dparams):
+        with FOLDS.defer(params[0].device, ws, *gouts):
             lib.call("adnm_adnprep_bwd", lib.ptr_table(params), lib.ptr_table(gouts), lib.ptr_table(dparams), dm, di, gn, P, ws.data_ptr(), nb,
                      _stream())
         return (None, None, None, None, *dparams)
@@ -981,7 +983,7 @@ def _skgemm(op, a, b, bias, c, dbias, M, N, K, defer=False):
                            "(every op needs N % 4 == 0 and K % 4 == 0)")
     nb = lib.query("adnm_skgemm_ws_bytes", op, M, N, K)
     ws = _ws(nb, a.device)
-    with FOLDS.defer(a.device, ws, c, dbias) if defer else _NODEFER:   # only the weight-gradient op (TN) may wait for its split-K fold
+    with FOLDS.defer(a.device, ws) if defer else _NODEFER:   # only the weight-gradient op (TN) may wait for its split-K fold
         lib.call("adnm_skgemm", op, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _p(bias), c.data_ptr(), c.stride(0), _p(dbias),
                  ws.data_ptr(), nb, M, N, K, _stream())
 
@@ -1037,17 +1039,18 @@ def colsum(t, out=None):
     return out
 
 
-def k_linear_dw(dy2, x2, want_bias, w_ptr=0, b_ptr=0):
-    """dW = dY^T X (N,K), dbias = column sums of dY.  w_ptr / b_ptr: data_ptr of the parameters (gradient-destination lookup)."""
+def k_linear_dw(dy2, x2, want_bias, w_ptr=0, b_ptr=0, dw_out=None):
+    """dW = dY^T X (N,K), dbias = column sums of dY.  w_ptr / b_ptr: data_ptr of the parameters (gradient-destination lookup);
+    dw_out: an explicit contiguous (N,K) destination instead."""
     M, N = dy2.shape
     K = x2.shape[1]
     dev = x2.device
-    dw = grad_dst(w_ptr, (N, K), dev)
+    dw = dw_out if dw_out is not None else grad_dst(w_ptr, (N, K), dev)
     db = grad_dst(b_ptr, (N,), dev) if want_bias else None
     if ts_ok_tn(M, N, K, x2):
         nb = lib.query("adnm_tsgemm_tn_ws_bytes", M, N, K)
         ws = _ws(nb, dev)
-        with FOLDS.defer(dev, ws, dw, db):
+        with FOLDS.defer(dev, ws):
             lib.call("adnm_tsgemm_tn", dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), dw.data_ptr(), _p(db), ws.data_ptr(), nb, M, N, K,
                      _stream())
         return dw, db
@@ -1089,6 +1092,12 @@ def linear(x, w, bias=None):
     _need_gpu(x)
     if x.dtype != torch.float32 or w.dim() != 2:
         raise RuntimeError(f"adnm_hip linear: needs fp32 tokens and a 2-D weight, got {x.dtype}, weight {tuple(w.shape)}")
+    N = w.shape[0]
+    if N % 4:   # the GEMM kernels move 16-byte vectors along N: run them on the weight padded with zero rows (a frame count like 6)
+        pad = 4 - N % 4
+        w = torch.nn.functional.pad(w, (0, 0, 0, pad))
+        bias = torch.nn.functional.pad(bias, (0, pad)) if bias is not None else None
+        return LinearFn.apply(x, w, bias)[..., :N]
     return LinearFn.apply(x, w, bias)
 
 
@@ -1151,7 +1160,7 @@ class Conv3Fn(torch.autograd.Function):
         db = grad_dst(b_ptr, (N,), dev) if has_bias else None
         nb = lib.query("adnm_conv3_wgrad_ws_bytes", B, H, W, K, N)
         wsb = _ws(nb, dev)
-        with FOLDS.defer(dev, wsb, g, db):
+        with FOLDS.defer(dev, wsb):
             lib.call("adnm_conv3_wgrad", dy2.data_ptr(), dy2.stride(0), _p(pre), N, act, x2.data_ptr(), x2.stride(0), g.data_ptr(), _p(db),
                      wsb.data_ptr(), nb, B, H, W, K, N, _stream())
         return dx, g, db, None, None, None
@@ -1159,6 +1168,62 @@ class Conv3Fn(torch.autograd.Function):
 
 def conv3(x, w, bias, H, W, act=lib.ACT_NONE):
     return Conv3Fn.apply(x, w, bias, H, W, act)
+
+
+# ------------------------------------------------------------------------------------------- stride-2 transposed conv (K9)
+class ConvT2xFn(torch.autograd.Function):
+    """nn.ConvTranspose2d(Cin, Cout, 3, stride=2, padding=1, output_padding=1) on tokens, (B, H*W, Cin) -> (B, 2H*2W, Cout)
+    (csrc/convt.hip): cols = X . Wf on the short-GEMM MFMA kernel with the weight read as the (Cin, 9*Cout) matrix it is in memory,
+    then the 4-phase gather; backward = the inverse gather + two more GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, H, W):
+        B, L, Cin = x.shape
+        Cout = w.shape[1]
+        _need_gpu(x)
+        if x.dtype != torch.float32 or tuple(w.shape) != (Cin, Cout, 3, 3) or L != H * W or Cout % 4 or Cin % 4:
+            _unsupported("convt2x", f"needs fp32 (B, H*W, Cin) tokens, a (Cin, Cout, 3, 3) weight and 4 | Cin, Cout; got {tuple(x.shape)}, {tuple(w.shape)}")
+        if w.stride() == (9 * Cout, 1, 3 * Cout, Cout):      # (Cin, 3, 3, Cout) memory order (the flat trainer's): columns (tap, co)
+            ct, cc = Cout, 1
+        else:                                                # nn.ConvTranspose2d's own order: columns (co, tap)
+            w = w.contiguous()
+            ct, cc = 1, 9
+        wf = torch.as_strided(w, (Cin, 9 * Cout), (9 * Cout, 1))
+        x2 = x.reshape(B * L, Cin)
+        x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
+        cols = k_linear_dx(x2, wf)                           # (M, Cin) . (Cin, 9 Cout)
+        out = torch.empty((B * 4 * L, Cout), dtype=torch.float32, device=x.device)
+        lib.call("adnm_convt_col2im", cols.data_ptr(), 9 * Cout, ct, cc, _p(bias), out.data_ptr(), Cout, B, H, W, Cout, _stream())
+        ctx.save_for_backward(x2, wf)
+        ctx.meta = (B, H, W, Cin, Cout, ct, cc, w.data_ptr(), bias.data_ptr() if bias is not None else 0, bias is not None)
+        return out.view(B, 4 * L, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wf = ctx.saved_tensors
+        B, H, W, Cin, Cout, ct, cc, w_ptr, b_ptr, has_bias = ctx.meta
+        dev = x2.device
+        M = B * H * W
+        dy2 = dy.reshape(4 * M, Cout)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        dcols = torch.empty((M, 9 * Cout), dtype=torch.float32, device=dev)
+        lib.call("adnm_convt_im2col", dy2.data_ptr(), Cout, dcols.data_ptr(), 9 * Cout, ct, cc, B, H, W, Cout, _stream())
+        dx = k_linear(dcols, wf, None).view(B, H * W, Cin) if ctx.needs_input_grad[0] else None
+        g = grad_dst(w_ptr, (Cin, Cout, 3, 3), dev)         # the trainer's slice has the weight's own memory order
+        if g.stride() != ((9 * Cout, 1, 3 * Cout, Cout) if cc == 1 else (9 * Cout, 9, 3, 1)):
+            g = torch.empty((Cin, 3, 3, Cout), dtype=torch.float32, device=dev).permute(0, 3, 1, 2) if cc == 1 else \
+                torch.empty((Cin, Cout, 3, 3), dtype=torch.float32, device=dev)
+        k_linear_dw(x2, dcols, False, dw_out=torch.as_strided(g, (Cin, 9 * Cout), (9 * Cout, 1)))   # dWf = X^T . dcols
+        db = None
+        if has_bias:
+            db = grad_dst(b_ptr, (Cout,), dev)
+            with FOLDS.defer(dev, dy2):
+                colsum(dy2, out=db)
+        return dx, g, db, None, None
+
+
+def convt2x(x, w, bias, H, W):
+    return ConvT2xFn.apply(x, w, bias, H, W)
 
 
 # ------------------------------------------------------------------------------------------- K1b chunked scan
@@ -1280,7 +1345,7 @@ class SkipGateFn(torch.autograd.Function):
         dp = torch.empty(int(lib.query("adnm_skipgate_grad_floats", c)), dtype=torch.float32, device=x.device)
         nb = lib.query("adnm_skipgate_bwd_ws_bytes", b, h, w, c)
         ws = _ws(nb, x.device)
-        with FOLDS.defer(x.device, ws, dp):   # every parameter of an EncoderToDecoder has this one node
+        with FOLDS.defer(x.device, ws):   # every parameter of an EncoderToDecoder has this one node
             lib.call("adnm_skipgate_bwd", dout.data_ptr(), x.data_ptr(), lib.ptr_table(params), pooled.data_ptr(), conv.data_ptr(), dx.data_ptr(),
                      dp.data_ptr(), ws.data_ptr(), nb, b, h, w, c, _stream())
         o = [0]

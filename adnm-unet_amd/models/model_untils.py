@@ -415,7 +415,12 @@ class UpSample(nn.Module):
     def forward(self, x):
         b, l, d = x.shape
         h, w = _hw(l)
-        return tokens_of(self.trans_conv(nchw_view(x, h, w)))
+        tc = self.trans_conv
+        c = tc.trans_conv
+        if (self.ratio != 2 or c.kernel_size != (3, 3) or c.padding != (1, 1) or c.output_padding != (1, 1) or c.groups != 1 or tc.norm or tc.act
+                or tc.dropout is not None):
+            raise RuntimeError(f"UpSample: the HIP transposed conv is k=3, s=2, p=1, output_padding=1 without norm/act, got {c}")
+        return ops.convt2x(x, c.weight, c.bias, h, w)
 
 
 class IntensityGate(nn.Module):

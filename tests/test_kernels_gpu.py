@@ -632,3 +632,24 @@ def test_conv3(B, H, W, K, N, act, bias, cl):
     assert_close(wg.grad, wo.grad, GRAD_TOL, "dw")
     if bias:
         assert_close(bg.grad, bo.grad, GRAD_TOL, "db")
+
+
+# ------------------------------------------------------------------------------------------- stride-2 transposed conv (K9)
+@pytest.mark.parametrize("B,H,W,C,cl", [(2, 4, 4, 64, True), (4, 8, 8, 256, True), (1, 16, 16, 32, False), (2, 6, 10, 16, True), (4, 64, 64, 32, True)])
+def test_convt2x(B, H, W, C, cl):
+    x, w, b, cot = T(f"ct.x{H}{C}", (B, H * W, C)), T(f"ct.w{C}", (C, C, 3, 3), 0.2), T(f"ct.b{C}", (C,)), T(f"ct.c{H}{C}", (B, 4 * H * W, C))
+    xo, wo, bo = leaf(x.double()), leaf(w.double()), leaf(b.double())
+    yo = F.conv_transpose2d(xo.view(B, H, W, C).permute(0, 3, 1, 2), wo, bo, stride=2, padding=1, output_padding=1)
+    yo = yo.permute(0, 2, 3, 1).reshape(B, 4 * H * W, C)
+    (yo * cot.double()).sum().backward()
+    xg, bg = leaf(x, DEV), leaf(b, DEV)
+    wg = w.to(DEV)
+    if cl:   # (Cin, 3, 3, Cout) memory order behind the logical (Cin, Cout, 3, 3) shape: the flat trainer's layout
+        wg = wg.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    wg = wg.detach().requires_grad_(True)
+    yg = ops.convt2x(xg, wg, bg, H, W)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, OUT_TOL, "y")
+    assert_close(xg.grad, xo.grad, GRAD_TOL, "dx")
+    assert_close(wg.grad, wo.grad, GRAD_TOL, "dw")
+    assert_close(bg.grad, bo.grad, GRAD_TOL, "db")
