@@ -64,6 +64,7 @@ class GradRegistry:
         self._lock = threading.Lock()
         self._dst = {}       # data_ptr -> (owner id, view into the owner's flat gradient buffer)
         self._claimed = {}   # owner id -> set of data_ptrs claimed in the running backward pass
+        self._multi = {}     # owner id -> data_ptrs claimed more than once (autograd summed several contributions)
 
     def register(self, owner, mapping):
         with self._lock:
@@ -71,6 +72,7 @@ class GradRegistry:
             for ptr, view in mapping.items():
                 self._dst[ptr] = (owner, view)
             self._claimed[owner] = set()
+            self._multi[owner] = set()
 
     def drop(self, owner, locked=False):
         if not locked:
@@ -79,11 +81,18 @@ class GradRegistry:
         for ptr in [k for k, (o, _) in self._dst.items() if o == owner]:
             del self._dst[ptr]
         self._claimed.pop(owner, None)
+        self._multi.pop(owner, None)
 
     def reset_claims(self, owner):
         with self._lock:
             if owner in self._claimed:
                 self._claimed[owner].clear()
+                self._multi[owner].clear()
+
+    def born_in_place(self, owner):
+        """data_ptrs of the parameters whose slice holds the complete gradient of the running step: claimed exactly once."""
+        with self._lock:
+            return set(self._claimed.get(owner, ())) - self._multi.get(owner, set())
 
     def take(self, ptr, shape, device, dtype=torch.float32):
         second = False
@@ -96,6 +105,8 @@ class GradRegistry:
                     # a fresh tensor object on the same memory: AccumulateGrad only keeps ("steals") a gradient nobody else references
                     return g.detach()
                 second = ptr in self._claimed[owner]
+                if second:
+                    self._multi[owner].add(ptr)
         if second:   # autograd is about to ADD this contribution to the first one: both must be complete when it does
             FOLDS.flush(device)
             FOLDS.hold(device)   # ... so the producer of this one must not defer its fold either

@@ -85,11 +85,14 @@ class FlatTrainer:
         self.state = torch.zeros(4, dtype=torch.float32, device=dev)
         self.g_views = []
 
+        # modules name the weights their NHWC kernels want in (out, kh, kw, in) memory order (dense 3x3 convs, transposed convs)
+        nhwc = {id(p) for m in self.model.modules() if hasattr(m, "adnm_nhwc_parameters") for p in m.adnm_nhwc_parameters()}
+
         def shaped(flat, o, p):
-            """view of the flat slice with p's logical shape.  Dense conv weights (Cout, Cin>1, kh, kw) get channels-last strides:
-            the NHWC conv kernels then read them (and write their gradients) as they lie."""
+            """view of the flat slice with p's logical shape.  The weights of the dense NHWC convs get channels-last strides: the
+            kernels then read them (and write their gradients) as they lie, with the reduction axis contiguous."""
             t = flat[o:o + p.numel()]
-            if p.dim() == 4 and p.shape[1] > 1 and p.is_cuda:
+            if id(p) in nhwc and p.dim() == 4 and p.is_cuda:
                 co, ci, kh, kw = p.shape
                 return t.view(co, kh, kw, ci).permute(0, 3, 1, 2)
             return t.view_as(p)
@@ -119,7 +122,10 @@ class FlatTrainer:
     def _gather(self, lo=0, hi=None):
         """Copy the gradients of used[lo:hi] that were not born inside the flat buffer (same data_ptr = already in place)."""
         hi = len(self.used) if hi is None else hi
-        pairs = [(gv, p.grad) for gv, p in zip(self.g_views[lo:hi], self.used[lo:hi]) if p.grad.data_ptr() != gv.data_ptr()]
+        # a slice that ONE backward node claimed holds that gradient itself (whatever tensor object autograd kept for p.grad)
+        born = ops.GRADS.born_in_place(id(self))
+        pairs = [(gv, p.grad) for gv, p in zip(self.g_views[lo:hi], self.used[lo:hi])
+                 if p.grad is not None and p.grad.data_ptr() != gv.data_ptr() and p.data_ptr() not in born]
         if pairs:
             torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
 

@@ -95,13 +95,16 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ in, int64_t
 }
 
 // ================================================================================================ forward / dgrad
+// LDS: [input tile (TH+2)(TW+2) x CKP] [weights of the chunk: 9 taps x NB*16 channels x CKP]
 template <int NB, int ACT_IN, int ACT_OUT>
 __global__ __launch_bounds__(kBlock) void conv3_kernel(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sIn[];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int TWp = a.TW + 2;
+  float* sIn = smem;
+  float* sW = smem + (a.TH + 2) * TWp * CKP;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, kk = lane >> 4;
   const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
   const int x0 = tx * a.TW, v0 = ty * a.TH, n0 = blockIdx.y * NB * 16;
-  const int TWp = a.TW + 2;
   const int dyj = j / a.TW, dxj = j - dyj * a.TW;
   int base[MB];
 #pragma unroll
@@ -117,30 +120,34 @@ __global__ __launch_bounds__(kBlock) void conv3_kernel(ConvArgs a) {
   for (int c = cbeg; c < cend; ++c) {
     __syncthreads();
     stage_tile<ACT_IN>(a.in, a.ldin, a.in2, a.ldin2, a.vec_in != 0, a.K, a.B, a.H, a.W, a.VR, a.TW, a.TH, sIn, v0, x0, c * CK);
+    // weights of this chunk: sW[(tap*NB*16 + nl)*CKP + kq*4 .. +3] = W(n0 + nl, tap, c*16 + 4 kq ..)
+    for (int it = threadIdx.x; it < 9 * NB * 16 * 4; it += kBlock) {
+      const int kq = it & 3, nl = (it >> 2) % (NB * 16), tap = it / (NB * 64);
+      const int n = n0 + nl, k0 = c * CK + 4 * kq;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (n < a.N && k0 < a.K) {
+        const float* wp = a.w + (int64_t)n * a.sn + (int64_t)(a.flip ? 8 - tap : tap) * a.st + (int64_t)k0 * a.sk;
+        if (a.vec_w && k0 + 3 < a.K) {
+          const float4 t = *reinterpret_cast<const float4*>(wp);
+          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k0 + e < a.K) v[e] = wp[(int64_t)e * a.sk];
+        }
+      }
+      *reinterpret_cast<float4*>(sW + (tap * NB * 16 + nl) * CKP + 4 * kq) = make_float4(v[0], v[1], v[2], v[3]);
+    }
     __syncthreads();
-    const int k0 = c * CK + 4 * kk;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int toff = ((tap / 3) * TWp + (tap % 3)) * CKP;
-      const int64_t wt = (int64_t)(a.flip ? 8 - tap : tap) * a.st;
-      float wa[NB][4];
+      float wa[NB][4], xb[MB][4];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const int n = n0 + nb * 16 + j;
-        wa[nb][0] = wa[nb][1] = wa[nb][2] = wa[nb][3] = 0.f;
-        if (n < a.N && k0 < a.K) {
-          const float* wp = a.w + (int64_t)n * a.sn + wt + (int64_t)k0 * a.sk;
-          if (a.vec_w && k0 + 3 < a.K) {
-            const float4 t = *reinterpret_cast<const float4*>(wp);
-            wa[nb][0] = t.x; wa[nb][1] = t.y; wa[nb][2] = t.z; wa[nb][3] = t.w;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (k0 + e < a.K) wa[nb][e] = wp[(int64_t)e * a.sk];
-          }
-        }
+        const float4 t = *reinterpret_cast<const float4*>(sW + (tap * NB * 16 + nb * 16 + j) * CKP + 4 * kk);
+        wa[nb][0] = t.x; wa[nb][1] = t.y; wa[nb][2] = t.z; wa[nb][3] = t.w;
       }
-      float xb[MB][4];
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const float4 t = *reinterpret_cast<const float4*>(sIn + base[mb] + toff);
@@ -211,7 +218,7 @@ struct WgArgs {
   const float* dout; int64_t lddo;    // (M, N)
   const float* pre;  int64_t ldpre;   // pre-activation of the forward output (ACT != NONE)
   const float* in;   int64_t ldin;    // (M, K)
-  float* part; int64_t rowlen;        // partial rows [gridDim.x * 4][N*9*K (+ N)]
+  float* part; int64_t rowlen;        // partial rows [gridDim.x][N*9*K (+ N)]
   int want_bias;
   int B, H, W, K, N, ntiles;
   int TW, RB, TH, VR, tiles_x;
@@ -286,19 +293,31 @@ __global__ __launch_bounds__(kBlock) void conv3_wgrad_kernel(WgArgs a) {
       for (int p = 0; p < MB * 16; ++p) bsum += sD[(wave * MB * 16 + p) * DP + lane];
     }
   }
-  // this wave's partial row: element (n, tap, k) at (n*9 + tap)*K + k ; D layout: row = channel kk*4 + reg, column = input channel j
-  float* dst = a.part + ((int64_t)blockIdx.x * kWaves + wave) * a.rowlen;
-  const int k = c0 + j;
+  // sum the 4 waves through LDS (fixed order), then ONE partial row per workgroup: element (n, tap, k) at (n*9 + tap)*K + k;
+  // D layout: row = channel kk*4 + reg, column = input channel j
+  __syncthreads();
+  float* red = smem;   // [kWaves][9*NB*4][64] floats (+ bias lanes) — fits: 4 * (72 + 1) * 64 * 4 B = 74.8 KB for NB = 2
+  constexpr int kPer = 9 * NB * 4;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + nb * 16 + kk * 4 + r;
-        if (n < a.N && k < a.K) dst[((int64_t)n * 9 + tap) * a.K + k] = acc[tap][nb][r];
-      }
-  if (a.want_bias && blockIdx.y == 0 && lane < NB * 16 && n0 + lane < a.N) dst[(int64_t)a.N * 9 * a.K + n0 + lane] = bsum;
+      for (int r = 0; r < 4; ++r) red[(wave * (kPer + 1) + (tap * NB + nb) * 4 + r) * 64 + lane] = acc[tap][nb][r];
+  red[(wave * (kPer + 1) + kPer) * 64 + lane] = bsum;
+  __syncthreads();
+  float* dst = a.part + (int64_t)blockIdx.x * a.rowlen;
+  for (int e = threadIdx.x; e < (kPer + 1) * 64; e += kBlock) {
+    const float v = (red[e] + red[(kPer + 1) * 64 + e]) + (red[2 * (kPer + 1) * 64 + e] + red[3 * (kPer + 1) * 64 + e]);
+    const int slot = e >> 6, ln = e & 63;
+    if (slot == kPer) {
+      if (a.want_bias && blockIdx.y == 0 && ln < NB * 16 && n0 + ln < a.N) dst[(int64_t)a.N * 9 * a.K + n0 + ln] = v;
+      continue;
+    }
+    const int r = slot & 3, nb = (slot >> 2) % NB, tap = slot / (4 * NB);
+    const int n = n0 + nb * 16 + (ln >> 4) * 4 + r, k = c0 + (ln & 15);
+    if (n < a.N && k < a.K) dst[((int64_t)n * 9 + tap) * a.K + k] = v;
+  }
 }
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -332,7 +351,7 @@ inline Split plan_split(const Geo& g, int64_t K, int64_t N) {
 
 template <int ACT_IN, int ACT_OUT>
 int launch_conv(const ConvArgs& a, const Geo& g, const Split& s, hipStream_t st, const char* prof, double bytes) {
-  const size_t smem = sizeof(float) * (size_t)(g.TH + 2) * (g.TW + 2) * CKP;
+  const size_t smem = sizeof(float) * ((size_t)(g.TH + 2) * (g.TW + 2) * CKP + (size_t)9 * s.nb * 16 * CKP);
   const dim3 grid((unsigned)(g.tiles_x * g.tiles_y), (unsigned)s.ngroups, (unsigned)s.nsplit);
   ADNM_PROF(prof, st, bytes);
   if (s.nb == 4) conv3_kernel<4, ACT_IN, ACT_OUT><<<grid, kBlock, smem, st>>>(a);
@@ -438,16 +457,16 @@ struct WgPlan {
 };
 inline WgPlan plan_wgrad(const Geo& g, int64_t K, int64_t N, bool bias) {
   WgPlan p;
-  p.nb = N > 32 ? 4 : (N > 16 ? 2 : 1);
+  p.nb = N > 16 ? 2 : 1;                                                   // 32 output channels per workgroup: 18 accumulator blocks per wave
   p.cogroups = (int)adnm_cdiv(N, p.nb * 16);
   p.cichunks = (int)adnm_cdiv(K, CK);
   p.rowlen = N * 9 * K + (bias ? N : 0);
   const int64_t ntiles = (int64_t)g.tiles_x * g.tiles_y;
-  int64_t r = adnm_cdiv(512, (int64_t)p.cichunks * p.cogroups);              // ~512 workgroups
-  const int64_t by_mem = (int64_t)(8 << 20) / (p.rowlen * 4 * kWaves);     // partials capped at ~8 MB
+  int64_t r = adnm_cdiv(768, (int64_t)p.cichunks * p.cogroups);              // ~768 workgroups (3 per CU)
+  const int64_t by_mem = (int64_t)(8 << 20) / (p.rowlen * 4);              // partials capped at ~8 MB
   if (r > by_mem) r = by_mem;
   if (r > ntiles) r = ntiles;
-  if (r > 64) r = 64;
+  if (r > 256) r = 256;
   p.rows = (int)(r < 1 ? 1 : r);
   return p;
 }
@@ -456,7 +475,7 @@ inline WgPlan plan_wgrad(const Geo& g, int64_t K, int64_t N, bool bias) {
 extern "C" int64_t adnm_conv3_wgrad_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t K, int64_t N) {
   if (B <= 0 || H <= 0 || W <= 0 || K <= 0 || N <= 0) return 0;
   const WgPlan p = plan_wgrad(make_geo(B, H, W), K, N, true);
-  return (int64_t)p.rows * kWaves * p.rowlen * (int64_t)sizeof(float);
+  return (int64_t)p.rows * p.rowlen * (int64_t)sizeof(float);
 }
 
 // dw[n][tap][k] (contiguous, = the channels-last weight layout) and dbias[n] (optional) of adnm_conv3_fwd.  OVERWRITES both.
@@ -470,8 +489,8 @@ extern "C" int adnm_conv3_wgrad(const float* dout, int64_t lddo, const float* pr
   ADNM_REQUIRE(N * 9 * K + N < (1ll << 31), "conv3_wgrad: weight too large");
   const Geo g = make_geo(B, H, W);
   const WgPlan p = plan_wgrad(g, K, N, dbias != nullptr);
-  if (!ws || ws_bytes < (int64_t)p.rows * kWaves * p.rowlen * 4) {
-    adnm_set_error("conv3_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)((int64_t)p.rows * kWaves * p.rowlen * 4));
+  if (!ws || ws_bytes < (int64_t)p.rows * p.rowlen * 4) {
+    adnm_set_error("conv3_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)((int64_t)p.rows * p.rowlen * 4));
     return ADNM_EWORKSPACE;
   }
   WgArgs a{};
@@ -482,7 +501,9 @@ extern "C" int adnm_conv3_wgrad(const float* dout, int64_t lddo, const float* pr
   a.vec_in = al16(in) && ldin % 4 == 0 && K % 4 == 0;
   a.vec_do = al16(dout) && lddo % 4 == 0 && N % 4 == 0 && (!pre || (al16(pre) && ldpre % 4 == 0));
   hipStream_t st = (hipStream_t)stream;
-  const size_t smem = sizeof(float) * ((size_t)(g.TH + 2) * (g.TW + 2) * CKP + (size_t)kTilePix * (p.nb * 16 + 16));
+  size_t smem = sizeof(float) * ((size_t)(g.TH + 2) * (g.TW + 2) * CKP + (size_t)kTilePix * (p.nb * 16 + 16));
+  const size_t red = sizeof(float) * (size_t)kWaves * (9 * p.nb * 4 + 1) * 64;   // the cross-wave sum reuses the same LDS
+  if (smem < red) smem = red;
   const dim3 grid((unsigned)p.rows, (unsigned)p.cichunks, (unsigned)p.cogroups);
   {
     ADNM_PROF("conv3_wgrad", st, 4.0 * ((double)B * H * W * (K + N * (act != ADNM_ACT_NONE ? 2 : 1)) + 9.0 * K * N));
@@ -496,13 +517,12 @@ extern "C" int adnm_conv3_wgrad(const float* dout, int64_t lddo, const float* pr
       conv3_wgrad_kernel<NBV, ADNM_ACT_NONE><<<grid, kBlock, smem, st>>>(a);                                      \
     }                                                                                                             \
   } while (0)
-    if (p.nb == 4) WG(4);
-    else if (p.nb == 2) WG(2);
+    if (p.nb == 2) WG(2);
     else WG(1);
 #undef WG
   }
   ADNM_CHECK_LAUNCH("conv3_wgrad");
-  adnm_launch_fold("conv3_wgrad_fold", (const float*)ws, p.rows * kWaves, (int)p.rowlen, {dw, (int)(N * 9 * K)}, {dbias, dbias ? (int)N : 0}, {nullptr, 0},
+  adnm_launch_fold("conv3_wgrad_fold", (const float*)ws, p.rows, (int)p.rowlen, {dw, (int)(N * 9 * K)}, {dbias, dbias ? (int)N : 0}, {nullptr, 0},
                    {nullptr, 0}, st);
   ADNM_CHECK_LAUNCH("conv3_wgrad_fold");
   return ADNM_OK;

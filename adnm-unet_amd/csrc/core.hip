@@ -1,6 +1,7 @@
 // Error reporting, ABI version and the opt-in per-kernel HIP-event profiler of libadnm_hip.
 #include "adnm_common.h"
 #include <atomic>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -157,10 +158,21 @@ struct FoldQueue {
 };
 thread_local FoldQueue* tls_foldq = nullptr;
 
+// measurement aid: ADNM_FOLD_BATCH=1 launches every queued fold on its own (and under its own profiler name)
+int fold_batch_limit() {
+  static const int lim = [] {
+    const char* e = getenv("ADNM_FOLD_BATCH");
+    const int v = e ? atoi(e) : kMaxFolds;
+    return v < 1 ? 1 : (v > kMaxFolds ? kMaxFolds : v);
+  }();
+  return lim;
+}
+
 void launch_folds(const FoldDesc* d, const char* const* names, int count, hipStream_t st) {
-  for (int i0 = 0; i0 < count; i0 += kMaxFolds) {
+  const int lim = fold_batch_limit();
+  for (int i0 = 0; i0 < count; i0 += lim) {
     MultiFold mf;
-    const int m = count - i0 < kMaxFolds ? count - i0 : kMaxFolds;
+    const int m = count - i0 < lim ? count - i0 : lim;
     mf.count = m;
     int blocks = 0;
     double bytes = 0;

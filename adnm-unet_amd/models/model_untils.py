@@ -155,6 +155,10 @@ class Conv2dLayer(nn.Module):
         return (c.groups == c.in_channels == c.out_channels and k[0] == k[1] and k[0] in (3, 5) and c.stride == (1, 1)
                 and c.dilation == (1, 1) and c.padding in ((k[0] // 2, k[0] // 2), 'same') and c.in_channels % 4 == 0)
 
+    def adnm_nhwc_parameters(self):
+        """adnm_hip.trainer.FlatTrainer keeps these in (out, kh, kw, in) memory order: the NHWC conv kernel's reduction axis contiguous."""
+        return [self.conv.weight] if self._is_dense3() else []
+
     def _is_dense3(self):
         c = self.conv
         return (c.kernel_size == (3, 3) and c.groups == 1 and c.stride == (1, 1) and c.dilation == (1, 1) and c.padding in ((1, 1), 'same')
@@ -272,6 +276,9 @@ class DeConv2dLayer(nn.Module):
         if norm:
             self.scale = nn.Parameter(torch.tensor(1.))
             self.shift = nn.Parameter(torch.tensor(0.))
+
+    def adnm_nhwc_parameters(self):
+        return [self.trans_conv.weight]
 
     def forward(self, x):
         if self.dropout is not None:
