@@ -350,6 +350,18 @@ int adnm_convt_col2im(const float* cols, int64_t ldc, int64_t col_tap_stride, in
 int adnm_convt_im2col(const float* dout, int64_t lddo, float* dcols, int64_t ldc, int64_t col_tap_stride, int64_t col_c_stride,
                       int64_t B, int64_t H, int64_t W, int64_t C, adnm_stream_t stream);
 
+/* ---------------------------------------------------------------- the data formats either side of the path
+ * adnm_radar_ingest: datasets/Shanghai.py:52-59,121 — uint8 frames (frames, H0, W0), value * mul (1/255), bilinear resize to (S, S)
+ *   (align_corners=False, no antialias = torchvision's tensor Resize) -> fp32 (frames, S, S).  src_u8 is a DEVICE pointer (the
+ *   caller moves the bytes, e.g. by an async copy from pinned host memory).
+ * adnm_eval_counts: datasets/Shanghai_metrics.py:49-152 — per frame [TP, FN, FP, TN] at each threshold on
+ *   uint16(clip(x,0,1) * value_scale) fields (truth = "obs", pred = "sim") and sum |d|, sum d^2 of the scaled clipped float fields.
+ *   thresholds_host: nthr <= 8 floats in HOST memory (they become kernel arguments).  out: (frames, 4*nthr + 2) fp32, OVERWRITTEN. */
+int adnm_radar_ingest(const void* src_u8, float* dst, int64_t frames, int64_t H0, int64_t W0, int64_t S, float mul, adnm_stream_t stream);
+int64_t adnm_eval_counts_ws_bytes(int64_t frames, int64_t hw, int64_t nthr);
+int adnm_eval_counts(const float* truth, const float* pred, float* out, const float* thresholds_host, int64_t nthr, float value_scale,
+                     void* ws, int64_t ws_bytes, int64_t frames, int64_t hw, adnm_stream_t stream);
+
 /* Wire format of the data-parallel gradient all-reduce that replaces nn.DataParallel's reduce_add_coalesced (train.py:99-102;
  * SURVEY.md §8e): dst[i] = (bf16)(scale * src[i]) before the collective, dst[i] = scale * (float)src[i] after it (scale = 1/world
  * folds the average in).  n elements, both buffers 16-byte aligned. */

@@ -177,6 +177,8 @@ def main():
     # round 2: BASELINE config 4 (10 -> 40 frames, 256x256): channels=10, out_channels=40 (ADNMUNet.py:906-940)
     whole_model_case("visionmamba_256_10to40_b1", 256, 1, radar="radar256x", cin=10, cout=40, deltas=True)
     convlstm_case()
+    evaluator_case()
+    resize_case()
 
 
 def whole_model_case(name, size, batch, radar, cin=5, cout=20, full_out=False, deltas=False):
@@ -231,6 +233,71 @@ def whole_model_case(name, size, batch, radar, cin=5, cout=20, full_out=False, d
         arrays["delta_small_sizes"] = np.array([t.numel() for t in small])
     save(name, **arrays)
     del model
+
+
+def evaluator_case():
+    """SimplifiedEvaluator (datasets/Shanghai_metrics.py:14-290) on a recipe batch: the contingency counts, MSE / MAE per frame and the
+    aggregated CSI / POD / HSS / FAR / RMSE of done().  lpips (a weight download) and cv2 (SSIM) are absent here: lpips.LPIPS is a stub
+    returning zeros and cv2's two functions are scipy stand-ins, so the SSIM / LPIPS entries are NOT recorded."""
+    name = "evaluator_b3_t5"
+    if not wanted(name):
+        return
+    import importlib.util
+    import types
+    import scipy.ndimage
+    H.load_reference()
+    lp = types.ModuleType("lpips")
+
+    class LPIPS(torch.nn.Module):
+        def __init__(self, **kw):
+            super().__init__()
+
+        def forward(self, a, b):
+            return torch.zeros(a.shape[0], 1, 1, 1)
+    lp.LPIPS = LPIPS
+    sys.modules["lpips"] = lp
+    cv2 = sys.modules["cv2"]
+
+    def gk(ksize, sigma):
+        x = np.arange(ksize) - (ksize - 1) / 2.0
+        k = np.exp(-(x ** 2) / (2 * sigma ** 2))
+        return (k / k.sum()).reshape(-1, 1)
+    cv2.getGaussianKernel = gk
+    cv2.filter2D = lambda img, ddepth, kern: scipy.ndimage.correlate(img, kern, mode="mirror")
+    # the reference's datasets/ has no __init__.py and an unrelated installed package owns that name: load the file itself
+    spec = importlib.util.spec_from_file_location("_adnm_ref_shanghai_metrics", os.path.join(H.REF_ROOT, "datasets", "Shanghai_metrics.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    B, T, S = 3, 5, 48
+    truth = recipe.tensor("eval.t", (B, T, S, S), 0.9, positive=True)
+    pred = (truth + 0.25 * recipe.tensor("eval.e", (B, T, S, S))).clamp(-0.1, 1.1)
+    ev = M.SimplifiedEvaluator(seq_len=T, value_scale=90, thresholds=[20, 30, 35, 40])
+    ev.evaluate(truth.numpy(), pred.numpy())
+    res = ev.done()
+    arrays = dict(truth=truth, pred=pred, value_scale=np.array(90.0), thresholds=np.array([20, 30, 35, 40]),
+                  mse=np.array(ev.losses["mse"]), mae=np.array(ev.losses["mae"]), FAR=np.array(res["FAR"]), RMSE=np.array(res["RMSE"]))
+    for thr in (20, 30, 35, 40):
+        for k in ("hits", "misses", "falsealarms", "correctnegs"):
+            arrays[f"{k}.{thr}"] = np.array(ev.metrics[thr][k])
+        for k in ("TP", "TN", "FP", "FN", "CSI", "POD", "HSS"):
+            arrays[f"{k}.{thr}"] = np.array(float(res["threshold_metrics"][thr][k]))
+    save(name, **arrays)
+
+
+def resize_case():
+    """datasets/Shanghai.py:52-59,121: uint8 (T, H0, W0) -> float / 255 -> transforms.Resize((S, S)).  torchvision is not installed here;
+    its tensor Resize (v0.16, antialias unset -> False) is torch.nn.functional.interpolate(mode='bilinear', align_corners=False), which
+    is what this fixture records — pinned to that torch call, not to torchvision itself."""
+    name = "radar_resize_565x784_to_128"
+    if not wanted(name):
+        return
+    rng = (recipe.uniform01("resize.u8", 3 * 57 * 79) * 71).astype(np.uint8).reshape(3, 57, 79)
+    small = torch.from_numpy(rng).float() / 255.0
+    out_small = torch.nn.functional.interpolate(small[None], size=(16, 16), mode="bilinear", align_corners=False)[0]
+    big = (recipe.uniform01("resize.big", 2 * 565 * 784) * 71).astype(np.uint8).reshape(2, 565, 784)
+    out_big = torch.nn.functional.interpolate(torch.from_numpy(big).float()[None] / 255.0, size=(128, 128), mode="bilinear", align_corners=False)[0]
+    idx = torch.from_numpy((recipe.uniform01("resize.idx", 2048) * out_big.numel()).astype(np.int64))
+    save(name, small_u8=rng, small_out=out_small, big_idx=idx, big_samples=out_big.flatten()[idx], big_sum=out_big.double().sum())
 
 
 def convlstm_case():
