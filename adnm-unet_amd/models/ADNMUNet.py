@@ -13,6 +13,7 @@ Differences that do not change results:
     receive a gradient.
 """
 import math
+import os
 from functools import partial
 
 import torch
@@ -366,7 +367,13 @@ def create_ADNMUNet(input_frames, output_frames, frame_interval, img_size=256, *
         InstanceNorm, kernel = True, [5, 5, 5]
     else:
         InstanceNorm, kernel = False, [5, 3, 3]
-    return VisionMamba(img_size=img_size, depth=[1, 1, 1], refine_depth=[1, 1, 1, 1], refine_headdim=[4, 4, 4, 4], refine_dim=refine_dim,
-                       embed_dim=[32, 64, 128, 256, 512, 1024], headdim=4, channels=input_frames, out_channels=output_frames,
-                       ssm_cfg=None, norm_epsilon=1e-6, initializer_cfg=None, kernel=kernel, ratio=[2, 2, 2, 2, 2, 2],
-                       wt_levels=[3, 2, 1], out_expand=2, InstanceNorm=InstanceNorm, **overrides)
+    model = VisionMamba(img_size=img_size, depth=[1, 1, 1], refine_depth=[1, 1, 1, 1], refine_headdim=[4, 4, 4, 4], refine_dim=refine_dim,
+                        embed_dim=[32, 64, 128, 256, 512, 1024], headdim=4, channels=input_frames, out_channels=output_frames,
+                        ssm_cfg=None, norm_epsilon=1e-6, initializer_cfg=None, kernel=kernel, ratio=[2, 2, 2, 2, 2, 2],
+                        wt_levels=[3, 2, 1], out_expand=2, InstanceNorm=InstanceNorm, **overrides)
+    # one process per GPU (WORLD_SIZE > 1): an unmodified train.py gets bucketed RCCL gradient averaging during backward
+    # (adnm_hip.ddp.attach) in place of its nn.DataParallel branch (train.py:99-102)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("ADNM_AUTO_DDP", "1") == "1":
+        from adnm_hip import ddp
+        ddp.attach(model)
+    return model

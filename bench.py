@@ -41,19 +41,23 @@ N_WINDOWS = 5
 
 # profiler scope (csrc/*.hip ADNM_PROF names) -> north-star kernel family
 FAMILIES = [
-    ("K1 ssd reduction fwd (reduce+apply)", ("ssd_reduce", "ssd_outer_reduce", "ssd_fold", "ssd_apply", "ssd_kv")),
-    ("K1 ssd reduction bwd", ("ssd_bwd", "ssd_bc_fold", "ssd_dkv")),
+    ("K1 ssd reduction fwd (kv + apply[+LayerNorm])", ("ssd_kv", "ssd_apply", "ssd_apply_ln")),
+    ("K1 ssd reduction bwd (dkv + bwd)", ("ssd_dkv", "ssd_bwd")),
     ("K4 depthwise 3x3 stencil", ("dwconv_k3",)),
     ("K3 depthwise 5x5 stencil (WTConv)", ("dwconv_k5",)),
-    ("K3/K4 depthwise weight gradient", ("dwconv_wgrad_k3", "dwconv_wgrad_k5", "dwconv_wgrad_fold")),
+    ("K3/K4 depthwise weight gradient", ("dwconv_wgrad_k3", "dwconv_wgrad_k5")),
     ("K3 Haar DWT/IDWT", ("haar_dwt", "haar_idwt", "wt_level_fwd", "wt_level_bwd")),
-    ("K2/K7 row norms", ("rownorm_fwd", "rownorm_bwd", "rownorm_bwd_fold")),
+    ("K2/K7 row norms", ("rownorm_fwd", "rownorm_bwd")),
     ("K8 instance norm", ("instnorm_stats", "instnorm_apply", "instnorm_bwd_stats", "instnorm_bwd_apply", "instnorm_bwd_scalar")),
-    ("K6 tall-skinny MFMA GEMM", ("tsgemm_nt", "tsgemm_tn", "tsgemm_tn_fold")),
-    ("K6b short MFMA GEMM", ("skgemm_nt", "skgemm_nn", "skgemm_tn", "skgemm_fold")),
-    ("K5/K9 dense 3x3 / transposed conv (MFMA)", ("conv3_fwd", "conv3_dgrad", "conv3_wgrad", "convt_fwd", "convt_dgrad", "convt_wgrad")),
-    ("scalar/gamma mixes + gates", ("lincomb_fwd", "lincomb_bwd", "lincomb_bwd_fold", "catmix_fwd", "catmix_bwd", "gate_fwd", "gate_bwd",
-                                    "igate_fwd", "igate_bwd")),
+    ("K6 tall-skinny MFMA GEMM", ("tsgemm_nt", "tsgemm_tn")),
+    ("K6b short MFMA GEMM", ("skgemm_nt", "skgemm_nn", "skgemm_tn")),
+    ("K5 dense 3x3 conv (MFMA implicit GEMM)", ("conv3_fwd", "conv3_dgrad", "conv3_wgrad", "conv3_join")),
+    ("K9 transposed conv gathers (its GEMMs are in K6b)", ("convt_col2im", "convt_im2col")),
+    ("second-stage folds (batched + critical-path)", ("fold_batch", "skgemm_fold", "ssd_fold", "ssd_bc_fold", "ssd_head_fold", "lincomb_bwd_fold",
+                                                      "igate_bwd_fold", "tokmean_fold", "rainloss_fold", "grad_sumsq_fold", "dwconv_wgrad_fold",
+                                                      "rownorm_bwd_fold", "tsgemm_tn_fold", "conv3_wgrad_fold", "catmix_bwd_fold", "colsum",
+                                                      "adn_prep_bwd_fold", "skip_vec_fold", "skip_scal_fold", "skip_wgrad_fold")),
+    ("scalar/gamma mixes + gates", ("lincomb_fwd", "lincomb_bwd", "catmix_fwd", "catmix_bwd", "gate_fwd", "gate_bwd", "igate_fwd", "igate_bwd")),
     ("K12 optimiser (sumsq + AdamW)", ("grad_sumsq", "adamw_update")),
 ]
 
@@ -233,6 +237,7 @@ def main():
     lib.load()
     torch.backends.cuda.preferred_blas_library("hipblas")   # whatever plain library GEMM is left: rocBLAS (hipBLASLt's long-reduction picks are 6x slower here)
 
+    os.environ["ADNM_AUTO_DDP"] = "0"   # FlatTrainer owns the gradient collective here (the factory's hook-driven DDP is for train.py)
     model = create_ADNMUNet(args.in_frames, args.out_frames, 6, img_size=args.size)
     recipe.fill_parameters(model)  # identical replicas on every rank, same parameters as the parity fixtures
     model = model.to(dev).train()

@@ -165,3 +165,103 @@ def test_flat_trainer_two_ranks_equals_global_batch():
         opt.zero_grad(set_to_none=True)
     for k, p in model.named_parameters():
         assert torch.allclose(a["final"][k], p, atol=2e-6, rtol=1e-5), k
+
+
+def _attach_worker(rank, world, port, q):
+    """The reference's train.py loop, unmodified (train.py:132-146): forward, loss, backward, clip_grad_norm_, optimizer.step,
+    zero_grad — on a model that only went through adnm_hip.ddp.attach (what create_ADNMUNet does when WORLD_SIZE > 1)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adnm-unet_amd"))
+    from adnm_hip import ddp
+    torch.manual_seed(7 + rank)          # different initial weights per rank: attach() must broadcast rank 0's
+    model = Toy()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.01 * rank)
+    ddp.attach(model)                    # no process group yet: created (gloo on CPU) on the first forward
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, eps=1e-9, weight_decay=1e-2)
+    torch.manual_seed(100 + rank)
+    xs = [torch.randn(5, 8) for _ in range(3)]
+    ts = [torch.randn(5, 4) for _ in range(3)]
+    for x, t in zip(xs, ts):
+        loss = (model(x) - t).pow(2).mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)
+        opt.step()
+        opt.zero_grad()
+    q.put((rank, _plain({"final": {k: p.detach().clone() for k, p in model.named_parameters()}, "xs": xs, "ts": ts,
+                         "dead_none": model.dead.weight.grad is None})))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unmodified_training_loop_with_attach():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_attach_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: _torchify(o) for r, o in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = res[0], res[1]
+    assert a["dead_none"] and b["dead_none"]
+    for k in a["final"]:
+        assert torch.equal(a["final"][k], b["final"][k]), f"replicas diverged at {k}"
+    # single process on the global batch, started from rank 0's weights (seed 7, no offset)
+    torch.manual_seed(7)
+    model = Toy()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, eps=1e-9, weight_decay=1e-2)
+    for i in range(3):
+        x = torch.cat([a["xs"][i], b["xs"][i]])
+        t = torch.cat([a["ts"][i], b["ts"][i]])
+        (model(x) - t).pow(2).mean().backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)
+        opt.step()
+        opt.zero_grad()
+    for k, p in model.named_parameters():
+        assert torch.allclose(a["final"][k], p, atol=2e-6, rtol=1e-5), k
+
+
+def _bf16_trainer_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adnm-unet_amd"))
+    from adnm_hip.trainer import FlatTrainer
+    model = Toy()
+    # the default for > 1 rank: overlap="auto" -> two-stage backward, late bucket reduced beside the early stage; bf16 wire format
+    tr = FlatTrainer(model, lambda o, t: (o - t).pow(2).mean(), lr=1e-2, eps=1e-9, weight_decay=1e-2, max_norm=0.5,
+                     use_graph=False, fused=False, reduce_dtype="bf16")
+    torch.manual_seed(100 + rank)
+    for _ in range(3):
+        tr.step(torch.randn(5, 8), torch.randn(5, 4))
+    assert tr.staged and len(tr.buckets) == 2
+    q.put((rank, _plain({"final": {k: p.detach().clone() for k, p in model.named_parameters()}, "g": tr.flat_g.clone()})))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_trainer_default_overlap_and_bf16_wire():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bf16_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: _torchify(o) for r, o in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k in res[0]["final"]:
+        assert torch.equal(res[0]["final"][k], res[1]["final"][k]), f"replicas diverged at {k}"
+    assert torch.equal(res[0]["g"], res[1]["g"])
