@@ -850,6 +850,10 @@ def lincomb(xs, scalars, gamma=None):
     """xs: 1-3 same-shape token tensors; scalars: matching list of 1-element parameters (or None = 1)."""
     C = xs[0].shape[-1]
     _need_gpu(xs[0])
+    if gamma is None and C % 4 and xs[0].numel() % 4 == 0 and all(x.shape == xs[0].shape and x.is_contiguous() for x in xs):
+        # a purely scalar mix is elementwise: run it on the flat arrays viewed as rows of 4 (PatchEmbed's 5-channel frames)
+        shp = xs[0].shape
+        return lincomb([x.view(-1, 4) for x in xs], scalars).view(shp)
     if C % 4 or C > 2048 or not 1 <= len(xs) <= 3 or any(s is not None and s.numel() != 1 for s in scalars):
         _unsupported("lincomb", f"needs 1-3 operands with 4 | C <= 2048 channels and 1-element scalars, got {len(xs)} operands, C={C}")
     return LinCombFn.apply(gamma, *xs, *scalars)
@@ -1110,6 +1114,66 @@ def linear(x, w, bias=None):
         bias = torch.nn.functional.pad(bias, (0, pad)) if bias is not None else None
         return LinearFn.apply(x, w, bias)[..., :N]
     return LinearFn.apply(x, w, bias)
+
+
+# ------------------------------------------------------------------------------------------- stand-alone activations
+class ActFn(torch.autograd.Function):
+    """GELU (exact) / SiLU over fp32 tokens (csrc/activation.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        _need_gpu(x)
+        if x.dtype != torch.float32 or x.numel() % 4:
+            _unsupported("act", f"needs fp32 tokens with a multiple of 4 elements, got {x.dtype} x {x.numel()}")
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        lib.call("adnm_act_fwd", xc.data_ptr(), y.data_ptr(), xc.numel(), act, _stream())
+        ctx.save_for_backward(xc)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(xc)
+        lib.call("adnm_act_bwd", dy.data_ptr(), xc.data_ptr(), dx.data_ptr(), xc.numel(), ctx.act, _stream())
+        return dx, None
+
+
+def act(x, code):
+    return ActFn.apply(x, code)
+
+
+class SwishFn(torch.autograd.Function):
+    """x * sigmoid(beta * x) with a learnable 1-element beta (model_untils.py:162-169)."""
+
+    @staticmethod
+    def forward(ctx, x, beta):
+        _need_gpu(x)
+        if x.dtype != torch.float32 or x.numel() % 4 or beta.numel() != 1:
+            _unsupported("swish", f"needs fp32 tokens with a multiple of 4 elements and a 1-element beta, got {x.dtype} x {x.numel()}")
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        lib.call("adnm_swish_fwd", xc.data_ptr(), beta.data_ptr(), y.data_ptr(), xc.numel(), _stream())
+        ctx.save_for_backward(xc, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, beta = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(xc)
+        dbeta = grad_dst(beta.data_ptr(), beta.shape, xc.device)
+        nb = lib.query("adnm_swish_bwd_ws_bytes", xc.numel())
+        ws = _ws(nb, xc.device)
+        with FOLDS.defer(xc.device, ws):
+            lib.call("adnm_swish_bwd", dy.data_ptr(), xc.data_ptr(), beta.data_ptr(), dx.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), nb, xc.numel(), _stream())
+        return dx, dbeta
+
+
+def swish(x, beta):
+    return SwishFn.apply(x, beta)
 
 
 # ------------------------------------------------------------------------------------------- dense 3x3 conv (K5)

@@ -112,7 +112,9 @@ class Mlp(nn.Module):
         self.act2 = act_func()
 
     def forward(self, x):
-        h = self.drop(self.act1(ops.linear(x, self.fc1.weight, self.fc1.bias)))
+        h = ops.linear(x, self.fc1.weight, self.fc1.bias)
+        code = _act_code(self.act1)
+        h = self.drop(ops.act(h, code) if code in (lib.ACT_GELU, lib.ACT_SILU) else self.act1(h))
         return self.drop(ops.linear(h, self.fc2.weight, self.fc2.bias))
 
 
@@ -122,7 +124,7 @@ class Swish(nn.Module):
         self.beta = nn.Parameter(torch.tensor(beta_init, dtype=torch.float))
 
     def forward(self, x):
-        return x * torch.sigmoid(self.beta * x)
+        return ops.swish(x, self.beta)   # one HIP pass each way (d beta through partials + the fold)
 
 
 def _act_code(act):
@@ -358,7 +360,7 @@ class PatchEmbed(nn.Module):
         b, l, d = x.shape
         h, w = _hw(l)
         res = x[..., -1].reshape(b, h, w)
-        x = self.alpha1 * self.conv1[0].forward_tokens(x, h, w) + self.beta1 * x
+        x = ops.lincomb([self.conv1[0].forward_tokens(x, h, w).contiguous(), x.contiguous()], [self.alpha1, self.beta1])
         shortcut = self.conv2[0].forward_tokens(x, h, w)
         x = ops.lincomb([self.conv3[0].forward_tokens(shortcut, h, w), shortcut], [self.alpha2, self.beta2], self.gamma)
         return x, res
@@ -594,7 +596,7 @@ class OutProj(nn.Module):
         x = ops.lincomb([self.wtconv.forward_tokens(x, h, w), x], [self.alpha, self.beta], self.gamma)
         x = self.conv[0].forward_tokens(x, h, w)
         x = self.conv[1].forward_tokens(x, h, w)
-        if residual is not None:
-            x = self.alpha1 * x + self.alpha2 * residual.reshape(b, l, 1)
+        if residual is not None:   # the last input frame, broadcast over the T_out channels (model_untils.py:886-888)
+            x = ops.lincomb([x, residual.reshape(b, l, 1).expand(b, l, x.shape[-1]).contiguous()], [self.alpha1, self.alpha2])
         x = self.conv2.forward_tokens(x, h, w)
         return nchw_view(x, h, w)

@@ -362,6 +362,18 @@ int64_t adnm_eval_counts_ws_bytes(int64_t frames, int64_t hw, int64_t nthr);
 int adnm_eval_counts(const float* truth, const float* pred, float* out, const float* thresholds_host, int64_t nthr, float value_scale,
                      void* ws, int64_t ws_bytes, int64_t frames, int64_t hw, adnm_stream_t stream);
 
+/* ---------------------------------------------------------------- stand-alone activations
+ * act_fwd / act_bwd: y = act(x), dpre = dy * act'(pre) over flat fp32 arrays (n % 4 == 0), act in {ADNM_ACT_SILU, ADNM_ACT_GELU}: nn.GELU
+ *   between Mlp.fc1 and fc2 (model_untils.py:52-70) and the backward of the GELUs fused into GEMM / conv epilogues.
+ * swish_fwd / bwd: Swish with a learnable slope, y = x * sigmoid(beta * x) (model_untils.py:162-169), beta a 1-element device tensor;
+ *   bwd OVERWRITES dx and dbeta (1 element). */
+int adnm_act_fwd(const float* x, float* y, int64_t n, int act, adnm_stream_t stream);
+int adnm_act_bwd(const float* dy, const float* pre, float* dpre, int64_t n, int act, adnm_stream_t stream);
+int adnm_swish_fwd(const float* x, const float* beta, float* y, int64_t n, adnm_stream_t stream);
+int64_t adnm_swish_bwd_ws_bytes(int64_t n);
+int adnm_swish_bwd(const float* dy, const float* x, const float* beta, float* dx, float* dbeta, void* ws, int64_t ws_bytes, int64_t n,
+                   adnm_stream_t stream);
+
 /* Wire format of the data-parallel gradient all-reduce that replaces nn.DataParallel's reduce_add_coalesced (train.py:99-102;
  * SURVEY.md §8e): dst[i] = (bf16)(scale * src[i]) before the collective, dst[i] = scale * (float)src[i] after it (scale = 1/world
  * folds the average in).  n elements, both buffers 16-byte aligned. */

@@ -653,3 +653,44 @@ def test_convt2x(B, H, W, C, cl):
     assert_close(xg.grad, xo.grad, GRAD_TOL, "dx")
     assert_close(wg.grad, wo.grad, GRAD_TOL, "dw")
     assert_close(bg.grad, bo.grad, GRAD_TOL, "db")
+
+
+# ------------------------------------------------------------------------------------------- stand-alone activations
+@pytest.mark.parametrize("code,fn", [(lib.ACT_GELU, F.gelu), (lib.ACT_SILU, F.silu)])
+def test_act(code, fn):
+    x, cot = T("act.x", (3, 1000, 8), 3.0), T("act.c", (3, 1000, 8))
+    xo = leaf(x.double())
+    yo = fn(xo)
+    (yo * cot.double()).sum().backward()
+    xg = leaf(x, DEV)
+    yg = ops.act(xg, code)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, 1e-6, "y")
+    assert_close(xg.grad, xo.grad, 1e-5, "dx")
+
+
+def test_swish_learnable_beta():
+    x, cot = T("sw.x", (2, 4096, 20), 3.0), T("sw.c", (2, 4096, 20))
+    xo, bo = leaf(x.double()), leaf(torch.tensor(1.3).double())
+    yo = xo * torch.sigmoid(bo * xo)
+    (yo * cot.double()).sum().backward()
+    xg, bg = leaf(x, DEV), leaf(torch.tensor(1.3), DEV)
+    yg = ops.swish(xg, bg)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, 1e-6, "y")
+    assert_close(xg.grad, xo.grad, 1e-5, "dx")
+    assert abs(float(bg.grad) - float(bo.grad)) <= 1e-4 * abs(float(bo.grad))
+
+
+def test_lincomb_scalar_mix_any_channel_count():
+    """PatchEmbed's alpha1 * conv(x) + beta1 * x on 5-channel frames (model_untils.py:306): elementwise, so it runs on the flat arrays."""
+    a, b, cot = T("lc5.a", (2, 64, 5)), T("lc5.b", (2, 64, 5)), T("lc5.c", (2, 64, 5))
+    s1, s2 = torch.tensor(0.7), torch.tensor(-1.2)
+    o = [leaf(t.double()) for t in (a, b, s1, s2)]
+    ((o[2] * o[0] + o[3] * o[1]) * cot.double()).sum().backward()
+    g = [leaf(t, DEV) for t in (a, b, s1, s2)]
+    y = ops.lincomb([g[0], g[1]], [g[2], g[3]])
+    (y * cot.to(DEV)).sum().backward()
+    assert_close(y, o[2] * o[0] + o[3] * o[1], 1e-6, "y")
+    for name, u, v in zip(("da", "db", "ds1", "ds2"), g, o):
+        assert_close(u.grad, v.grad, 1e-4, name)
