@@ -13,6 +13,20 @@ from . import lib
 
 _DT = {torch.float32: lib.F32, torch.bfloat16: lib.BF16}
 
+# Matrix-core precision of the GEMM-shaped kernels (short GEMMs, dense 3x3 convs; include/adnm_hip.h ADNM_MFMA_*): "f32" = exact fp32
+# MFMA (the parity path), "bf16" = operands rounded to bf16 into the bf16 MFMA with fp32 accumulation (BASELINE's bf16 configs).
+# A process-wide setting like torch's autocast state; kernels take it as an explicit argument.
+MFMA_PREC = [0]
+
+
+def set_mfma_precision(name):
+    MFMA_PREC[0] = {"f32": 0, "fp32": 0, "bf16": 1}[name]
+
+
+def mfma_precision():
+    return "bf16" if MFMA_PREC[0] else "f32"
+
+
 
 def _dt(t):
     try:
@@ -1000,7 +1014,7 @@ def _skgemm(op, a, b, bias, c, dbias, M, N, K, defer=False):
     ws = _ws(nb, a.device)
     with FOLDS.defer(a.device, ws) if defer else _NODEFER:   # only the weight-gradient op (TN) may wait for its split-K fold
         lib.call("adnm_skgemm", op, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _p(bias), c.data_ptr(), c.stride(0), _p(dbias),
-                 ws.data_ptr(), nb, M, N, K, _stream())
+                 ws.data_ptr(), nb, M, N, K, MFMA_PREC[0], _stream())
 
 
 def _out_view_ok(out):
@@ -1208,7 +1222,7 @@ class Conv3Fn(torch.autograd.Function):
         nb = lib.query("adnm_conv3_ws_bytes", B, H, W, K, N)
         wsb = _ws(nb, dev)
         lib.call("adnm_conv3_fwd", x2.data_ptr(), x2.stride(0), w.data_ptr(), ws_[0], ws_[1], ws_[2], _p(bias), y.data_ptr(), N, _p(pre), N,
-                 wsb.data_ptr(), nb, B, H, W, K, N, act, _stream())
+                 wsb.data_ptr(), nb, B, H, W, K, N, act, MFMA_PREC[0], _stream())
         ctx.save_for_backward(x2, w, pre)
         ctx.meta = (B, H, W, K, N, act, ws_, bias.data_ptr() if bias is not None else 0, bias is not None)
         return y.view(B, L, N)
@@ -1226,7 +1240,7 @@ class Conv3Fn(torch.autograd.Function):
             nb = lib.query("adnm_conv3_ws_bytes", B, H, W, N, K)
             wsb = _ws(nb, dev)
             lib.call("adnm_conv3_dgrad", dy2.data_ptr(), dy2.stride(0), _p(pre), N, act, w.data_ptr(), ws_[0], ws_[1], ws_[2], dx.data_ptr(), K,
-                     wsb.data_ptr(), nb, B, H, W, K, N, _stream())
+                     wsb.data_ptr(), nb, B, H, W, K, N, MFMA_PREC[0], _stream())
             dx = dx.view(B, H * W, K)
         # the weight gradient is produced in (Cout, 3, 3, Cin) memory order: the flat trainer's channels-last slice takes it as it lies
         g = grad_dst(w.data_ptr(), (N, K, 3, 3), dev)
@@ -1237,7 +1251,7 @@ class Conv3Fn(torch.autograd.Function):
         wsb = _ws(nb, dev)
         with FOLDS.defer(dev, wsb):
             lib.call("adnm_conv3_wgrad", dy2.data_ptr(), dy2.stride(0), _p(pre), N, act, x2.data_ptr(), x2.stride(0), g.data_ptr(), _p(db),
-                     wsb.data_ptr(), nb, B, H, W, K, N, _stream())
+                     wsb.data_ptr(), nb, B, H, W, K, N, MFMA_PREC[0], _stream())
         return dx, g, db, None, None, None
 
 

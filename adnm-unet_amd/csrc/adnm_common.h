@@ -112,6 +112,27 @@ struct Io<uint16_t> {  // bf16 storage
   static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
+// ---- MFMA precision of the GEMM-shaped kernels (tsgemm, skgemm, conv3): ADNM_MFMA_F32 = v_mfma_f32_16x16x4_f32 (exact fp32, an fmaf
+// chain); ADNM_MFMA_BF16 = operands rounded to bf16 (RNE) on the way into v_mfma_f32_16x16x16_bf16, fp32 accumulation — the arithmetic
+// of BASELINE's bf16 configs at 8x the matrix rate.  Lane (i, kq) of a 16x16x16 bf16 operand holds k = 4*kq .. 4*kq+3: exactly the
+// four consecutive reduction steps one float4 fragment load provides, so both precisions share every loader.
+using adnm_f32x4 = __attribute__((ext_vector_type(4))) float;
+using adnm_bf16x4 = __attribute__((ext_vector_type(4))) short;
+__device__ __forceinline__ adnm_bf16x4 adnm_pack_bf16(float a, float b, float c, float d) {
+  using bf4 = __attribute__((ext_vector_type(4))) __bf16;
+  const adnm_f32x4 v = {a, b, c, d};
+  const bf4 h = __builtin_convertvector(v, bf4);   // two v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(adnm_bf16x4, h);
+}
+// acc += A(16 x 16 k-steps) . B for one 16x16 block: a[e], b[e] = the operands of reduction step 4*kq + e of this lane
+template <bool BF16>
+__device__ __forceinline__ adnm_f32x4 adnm_mfma16(const float (&a)[4], const float (&b)[4], adnm_f32x4 acc) {
+  if (BF16) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(adnm_pack_bf16(a[0], a[1], a[2], a[3]), adnm_pack_bf16(b[0], b[1], b[2], b[3]), acc, 0, 0, 0);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+  return acc;
+}
+
 // ---- math ----------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }

@@ -23,7 +23,7 @@
 
 namespace {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x4 = adnm_f32x4;
 constexpr int kBlock = 256, kWaves = 4;
 constexpr int CK = 16, CKP = CK + 4;   // channels per staged chunk, LDS pitch of a pixel
 constexpr int MB = 2;                  // pixel blocks per wave
@@ -96,7 +96,7 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ in, int64_t
 
 // ================================================================================================ forward / dgrad
 // LDS: [input tile (TH+2)(TW+2) x CKP] [weights of the chunk: 9 taps x NB*16 channels x CKP]
-template <int NB, int ACT_IN, int ACT_OUT>
+template <int NB, int ACT_IN, int ACT_OUT, bool BF16>
 __global__ __launch_bounds__(kBlock) void conv3_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int TWp = a.TW + 2;
@@ -154,11 +154,9 @@ __global__ __launch_bounds__(kBlock) void conv3_kernel(ConvArgs a) {
         xb[mb][0] = t.x; xb[mb][1] = t.y; xb[mb][2] = t.z; xb[mb][3] = t.w;
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb][e], xb[mb][e], acc[nb][mb], 0, 0, 0);
+        for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = adnm_mfma16<BF16>(wa[nb], xb[mb], acc[nb][mb]);
     }
   }
   // epilogue.  D layout: row = channel (kk*4 + reg) of the block, column = pixel j
@@ -225,7 +223,7 @@ struct WgArgs {
   int vec_in, vec_do;
 };
 
-template <int NB, int ACT>
+template <int NB, int ACT, bool BF16>
 __global__ __launch_bounds__(kBlock) void conv3_wgrad_kernel(WgArgs a) {
   constexpr int DP = NB * 16 + 16;   // pitch of a dpre pixel row: (DP mod 32) == 16 -> conflict-free A-operand reads
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -273,19 +271,22 @@ __global__ __launch_bounds__(kBlock) void conv3_wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int pbw = 0; pbw < MB; ++pbw) {
       const int pb = wave * MB + pbw;
+      // reduction = the 16 pixels of the block: lane (., kk) takes pixels 4 kk .. 4 kk + 3 (step e)
+      float av[NB][4];
+      const float* bp[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int jj = 4 * s + kk, pxl = pb * 16 + jj, dy_ = jj / a.TW, dx_ = jj - dy_ * a.TW;
-        float av[NB];
+      for (int e = 0; e < 4; ++e) {
+        const int jj = 4 * kk + e, pxl = pb * 16 + jj, dy_ = jj / a.TW, dx_ = jj - dy_ * a.TW;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) av[nb] = sD[pxl * DP + nb * 16 + j];   // A[i = channel][k = pixel]
-        const float* bp = sIn + ((pb * a.RB + dy_) * TWp + dx_) * CKP + j;      // B[k = pixel][j = input channel], tap (0,0)
+        for (int nb = 0; nb < NB; ++nb) av[nb][e] = sD[pxl * DP + nb * 16 + j];   // A[i = channel][k = pixel]
+        bp[e] = sIn + ((pb * a.RB + dy_) * TWp + dx_) * CKP + j;                   // B[k = pixel][j = input channel], tap (0,0)
+      }
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const float bv = bp[((tap / 3) * TWp + (tap % 3)) * CKP];
+      for (int tap = 0; tap < 9; ++tap) {
+        const int toff = ((tap / 3) * TWp + (tap % 3)) * CKP;
+        const float bv[4] = {bp[0][toff], bp[1][toff], bp[2][toff], bp[3][toff]};
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) acc[tap][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nb], bv, acc[tap][nb], 0, 0, 0);
-        }
+        for (int nb = 0; nb < NB; ++nb) acc[tap][nb] = adnm_mfma16<BF16>(av[nb], bv, acc[tap][nb]);
       }
     }
     if (a.want_bias && blockIdx.y == 0 && lane < NB * 16) {
@@ -350,13 +351,19 @@ inline Split plan_split(const Geo& g, int64_t K, int64_t N) {
 }
 
 template <int ACT_IN, int ACT_OUT>
-int launch_conv(const ConvArgs& a, const Geo& g, const Split& s, hipStream_t st, const char* prof, double bytes) {
+int launch_conv(const ConvArgs& a, const Geo& g, const Split& s, int prec, hipStream_t st, const char* prof, double bytes) {
   const size_t smem = sizeof(float) * ((size_t)(g.TH + 2) * (g.TW + 2) * CKP + (size_t)9 * s.nb * 16 * CKP);
   const dim3 grid((unsigned)(g.tiles_x * g.tiles_y), (unsigned)s.ngroups, (unsigned)s.nsplit);
   ADNM_PROF(prof, st, bytes);
-  if (s.nb == 4) conv3_kernel<4, ACT_IN, ACT_OUT><<<grid, kBlock, smem, st>>>(a);
-  else if (s.nb == 2) conv3_kernel<2, ACT_IN, ACT_OUT><<<grid, kBlock, smem, st>>>(a);
-  else conv3_kernel<1, ACT_IN, ACT_OUT><<<grid, kBlock, smem, st>>>(a);
+  if (prec == ADNM_MFMA_BF16) {
+    if (s.nb == 4) conv3_kernel<4, ACT_IN, ACT_OUT, true><<<grid, kBlock, smem, st>>>(a);
+    else if (s.nb == 2) conv3_kernel<2, ACT_IN, ACT_OUT, true><<<grid, kBlock, smem, st>>>(a);
+    else conv3_kernel<1, ACT_IN, ACT_OUT, true><<<grid, kBlock, smem, st>>>(a);
+  } else {
+    if (s.nb == 4) conv3_kernel<4, ACT_IN, ACT_OUT, false><<<grid, kBlock, smem, st>>>(a);
+    else if (s.nb == 2) conv3_kernel<2, ACT_IN, ACT_OUT, false><<<grid, kBlock, smem, st>>>(a);
+    else conv3_kernel<1, ACT_IN, ACT_OUT, false><<<grid, kBlock, smem, st>>>(a);
+  }
   return ADNM_OK;
 }
 
@@ -376,7 +383,7 @@ extern "C" int64_t adnm_conv3_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t 
 // and the channels-last one (Cout,3,3,Cin) (ws_n=9K, ws_tap=K, ws_k=1) are read in place.
 extern "C" int adnm_conv3_fwd(const float* in, int64_t ldin, const float* w, int64_t ws_n, int64_t ws_tap, int64_t ws_k, const float* bias,
                               float* out, int64_t ldo, float* pre, int64_t ldpre, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W,
-                              int64_t K, int64_t N, int act, adnm_stream_t stream) {
+                              int64_t K, int64_t N, int act, int prec, adnm_stream_t stream) {
   if (int rc = check_shape("conv3_fwd", B, H, W, K, N)) return rc;
   ADNM_REQUIRE(in && w && out, "conv3_fwd: null pointer");
   ADNM_REQUIRE(ldin >= K && ldo >= N && (!pre || ldpre >= N), "conv3_fwd: row strides smaller than the rows");
@@ -398,8 +405,8 @@ extern "C" int adnm_conv3_fwd(const float* in, int64_t ldin, const float* w, int
   a.vec_out = al16(out) && ldo % 4 == 0 && N % 4 == 0 && (!pre || (al16(pre) && ldpre % 4 == 0));
   hipStream_t st = (hipStream_t)stream;
   const double bytes = 4.0 * ((double)B * H * W * (K + N * (pre ? 2 : 1)) + 9.0 * K * N);
-  if (act == ADNM_ACT_GELU && s.nsplit == 1) launch_conv<ADNM_ACT_NONE, ADNM_ACT_GELU>(a, g, s, st, "conv3_fwd", bytes);
-  else launch_conv<ADNM_ACT_NONE, ADNM_ACT_NONE>(a, g, s, st, "conv3_fwd", bytes);
+  if (act == ADNM_ACT_GELU && s.nsplit == 1) launch_conv<ADNM_ACT_NONE, ADNM_ACT_GELU>(a, g, s, prec, st, "conv3_fwd", bytes);
+  else launch_conv<ADNM_ACT_NONE, ADNM_ACT_NONE>(a, g, s, prec, st, "conv3_fwd", bytes);
   ADNM_CHECK_LAUNCH("conv3_fwd");
   if (s.nsplit > 1) {
     const int64_t M = B * H * W, nthreads = M * (N / 4);
@@ -416,7 +423,7 @@ extern "C" int adnm_conv3_fwd(const float* in, int64_t ldin, const float* w, int
 // din = conv3x3^T(dout * act'(pre), w): the input gradient of adnm_conv3_fwd (K = Cin, N = Cout of the forward conv, same w strides).
 extern "C" int adnm_conv3_dgrad(const float* dout, int64_t lddo, const float* pre, int64_t ldpre, int act, const float* w, int64_t ws_n,
                                 int64_t ws_tap, int64_t ws_k, float* din, int64_t lddin, void* ws, int64_t ws_bytes, int64_t B, int64_t H,
-                                int64_t W, int64_t K, int64_t N, adnm_stream_t stream) {
+                                int64_t W, int64_t K, int64_t N, int prec, adnm_stream_t stream) {
   if (int rc = check_shape("conv3_dgrad", B, H, W, K, N)) return rc;
   ADNM_REQUIRE(dout && w && din, "conv3_dgrad: null pointer");
   ADNM_REQUIRE(act == ADNM_ACT_NONE || (act == ADNM_ACT_GELU && pre), "conv3_dgrad: activation %d needs the saved pre-activation", act);
@@ -438,8 +445,8 @@ extern "C" int adnm_conv3_dgrad(const float* dout, int64_t lddo, const float* pr
   a.vec_out = al16(din) && lddin % 4 == 0 && K % 4 == 0;
   hipStream_t st = (hipStream_t)stream;
   const double bytes = 4.0 * ((double)B * H * W * (K + N * (act != ADNM_ACT_NONE ? 2 : 1)) + 9.0 * K * N);
-  if (act == ADNM_ACT_GELU) launch_conv<ADNM_ACT_GELU, ADNM_ACT_NONE>(a, g, s, st, "conv3_dgrad", bytes);
-  else launch_conv<ADNM_ACT_NONE, ADNM_ACT_NONE>(a, g, s, st, "conv3_dgrad", bytes);
+  if (act == ADNM_ACT_GELU) launch_conv<ADNM_ACT_GELU, ADNM_ACT_NONE>(a, g, s, prec, st, "conv3_dgrad", bytes);
+  else launch_conv<ADNM_ACT_NONE, ADNM_ACT_NONE>(a, g, s, prec, st, "conv3_dgrad", bytes);
   ADNM_CHECK_LAUNCH("conv3_dgrad");
   if (s.nsplit > 1) {
     const int64_t M = B * H * W, nthreads = M * (K / 4);
@@ -481,7 +488,7 @@ extern "C" int64_t adnm_conv3_wgrad_ws_bytes(int64_t B, int64_t H, int64_t W, in
 // dw[n][tap][k] (contiguous, = the channels-last weight layout) and dbias[n] (optional) of adnm_conv3_fwd.  OVERWRITES both.
 extern "C" int adnm_conv3_wgrad(const float* dout, int64_t lddo, const float* pre, int64_t ldpre, int act, const float* in, int64_t ldin,
                                 float* dw, float* dbias, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W, int64_t K, int64_t N,
-                                adnm_stream_t stream) {
+                                int prec, adnm_stream_t stream) {
   if (int rc = check_shape("conv3_wgrad", B, H, W, K, N)) return rc;
   ADNM_REQUIRE(dout && in && dw, "conv3_wgrad: null pointer");
   ADNM_REQUIRE(act == ADNM_ACT_NONE || (act == ADNM_ACT_GELU && pre), "conv3_wgrad: activation %d needs the saved pre-activation", act);
@@ -507,19 +514,20 @@ extern "C" int adnm_conv3_wgrad(const float* dout, int64_t lddo, const float* pr
   const dim3 grid((unsigned)p.rows, (unsigned)p.cichunks, (unsigned)p.cogroups);
   {
     ADNM_PROF("conv3_wgrad", st, 4.0 * ((double)B * H * W * (K + N * (act != ADNM_ACT_NONE ? 2 : 1)) + 9.0 * K * N));
-#define WG(NBV)                                                                                                   \
-  do {                                                                                                            \
-    if (act == ADNM_ACT_GELU) {                                                                                   \
-      ADNM_ALLOW_LDS((conv3_wgrad_kernel<NBV, ADNM_ACT_GELU>), smem, "conv3_wgrad");                              \
-      conv3_wgrad_kernel<NBV, ADNM_ACT_GELU><<<grid, kBlock, smem, st>>>(a);                                      \
-    } else {                                                                                                      \
-      ADNM_ALLOW_LDS((conv3_wgrad_kernel<NBV, ADNM_ACT_NONE>), smem, "conv3_wgrad");                              \
-      conv3_wgrad_kernel<NBV, ADNM_ACT_NONE><<<grid, kBlock, smem, st>>>(a);                                      \
-    }                                                                                                             \
+#define WG1(NBV, ACTV, BFV)                                                                   \
+  do {                                                                                        \
+    ADNM_ALLOW_LDS((conv3_wgrad_kernel<NBV, ACTV, BFV>), smem, "conv3_wgrad");                \
+    conv3_wgrad_kernel<NBV, ACTV, BFV><<<grid, kBlock, smem, st>>>(a);                        \
+  } while (0)
+#define WG(NBV)                                                                               \
+  do {                                                                                        \
+    if (act == ADNM_ACT_GELU) { if (prec == ADNM_MFMA_BF16) WG1(NBV, ADNM_ACT_GELU, true); else WG1(NBV, ADNM_ACT_GELU, false); } \
+    else { if (prec == ADNM_MFMA_BF16) WG1(NBV, ADNM_ACT_NONE, true); else WG1(NBV, ADNM_ACT_NONE, false); }                     \
   } while (0)
     if (p.nb == 2) WG(2);
     else WG(1);
 #undef WG
+#undef WG1
   }
   ADNM_CHECK_LAUNCH("conv3_wgrad");
   adnm_launch_fold("conv3_wgrad_fold", (const float*)ws, p.rows, (int)p.rowlen, {dw, (int)(N * 9 * K)}, {dbias, dbias ? (int)N : 0}, {nullptr, 0},

@@ -23,7 +23,7 @@
 
 namespace {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x4 = adnm_f32x4;
 constexpr int kBlock = 512;
 constexpr int kWaves = kBlock / 64;
 constexpr int kT = 4;
@@ -44,7 +44,7 @@ struct SkArgs {
 };
 
 // A_RC / B_RC: operand contiguous along the reduction axis
-template <bool A_RC, bool B_RC>
+template <bool A_RC, bool B_RC, bool BF16>
 __global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
   __shared__ __attribute__((aligned(16))) float red[(kWaves / 2) * kBuf];
   const int wave = threadIdx.x >> 6;
@@ -120,16 +120,15 @@ __global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
       for (int t = 0; t < kT; ++t) bs[t] += (av[t][0] + av[t][1]) + (av[t][2] + av[t][3]);
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int a = 0; a < kT; ++a)
 #pragma unroll
-      for (int a = 0; a < kT; ++a)
-#pragma unroll
-        for (int b = 0; b < kT; ++b) {
-          // B_RC (the NT op): operands swapped, so the accumulator block is C^T and a lane ends up with four CONSECUTIVE output
-          // columns of one row (float4 stores); otherwise the 4 interleaved column blocks already give that
-          if (B_RC) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[b][e], av[a][e], acc[a][b], 0, 0, 0);
-          else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][e], bv[b][e], acc[a][b], 0, 0, 0);
-        }
+      for (int b = 0; b < kT; ++b) {
+        // B_RC (the NT op): operands swapped, so the accumulator block is C^T and a lane ends up with four CONSECUTIVE output
+        // columns of one row (float4 stores); otherwise the 4 interleaved column blocks already give that.
+        // av[.][e] / bv[.][e] = reduction step 4*kk + e of the chunk: one bf16 MFMA (ADNM_MFMA_BF16) or four fp32 ones
+        if (B_RC) acc[a][b] = adnm_mfma16<BF16>(bv[b], av[a], acc[a][b]);
+        else acc[a][b] = adnm_mfma16<BF16>(av[a], bv[b], acc[a][b]);
+      }
   };
   // fetches are unconditional (past the end they re-read the last chunk): a branch around them would make the compiler's
   // wait-count bookkeeping assume the worst path and wait for the NEW loads before the first MFMA
@@ -274,7 +273,8 @@ extern "C" int64_t adnm_skgemm_ws_bytes(int op, int64_t M, int64_t N, int64_t K)
 }
 
 extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, float* dbias,
-                           void* ws, int64_t ws_bytes, int64_t M, int64_t N, int64_t K, adnm_stream_t stream) {
+                           void* ws, int64_t ws_bytes, int64_t M, int64_t N, int64_t K, int prec, adnm_stream_t stream) {
+  ADNM_REQUIRE(prec == ADNM_MFMA_F32 || prec == ADNM_MFMA_BF16, "skgemm: bad prec %d", prec);
   ADNM_REQUIRE(a && b && c, "skgemm: null pointer");
   ADNM_REQUIRE(shape_ok(op, M, N, K), "skgemm: unsupported op/shape op=%d M=%lld N=%lld K=%lld", op, (long long)M, (long long)N, (long long)K);
   int64_t I, J, R;
@@ -307,9 +307,15 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   const unsigned grid = (unsigned)adnm_cdiv((int64_t)pl.ntiles * pl.nbs, kWaves / pl.wpt);
   {
     ADNM_PROF(op == ADNM_SKGEMM_NT ? "skgemm_nt" : (op == ADNM_SKGEMM_NN ? "skgemm_nn" : "skgemm_tn"), st, 4.0 * ((double)M * (K + N) + (double)N * K));
-    if (op == ADNM_SKGEMM_NT) skgemm_kernel<true, true><<<grid, kBlock, 0, st>>>(p);
-    else if (op == ADNM_SKGEMM_NN) skgemm_kernel<true, false><<<grid, kBlock, 0, st>>>(p);
-    else skgemm_kernel<false, false><<<grid, kBlock, 0, st>>>(p);
+    if (prec == ADNM_MFMA_BF16) {
+      if (op == ADNM_SKGEMM_NT) skgemm_kernel<true, true, true><<<grid, kBlock, 0, st>>>(p);
+      else if (op == ADNM_SKGEMM_NN) skgemm_kernel<true, false, true><<<grid, kBlock, 0, st>>>(p);
+      else skgemm_kernel<false, false, true><<<grid, kBlock, 0, st>>>(p);
+    } else {
+      if (op == ADNM_SKGEMM_NT) skgemm_kernel<true, true, false><<<grid, kBlock, 0, st>>>(p);
+      else if (op == ADNM_SKGEMM_NN) skgemm_kernel<true, false, false><<<grid, kBlock, 0, st>>>(p);
+      else skgemm_kernel<false, false, false><<<grid, kBlock, 0, st>>>(p);
+    }
   }
   ADNM_CHECK_LAUNCH("skgemm");
   if (split) {

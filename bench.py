@@ -80,6 +80,10 @@ def parse():
     ap.add_argument("--reduce-dtype", default="f32", choices=["f32", "bf16"], help="wire dtype of the gradient all-reduce (N>1)")
     ap.add_argument("--dump-prof", default="", help="write the per-(kernel, shape) HIP-event table of the instrumented steps to this file")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): replay fwd+bwd as captured hipGraphs; 0: eager launches")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="matrix-core precision of the GEMM-shaped kernels: f32 = exact fp32 MFMA (the parity path, tolerance 1e-4 / 1e-3); "
+                         "bf16 = BASELINE config 2's precision: bf16 MFMA operands, fp32 accumulation and storage (tolerance 6e-2 vs the "
+                         "fp32 reference, tests/test_model_gpu.py::test_visionmamba_bf16_mfma_vs_reference)")
     return ap.parse_args()
 
 
@@ -235,7 +239,8 @@ def main():
     from models.ADNMUNet import create_ADNMUNet
     from models.loss import enRainfallLoss
     lib.load()
-    torch.backends.cuda.preferred_blas_library("hipblas")   # whatever plain library GEMM is left: rocBLAS (hipBLASLt's long-reduction picks are 6x slower here)
+    from adnm_hip import ops
+    ops.set_mfma_precision(args.dtype)
 
     os.environ["ADNM_AUTO_DDP"] = "0"   # FlatTrainer owns the gradient collective here (the factory's hook-driven DDP is for train.py)
     model = create_ADNMUNet(args.in_frames, args.out_frames, 6, img_size=args.size)
@@ -352,7 +357,8 @@ def main():
             "metric": "sequences/sec training ADNM-UNet 5->20x128x128", "value": round(world * args.batch * args.steps / dt, 3),
             "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.dtype == "f32" else "bf16 MFMA operands (short GEMMs, dense convs), f32 accumulation + storage",
+            "data": "synthetic",
             "config": {"workload": f"ADNM-UNet create_ADNMUNet({args.in_frames},{args.out_frames},6) {args.size}x{args.size} full training step "
                                    "(fwd + enRainfallLoss + bwd + clip_grad_norm_ + AdamW), recipe parameters, synthetic radar frames in HBM",
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch, "frames": f"{args.in_frames}->{args.out_frames}",

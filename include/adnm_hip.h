@@ -38,6 +38,9 @@ typedef void* adnm_stream_t; /* hipStream_t */
 enum { ADNM_F32 = 0, ADNM_BF16 = 1 };
 enum { ADNM_ACT_NONE = 0, ADNM_ACT_SILU = 1, ADNM_ACT_GELU = 2 };
 enum { ADNM_OK = 0, ADNM_EINVAL = -1, ADNM_ELAUNCH = -2, ADNM_EWORKSPACE = -3 };
+/* `prec` of the GEMM-shaped entry points (tsgemm, skgemm, conv3): exact fp32 MFMA, or operands rounded to bf16 on the way into the
+ * bf16 MFMA with fp32 accumulation (BASELINE's bf16 configurations: 8x the matrix rate; storage stays fp32). */
+enum { ADNM_MFMA_F32 = 0, ADNM_MFMA_BF16 = 1 };
 
 const char* adnm_last_error(void);
 int adnm_abi_version(void);
@@ -268,7 +271,7 @@ int adnm_colsum(const float* x, float* out, int64_t rows, int64_t n, adnm_stream
 int adnm_skgemm_supported(int op, int64_t M, int64_t N, int64_t K);
 int64_t adnm_skgemm_ws_bytes(int op, int64_t M, int64_t N, int64_t K);
 int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, float* dbias,
-                void* ws, int64_t ws_bytes, int64_t M, int64_t N, int64_t K, adnm_stream_t stream);
+                void* ws, int64_t ws_bytes, int64_t M, int64_t N, int64_t K, int prec, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- enRainfallLoss (K14)
  * models/loss.py:30-57 of the reference (train_untils.py:43 builds it with omega_t 0.57, alpha 0.25, gamma 0):
@@ -329,14 +332,14 @@ int adnm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, flo
 int64_t adnm_conv3_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t K, int64_t N);
 int adnm_conv3_fwd(const float* in, int64_t ldin, const float* w, int64_t ws_n, int64_t ws_tap, int64_t ws_k, const float* bias,
                    float* out, int64_t ldo, float* pre, int64_t ldpre, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W,
-                   int64_t K, int64_t N, int act, adnm_stream_t stream);
+                   int64_t K, int64_t N, int act, int prec, adnm_stream_t stream);
 int adnm_conv3_dgrad(const float* dout, int64_t lddo, const float* pre, int64_t ldpre, int act, const float* w, int64_t ws_n,
                      int64_t ws_tap, int64_t ws_k, float* din, int64_t lddin, void* ws, int64_t ws_bytes, int64_t B, int64_t H,
-                     int64_t W, int64_t K, int64_t N, adnm_stream_t stream);
+                     int64_t W, int64_t K, int64_t N, int prec, adnm_stream_t stream);
 int64_t adnm_conv3_wgrad_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t K, int64_t N);
 int adnm_conv3_wgrad(const float* dout, int64_t lddo, const float* pre, int64_t ldpre, int act, const float* in, int64_t ldin,
                      float* dw, float* dbias, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W, int64_t K, int64_t N,
-                     adnm_stream_t stream);
+                     int prec, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- stride-2 transposed conv of UpSample (K9)
  * nn.ConvTranspose2d(C, C, k=3, s=2, p=1, output_padding=1) (model_untils.py:120-158,490-520) = one GEMM over the input pixels

@@ -15,7 +15,7 @@ THR = [20, 30, 35, 40]
 
 def test_oracle_resize_vs_fixture():
     z = load_npz("radar_resize_565x784_to_128")
-    out = O.radar_resize(z["small_u8"], 16)
+    out = O.radar_resize(np.asarray(z["small_u8"]), 16)
     assert_close(out, z["small_out"], 1e-6, "small resize")
 
 
@@ -79,7 +79,7 @@ def test_checkpoint_full_model_keys():
 def test_radar_ingest_vs_fixture():
     from adnm_hip import dataio
     z = load_npz("radar_resize_565x784_to_128")
-    small = z["small_u8"].to(torch.uint8).cuda()[None]      # (1, 3, 57, 79)
+    small = torch.as_tensor(np.asarray(z["small_u8"])).to(torch.uint8).cuda()[None]      # (1, 3, 57, 79)
     out = dataio.ingest(small, 16)
     assert out.shape == (1, 3, 1, 16, 16)
     assert_close(out[0, :, 0], z["small_out"], 1e-6, "small resize")

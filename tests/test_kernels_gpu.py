@@ -584,7 +584,7 @@ def test_unsupported_shapes_raise():
     with pytest.raises(RuntimeError, match="no PyTorch fallback"):
         ops.catmix(odd, odd, None, one, one)
     with pytest.raises(RuntimeError, match="no PyTorch fallback"):
-        ops.lincomb([odd, odd], [one, one])
+        ops.lincomb([odd, odd], [one, one], gamma=torch.ones(6, device=DEV))     # a per-channel gamma needs 4 | C
     with pytest.raises(RuntimeError, match="no PyTorch fallback"):
         ops.igate(torch.zeros(3, device=DEV), one, one)
     with pytest.raises(RuntimeError, match="no PyTorch fallback"):
@@ -694,3 +694,46 @@ def test_lincomb_scalar_mix_any_channel_count():
     assert_close(y, o[2] * o[0] + o[3] * o[1], 1e-6, "y")
     for name, u, v in zip(("da", "db", "ds1", "ds2"), g, o):
         assert_close(u.grad, v.grad, 1e-4, name)
+
+
+# ------------------------------------------------------------------------------------------- bf16 MFMA precision (BASELINE's bf16 configs)
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+@pytest.fixture
+def bf16_mfma():
+    ops.set_mfma_precision("bf16")
+    yield
+    ops.set_mfma_precision("f32")
+
+
+@pytest.mark.parametrize("M,K,N", [(64, 1024, 512), (1024, 256, 1216), (300, 20, 64)])
+def test_skgemm_bf16_mfma(M, K, N, bf16_mfma):
+    """prec = ADNM_MFMA_BF16: operands rounded to bf16 (RNE), products and sums in fp32 — i.e. EXACTLY the fp32 GEMM of the rounded
+    operands (up to summation order), and within bf16 rounding (2^-9 per operand) of the unrounded one."""
+    x, w, cot = T(f"bf.x{M}{K}", (M, K)), T(f"bf.w{N}{K}", (N, K), 0.05), T(f"bf.c{M}{N}", (M, N))
+    xg, wg = leaf(x, DEV), leaf(w, DEV)
+    yg = ops.linear(xg, wg, None)
+    (yg * cot.to(DEV)).sum().backward()
+    xr, wr, cr = _bf16_round(x).double(), _bf16_round(w).double(), _bf16_round(cot).double()
+    assert_close(yg, xr @ wr.t(), 2e-6, "y vs the GEMM of bf16-rounded operands")
+    assert_close(yg, x.double() @ w.double().t(), 1e-2, "y vs the unrounded GEMM")
+    assert_close(xg.grad, cr @ wr, 2e-6, "dx")
+    assert_close(wg.grad, cr.t() @ xr, 2e-6, "dw")
+
+
+def test_conv3_bf16_mfma(bf16_mfma):
+    B, H, W, K, N = 2, 16, 16, 32, 64
+    x, w, b, cot = T("bfc.x", (B, H * W, K)), T("bfc.w", (N, K, 3, 3), 0.2), T("bfc.b", (N,)), T("bfc.c", (B, H * W, N))
+    xg, wg, bg = leaf(x, DEV), leaf(w, DEV), leaf(b, DEV)
+    yg = ops.conv3(xg, wg, bg, H, W, lib.ACT_NONE)
+    (yg * cot.to(DEV)).sum().backward()
+    xr, wr, cr = _bf16_round(x).double(), _bf16_round(w).double(), _bf16_round(cot).double()
+    xo, wo = leaf(xr), leaf(wr)
+    yo = F.conv2d(xo.view(B, H, W, K).permute(0, 3, 1, 2), wo, b.double(), padding=1).permute(0, 2, 3, 1).reshape(B, H * W, N)
+    (yo * cr).sum().backward()
+    assert_close(yg, yo, 2e-6, "y vs the conv of bf16-rounded operands")
+    assert_close(xg.grad, xo.grad, 2e-6, "dx")
+    assert_close(wg.grad, wo.grad, 2e-6, "dw")
+    assert_close(bg.grad, cot.double().sum((0, 1)), 1e-5, "db (fp32 sums of the unrounded gradient)")
