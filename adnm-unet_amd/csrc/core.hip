@@ -110,11 +110,16 @@ struct MultiFold {
   int blk_end[kMaxFolds];   // exclusive prefix of column-block counts
   FoldDesc d[kMaxFolds];
 };
-__global__ __launch_bounds__(kFoldCols* kFoldSlices) void fold_rows_kernel(MultiFold mf) {
+__global__ __launch_bounds__(kFoldCols* kFoldSlices) void fold_rows_kernel(MultiFold mf_by_value) {
   __shared__ float sm[kFoldSlices][kFoldCols + 1];
+  // The descriptor table is indexed with a run-time (workgroup-uniform) k.  Indexing the by-value argument makes the compiler copy the
+  // whole 1.1 KB struct into per-thread scratch first (measured: a 3.7 MB fold took 167 us); reading it through the kernarg segment
+  // pointer keeps it in constant memory / scalar loads.  The explicit arguments of a HIP kernel start at offset 0 of that segment.
+  (void)mf_by_value;
+  const __attribute__((address_space(4))) MultiFold& mf = *(const __attribute__((address_space(4))) MultiFold*)__builtin_amdgcn_kernarg_segment_ptr();
   int k = 0;
   while (k + 1 < mf.count && (int)blockIdx.x >= mf.blk_end[k]) ++k;
-  const FoldDesc& fd = mf.d[k];
+  const __attribute__((address_space(4))) FoldDesc& fd = mf.d[k];
   const float* __restrict__ part = fd.part;
   const int rows = fd.rows, n = fd.n;
   const int cl = threadIdx.x & (kFoldCols - 1), sl = threadIdx.x / kFoldCols;
