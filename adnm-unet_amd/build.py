@@ -30,7 +30,7 @@ def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
-    deps = tuple(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + (
+    deps = tuple(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + (
         os.path.join(os.path.dirname(HERE), "include", "adnm_hip.h"),)
     jobs = []
     for f in srcs:

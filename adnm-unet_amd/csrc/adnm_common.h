@@ -31,6 +31,14 @@ struct AdnmFoldSeg {
 void adnm_launch_fold(const char* prof_name, const float* part, int rows, int n, AdnmFoldSeg s0, AdnmFoldSeg s1, AdnmFoldSeg s2,
                       AdnmFoldSeg s3, hipStream_t st);
 
+// LDS-tiled NT / NN GEMM (lgemm.hip), reached through adnm_skgemm.  b_oc: second operand contiguous along the output axis (op NN);
+// nbs: cross-workgroup split of the reduction (combined inside the launch).  adnm_take_tickets (skgemm.hip): `n` zeroed arrival
+// counters from the per-device ring, NULL on failure.
+int64_t adnm_lgemm_ws_bytes(int64_t I, int64_t J, int64_t R, int nbs);
+int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, void* ws,
+                      int64_t ws_bytes, int64_t I, int64_t J, int64_t R, int nbs, int prec, hipStream_t st);
+int* adnm_take_tickets(int n, hipStream_t st);
+
 #define ADNM_REQUIRE(cond, ...)            \
   do {                                     \
     if (!(cond)) {                         \

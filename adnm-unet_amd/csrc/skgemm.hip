@@ -1,147 +1,187 @@
-// K6b — the Linear layers of the DEEP stages (4x4 .. 16x16 maps: M = 64 .. 1024 token rows, 128 .. 4672 features) as
-// "short" fp32 GEMMs on the matrix cores.  Reference call sites: Mamba2.in_proj / out_proj (ADNssd.py:309,461),
-// FeedForward.project_in / project_out (model_untils.py:193,196), Mlp.fc1/fc2 (:64,67), ConvFFD (:217,221),
-// Block.out_proj (ADNMUNet.py:163), StandardAttention.to_qkv / to_out (ADNssd.py:33-34), Channel_Att_Bridge.att* (:744-750).
+// K6b — the Linear layers of the DEEP stages (4x4 .. 32x32 maps: M = 4 .. 1024 token rows, 128 .. 4672 features) as "short" GEMMs on
+// the matrix cores, fp32 in memory.  Reference call sites: Mamba2.in_proj / out_proj (ADNssd.py:309,461), FeedForward.project_in /
+// project_out (model_untils.py:193,196), Mlp.fc1/fc2 (:64,67), ConvFFD (:217,221), Block.out_proj (ADNMUNet.py:163),
+// StandardAttention.to_qkv / to_out (ADNssd.py:33-34), Channel_Att_Bridge.att* (:744-750), UpSample's ConvTranspose2d as a GEMM.
 //
-// With M = 64 every weight element is used for 64 rows = 32 FLOP per byte: the fp32 MFMA peak (157 TFLOP/s) and the HBM
-// peak meet there, so the job is to stream each weight ONCE at full bandwidth while all 1024 SIMDs issue MFMAs.  Library
-// GEMMs pick 32x32..256x256 macro tiles and leave most of the chip idle on these shapes (measured 13 us average, 123 us
-// worst).  Here ONE WAVE is the unit of work: a 64x64 output tile (4x4 blocks of v_mfma_f32_16x16x4_f32, exact fp32)
-// over one slice of the reduction axis; tiles x slices are spread over the whole chip.  The 2/4/8 waves of a workgroup
-// that share a tile sum their slices through LDS (tree, fixed order); what is left of the split goes through fp32
-// partials and the shared deterministic fold (no atomics).  A wave's operands come straight from global memory as
-// 16-byte loads, double-buffered in registers.
-//
-//   op NT:  C[M,N] = A[M,K] . W[N,K]^T (+ bias)      forward            both operands contiguous along the reduction
-//   op NN:  C[M,K] = A[M,N] . W[N,K]                 input gradient     W contiguous along the OUTPUT axis
+//   op NT:  C[M,N] = A[M,K] . W[N,K]^T (+ bias)      forward            both operands contiguous along the reduction ("RC")
+//   op NN:  C[M,K] = A[M,N] . W[N,K]                 input gradient     W contiguous along the OUTPUT axis ("OC")
 //   op TN:  C[N,K] = A[M,N]^T . X[M,K], db = sum_m A  weight gradient    both contiguous along the output axes
 //
-// An operand that is contiguous along the reduction gives a lane 4 consecutive reduction steps of one tile row per float4;
-// one contiguous along the output axis gives a lane ONE step of 4 interleaved tile rows (tile row 4*l+t of block t), so
-// the 64-wide tile is a permutation of 64 consecutive rows/columns and the epilogue stores whole float4s.
+// These problems are small (0.1 - 2 GFLOP, 1 - 20 MB) and every one sits on the step's critical path, so what decides the time is
+// how many CUs pull operand bytes at once and how many bytes each keeps in flight — not the MFMA rate.  Two kernels share the work
+// (adnm_skgemm picks one per shape, statically: the same choice in every process and on every rank):
+//
+//   * this file, the REGISTER-STREAMING kernel: one wave owns a (16 TM) x (16 TN) output tile over one slice of the reduction and
+//     loads its MFMA operands straight from global memory into registers (16-byte loads, three register buffers = two 16 KC-step
+//     chunks in flight under the MFMAs of the third), no LDS staging and no barrier in the loop.  The 2 / 4 / 8 waves of a workgroup
+//     that share a tile take different slices and sum them through LDS (tree, fixed order).  Small outputs take small tiles
+//     (TM x TN = 1x1, 2x2: more tiles -> more CUs; the operands they re-read come from L2), large ones 4x4.  A reduction that still
+//     leaves CUs idle is split over workgroups: the weight-gradient op (TN) writes fp32 partials for the shared fold kernel, whose
+//     launch is batched with the other parameter-gradient folds and deferred off the critical path; NT / NN combine their slabs
+//     INSIDE the launch (arrival tickets; the last workgroup of a tile adds the slabs in slice order: bitwise reproducible).
+//   * lgemm.hip, the LDS-TILED kernel, for outputs of >= ~128 64x64 tiles, where sharing each operand tile between four waves halves
+//     the L2 -> CU traffic that bounds those shapes.
+//
+// An operand that is contiguous along the reduction gives a lane 4 consecutive reduction steps of one tile row per float4; one
+// contiguous along the output axis gives a lane ONE step of 4 interleaved tile rows (tile row 4*l+t of block t; such an operand is
+// always 4 blocks = 64 wide), so the 64-wide tile is a permutation of 64 consecutive rows/columns and the epilogue stores float4s.
+// Which reduction steps a lane feeds to which MFMA is a permutation shared by both operands ("k-permutation").
 #include "adnm_common.h"
+
+#include <mutex>
 
 namespace {
 
 using f32x4 = adnm_f32x4;
 constexpr int kBlock = 512;
 constexpr int kWaves = kBlock / 64;
-constexpr int kT = 4;
-constexpr int kBuf = 64 * 64 + 4 * 64;   // one wave's accumulators (+ its bias-gradient lanes) in LDS   // 4 x 4 blocks of 16 x 16 per wave
 
 struct SkArgs {
   const float* A;
   int64_t sa_i, sa_r;   // A(i, r) = A[i*sa_i + r*sa_r]
   const float* B;
   int64_t sb_r, sb_j;   // B(r, j) = B[r*sb_r + j*sb_j]
-  const float* bias;    // added to slice 0 (NT), or NULL
-  float* C;             // output, or the partial base when nslices > 1
+  const float* bias;    // NT: added once, or NULL
+  float* C;             // output; with nbs > 1 the slab base ([slice][I*J (+I)])
   int64_t ldc, slice_stride;
   float* bsum;          // TN: column sums of A (bias gradient), or NULL
   int64_t bsum_stride;
   int I, J, R;
-  int tiles_j, ntiles, nbs, wpt, chunks_per_wave, nchunks;   // nbs block-slices x wpt waves per tile
+  int tiles_j, ntiles, nbs, wpt, chunks_per_wave, nchunks;   // nbs workgroup-slices x wpt waves per tile; a chunk = 16 KC steps
+  int* tickets;         // NT / NN with nbs > 1: one arrival counter per output tile (zero when idle); the result goes to `out`
+  float* out;
+  int64_t ldo;
 };
 
-// A_RC / B_RC: operand contiguous along the reduction axis
-template <bool A_RC, bool B_RC, bool BF16>
+// A_RC / B_RC: operand contiguous along the reduction axis.  TM x TN blocks of 16 x 16 per wave, KC 16-step groups per chunk.
+template <bool A_RC, bool B_RC, bool BF16, int TM, int TN, int KC>
 __global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
+  static_assert((A_RC || TM == 4) && (B_RC || TN == 4), "an operand contiguous along the output axis is 4 interleaved blocks wide");
+  constexpr int kAcc = TM * TN * 256;        // one wave's accumulators ...
+  constexpr int kBuf = kAcc + 4 * 64;        // ... + its bias-gradient lanes, in LDS
   __shared__ __attribute__((aligned(16))) float red[(kWaves / 2) * kBuf];
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, and the compiler should know it
   const int gw = wave % p.wpt, group = wave / p.wpt;                 // slice within the tile's wave group, group within the block
-  const int ts = blockIdx.x * (kWaves / p.wpt) + group;
+  int ts = blockIdx.x * (kWaves / p.wpt) + group;
   const bool active = ts < p.ntiles * p.nbs;
-  const int tile = active ? ts % p.ntiles : 0, bslice = active ? ts / p.ntiles : 0;
-  const int i0 = (tile / p.tiles_j) * 16 * kT, j0 = (tile % p.tiles_j) * 16 * kT;
+  int tile, bslice;
+  if (p.tickets) {
+    // one tile slice per workgroup.  Workgroups go round-robin over the 8 XCDs: give each XCD a contiguous run of (tile, slice) pairs so
+    // that the slices of a tile (whose slabs the last of them reads back) and neighbouring tiles (which share A rows) meet in one L2.
+    // A speed choice only: the combine below is correct for any placement.
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) ts = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    tile = ts / p.nbs, bslice = ts % p.nbs;
+  } else {
+    tile = active ? ts % p.ntiles : 0, bslice = active ? ts / p.ntiles : 0;
+  }
+  const int i0 = (tile / p.tiles_j) * 16 * TM, j0 = (tile % p.tiles_j) * 16 * TN;
   const int lane = threadIdx.x & 63, l15 = lane & 15, kk = lane >> 4;
   const int c0 = active ? (bslice * p.wpt + gw) * p.chunks_per_wave : 0;
   const int c1 = !active ? 0 : (c0 + p.chunks_per_wave < p.nchunks ? c0 + p.chunks_per_wave : p.nchunks);
 
-  // fetch one chunk (16 reduction steps' worth = 4 MFMA steps) of both operands: v[t][e] = value of tile block t at step e.
-  // Out-of-range rows / columns read a clamped (valid) address: their products land in accumulator rows / columns that are
-  // never stored.  Reduction steps past R (only the TN op has such a tail) are zeroed on the A side when they are USED,
-  // so nothing in here waits for a load and all 8 stay in flight under the previous chunk's MFMAs.
-  auto fetch = [&](int c, float (&av)[kT][4], float (&bv)[kT][4]) {
-    const int r0 = c * 16;
-    // operands contiguous along the reduction: a ragged last chunk (R % 16 != 0; R % 4 == 0) re-reads a valid quad; its products are
-    // zeroed on the A side when they are used
-    const int rq4 = r0 + 4 * kk < p.R ? r0 + 4 * kk : 0;
-    if (A_RC) {
+  // fetch one chunk (KC groups of 16 reduction steps = 4 MFMA steps each) of both operands: v[t][s][e] = value of tile block t at
+  // step e of the lane's quad in group s.  Out-of-range rows / columns read a clamped (valid) address: their products land in
+  // accumulator rows / columns that are never stored.  Reduction steps past R are zeroed on the A side when they are USED, so nothing
+  // in here waits for a load and every load stays in flight under the previous chunk's MFMAs.
+  // `live` (wave-uniform): a fetch past the wave's last chunk still issues its loads (a branch around them would make the compiler's
+  // wait counts assume the worst path), but all lanes read ONE 16-byte word: a single broadcast request instead of 16 line requests.
+  auto fetch = [&](int c, bool live, float (&av)[TM][KC][4], float (&bv)[TN][KC][4]) {
 #pragma unroll
-      for (int t = 0; t < kT; ++t) {
-        const int row = i0 + 16 * t + l15, rc = row < p.I ? row : p.I - 1;
-        const float4 v = *reinterpret_cast<const float4*>(p.A + (int64_t)rc * p.sa_i + rq4);
-        av[t][0] = v.x; av[t][1] = v.y; av[t][2] = v.z; av[t][3] = v.w;
+    for (int s = 0; s < KC; ++s) {
+      const int r0 = (c * KC + s) * 16;
+      // operands contiguous along the reduction: a group past R (R % 4 == 0) re-reads a valid quad
+      const int rq4 = r0 + 4 * kk < p.R ? r0 + 4 * kk : 0;
+      if constexpr (A_RC) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          const int row = i0 + 16 * t + l15, rc = row < p.I ? row : p.I - 1;
+          const float4 v = *reinterpret_cast<const float4*>(p.A + (live ? (int64_t)rc * p.sa_i + rq4 : 0));
+          av[t][s][0] = v.x, av[t][s][1] = v.y, av[t][s][2] = v.z, av[t][s][3] = v.w;
+        }
+      } else {
+        const int row = i0 + 4 * l15, rc = row < p.I ? row : p.I - 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int rr = r0 + 4 * kk + e, rq = rr < p.R ? rr : p.R - 1;
+          const float4 v = *reinterpret_cast<const float4*>(p.A + (live ? (int64_t)rq * p.sa_r + rc : 0));
+          av[0][s][e] = v.x, av[1 % TM][s][e] = v.y, av[2 % TM][s][e] = v.z, av[3 % TM][s][e] = v.w;
+        }
       }
-    } else {
-      const int row = i0 + 4 * l15, rc = row < p.I ? row : p.I - 4;
+      if constexpr (B_RC) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int rr = r0 + 4 * kk + e, rq = rr < p.R ? rr : p.R - 1;
-        const float4 v = *reinterpret_cast<const float4*>(p.A + (int64_t)rq * p.sa_r + rc);
-        av[0][e] = v.x; av[1][e] = v.y; av[2][e] = v.z; av[3][e] = v.w;
-      }
-    }
-    if (B_RC) {
+        for (int t = 0; t < TN; ++t) {
+          const int col = j0 + 16 * t + l15, cc = col < p.J ? col : p.J - 1;
+          const float4 v = *reinterpret_cast<const float4*>(p.B + (live ? (int64_t)cc * p.sb_j + rq4 : 0));
+          bv[t][s][0] = v.x, bv[t][s][1] = v.y, bv[t][s][2] = v.z, bv[t][s][3] = v.w;
+        }
+      } else {
+        const int col = j0 + 4 * l15, cc = col < p.J ? col : p.J - 4;
 #pragma unroll
-      for (int t = 0; t < kT; ++t) {
-        const int col = j0 + 16 * t + l15, cc = col < p.J ? col : p.J - 1;
-        const float4 v = *reinterpret_cast<const float4*>(p.B + (int64_t)cc * p.sb_j + rq4);
-        bv[t][0] = v.x; bv[t][1] = v.y; bv[t][2] = v.z; bv[t][3] = v.w;
-      }
-    } else {
-      const int col = j0 + 4 * l15, cc = col < p.J ? col : p.J - 4;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int rr = r0 + 4 * kk + e, rq = rr < p.R ? rr : p.R - 1;
-        const float4 v = *reinterpret_cast<const float4*>(p.B + (int64_t)rq * p.sb_r + cc);
-        bv[0][e] = v.x; bv[1][e] = v.y; bv[2][e] = v.z; bv[3][e] = v.w;
+        for (int e = 0; e < 4; ++e) {
+          const int rr = r0 + 4 * kk + e, rq = rr < p.R ? rr : p.R - 1;
+          const float4 v = *reinterpret_cast<const float4*>(p.B + (live ? (int64_t)rq * p.sb_r + cc : 0));
+          bv[0][s][e] = v.x, bv[1 % TN][s][e] = v.y, bv[2 % TN][s][e] = v.z, bv[3 % TN][s][e] = v.w;
+        }
       }
     }
   };
 
-  f32x4 acc[kT][kT];
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int a = 0; a < kT; ++a)
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < kT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bs[kT] = {0.f, 0.f, 0.f, 0.f};
-  // ping-pong register buffers, two chunks per trip: the loads of chunk c+1 are issued BEFORE the 64 MFMAs of chunk c (the
-  // scheduling barriers keep the compiler from sinking them below), so HBM latency hides under the matrix pipe
-  float a0[kT][4], b0[kT][4], a1[kT][4], b1[kT][4];
-  auto compute = [&](int c, float (&av)[kT][4], const float (&bv)[kT][4]) {
-    if (c * 16 + 16 > p.R) {   // reduction tail (wave-uniform branch): zero the A side, the B side may hold anything finite
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](int c, float (&av)[TM][KC][4], const float (&bv)[TN][KC][4]) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (c * 16 + 4 * kk + (A_RC ? 0 : e) >= p.R) av[0][e] = av[1][e] = av[2][e] = av[3][e] = 0.f;
-    }
-    if (!A_RC && p.bsum) {
+    for (int s = 0; s < KC; ++s) {
+      const int r0 = (c * KC + s) * 16;
+      if (r0 + 16 > p.R) {   // reduction tail (wave-uniform branch): zero the A side, the B side may hold anything finite
 #pragma unroll
-      for (int t = 0; t < kT; ++t) bs[t] += (av[t][0] + av[t][1]) + (av[t][2] + av[t][3]);
-    }
+        for (int e = 0; e < 4; ++e)
+          if (r0 + 4 * kk + (A_RC ? 0 : e) >= p.R) {
 #pragma unroll
-    for (int a = 0; a < kT; ++a)
-#pragma unroll
-      for (int b = 0; b < kT; ++b) {
-        // B_RC (the NT op): operands swapped, so the accumulator block is C^T and a lane ends up with four CONSECUTIVE output
-        // columns of one row (float4 stores); otherwise the 4 interleaved column blocks already give that.
-        // av[.][e] / bv[.][e] = reduction step 4*kk + e of the chunk: one bf16 MFMA (ADNM_MFMA_BF16) or four fp32 ones
-        if (B_RC) acc[a][b] = adnm_mfma16<BF16>(bv[b], av[a], acc[a][b]);
-        else acc[a][b] = adnm_mfma16<BF16>(av[a], bv[b], acc[a][b]);
+            for (int t = 0; t < TM; ++t) av[t][s][e] = 0.f;
+          }
       }
+      if (!A_RC && p.bsum) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) bs[t] += (av[t][s][0] + av[t][s][1]) + (av[t][s][2] + av[t][s][3]);
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          // B_RC (the NT op): operands swapped, so the accumulator block is C^T and a lane ends up with four CONSECUTIVE output
+          // columns of one row (float4 stores); otherwise the 4 interleaved column blocks already give that.
+          // av[.][s][e] / bv[.][s][e] = one reduction step: one bf16 MFMA (ADNM_MFMA_BF16) or four fp32 ones per group
+          if (B_RC) acc[a][b] = adnm_mfma16<BF16>(bv[b][s], av[a][s], acc[a][b]);
+          else acc[a][b] = adnm_mfma16<BF16>(av[a][s], bv[b][s], acc[a][b]);
+        }
+    }
   };
-  // fetches are unconditional (past the end they re-read the last chunk): a branch around them would make the compiler's
-  // wait-count bookkeeping assume the worst path and wait for the NEW loads before the first MFMA
-  const int clast = p.nchunks - 1;
-  fetch(c0 < clast ? c0 : clast, a0, b0);
-  for (int c = c0; c < c1; c += 2) {
-    fetch(c + 1 < clast ? c + 1 : clast, a1, b1);
+  // three register buffers, three chunks per trip: the loads of chunks c+1 and c+2 are in flight under the MFMAs of chunk c (the
+  // scheduling barriers keep the compiler from sinking them below), so two HBM/L2 round trips overlap per wave
+  float a0[TM][KC][4], b0[TN][KC][4], a1[TM][KC][4], b1[TN][KC][4], a2[TM][KC][4], b2[TN][KC][4];
+  const int cl = c1 > c0 ? c1 - 1 : 0;
+  auto fetch_at = [&](int c, float (&av)[TM][KC][4], float (&bv)[TN][KC][4]) { fetch(c < c1 ? c : cl, c < c1, av, bv); };
+  fetch_at(c0, a0, b0);
+  __builtin_amdgcn_sched_barrier(0);
+  fetch_at(c0 + 1, a1, b1);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int c = c0; c < c1; c += 3) {
+    fetch_at(c + 2, a2, b2);
     __builtin_amdgcn_sched_barrier(0);
     compute(c, a0, b0);
     __builtin_amdgcn_sched_barrier(0);
-    fetch(c + 2 < clast ? c + 2 : clast, a0, b0);
+    fetch_at(c + 3, a0, b0);
     __builtin_amdgcn_sched_barrier(0);
     if (c + 1 < c1) compute(c + 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_at(c + 4, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 2 < c1) compute(c + 2, a2, b2);
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -150,89 +190,152 @@ __global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
     if (gw >= half && gw < 2 * half) {
       float* buf = red + (group * (p.wpt >> 1) + (gw - half)) * kBuf;
 #pragma unroll
-      for (int a = 0; a < kT; ++a)
+      for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < kT; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) buf[((a * kT + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+          for (int r = 0; r < 4; ++r) buf[((a * TN + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+      if (!A_RC) {
 #pragma unroll
-      for (int t = 0; t < kT; ++t) buf[64 * 64 + t * 64 + lane] = bs[t];
+        for (int t = 0; t < 4; ++t) buf[kAcc + t * 64 + lane] = bs[t];
+      }
     }
     __syncthreads();
     if (gw < half) {
       const float* buf = red + (group * (p.wpt >> 1) + gw) * kBuf;
 #pragma unroll
-      for (int a = 0; a < kT; ++a)
+      for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < kT; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[a][b][r] += buf[((a * kT + b) * 4 + r) * 64 + lane];
+          for (int r = 0; r < 4; ++r) acc[a][b][r] += buf[((a * TN + b) * 4 + r) * 64 + lane];
+      if (!A_RC) {
 #pragma unroll
-      for (int t = 0; t < kT; ++t) bs[t] += buf[64 * 64 + t * 64 + lane];
+        for (int t = 0; t < 4; ++t) bs[t] += buf[kAcc + t * 64 + lane];
+      }
     }
     __syncthreads();
   }
-  if (!active || gw != 0) return;
+  if (!p.tickets && (!active || gw != 0)) return;
 
-  // epilogue.  MFMA C layout: column = lane & 15, row = (lane >> 4) * 4 + reg (local to the 16 x 16 block)
-  float* Cp = p.C + (int64_t)bslice * p.slice_stride;
-  const bool add_bias = p.bias && bslice == 0;
-  if (B_RC) {
-    // C^T blocks: column (lane & 15) -> row i of C, row (lane >> 4) * 4 + reg -> column j of C
-    const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(Cp) & 15) == 0 && (!add_bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
+  if (gw == 0) {
+    // epilogue.  MFMA C layout: column = lane & 15, row = (lane >> 4) * 4 + reg (local to the 16 x 16 block)
+    float* Cp = p.C + (int64_t)bslice * p.slice_stride;
+    const bool add_bias = p.bias && bslice == 0 && !p.tickets;
+    if constexpr (B_RC) {
+      // C^T blocks: column (lane & 15) -> row i of C, row (lane >> 4) * 4 + reg -> column j of C
+      const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(Cp) & 15) == 0 && (!add_bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
 #pragma unroll
-    for (int a = 0; a < kT; ++a) {
-      const int ig = i0 + 16 * a + l15;
-      if (ig >= p.I) continue;
+      for (int a = 0; a < TM; ++a) {
+        const int ig = i0 + 16 * a + l15;
+        if (ig >= p.I) continue;
 #pragma unroll
-      for (int b = 0; b < kT; ++b) {
-        const int jg = j0 + 16 * b + 4 * kk;
-        if (vec_ok && jg + 3 < p.J) {
-          float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (add_bias) bv4 = *reinterpret_cast<const float4*>(p.bias + jg);
-          *reinterpret_cast<float4*>(Cp + (int64_t)ig * p.ldc + jg) =
-              make_float4(acc[a][b][0] + bv4.x, acc[a][b][1] + bv4.y, acc[a][b][2] + bv4.z, acc[a][b][3] + bv4.w);
-        } else {
+        for (int b = 0; b < TN; ++b) {
+          const int jg = j0 + 16 * b + 4 * kk;
+          if (vec_ok && jg + 3 < p.J) {
+            float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (add_bias) bv4 = *reinterpret_cast<const float4*>(p.bias + jg);
+            *reinterpret_cast<float4*>(Cp + (int64_t)ig * p.ldc + jg) =
+                make_float4(acc[a][b][0] + bv4.x, acc[a][b][1] + bv4.y, acc[a][b][2] + bv4.z, acc[a][b][3] + bv4.w);
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (jg + r < p.J) Cp[(int64_t)ig * p.ldc + jg + r] = acc[a][b][r] + (add_bias ? p.bias[jg + r] : 0.f);
+            for (int r = 0; r < 4; ++r)
+              if (jg + r < p.J) Cp[(int64_t)ig * p.ldc + jg + r] = acc[a][b][r] + (add_bias ? p.bias[jg + r] : 0.f);
+          }
         }
       }
+    } else {   // TN == 4: the four column blocks are interleaved
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int il = kk * 4 + r;
+          const int ig = A_RC ? i0 + 16 * a + il : i0 + 4 * il + a;
+          if (ig >= p.I) continue;
+          const int jg = j0 + 4 * l15;
+          if (jg < p.J)
+            *reinterpret_cast<float4*>(Cp + (int64_t)ig * p.ldc + jg) = make_float4(acc[a][0][r], acc[a][1 % TN][r], acc[a][2 % TN][r], acc[a][3 % TN][r]);
+        }
     }
-  } else {
+    if (!A_RC && p.bsum && (tile % p.tiles_j) == 0) {   // bias gradient: the kk lanes hold different reduction rows
 #pragma unroll
-    for (int a = 0; a < kT; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int il = kk * 4 + r;
-        const int ig = A_RC ? i0 + 16 * a + il : i0 + 4 * il + a;
-        if (ig >= p.I) continue;
-        const int jg = j0 + 4 * l15;
-        if (jg < p.J) *reinterpret_cast<float4*>(Cp + (int64_t)ig * p.ldc + jg) = make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
-      }
+      for (int t = 0; t < 4; ++t) bs[t] += __shfl_xor(bs[t], 16, 64), bs[t] += __shfl_xor(bs[t], 32, 64);
+      const int ig = i0 + 4 * l15;
+      if (kk == 0 && ig < p.I) *reinterpret_cast<float4*>(p.bsum + (int64_t)bslice * p.bsum_stride + ig) = make_float4(bs[0], bs[1], bs[2], bs[3]);
+    }
   }
-  if (!A_RC && p.bsum && (tile % p.tiles_j) == 0) {   // bias gradient: the kk lanes hold different reduction rows
-#pragma unroll
-    for (int t = 0; t < kT; ++t) bs[t] += __shfl_xor(bs[t], 16, 64), bs[t] += __shfl_xor(bs[t], 32, 64);
-    const int ig = i0 + 4 * l15;
-    if (kk == 0 && ig < p.I) *reinterpret_cast<float4*>(p.bsum + (int64_t)bslice * p.bsum_stride + ig) = make_float4(bs[0], bs[1], bs[2], bs[3]);
+  if (!p.tickets) return;
+
+  // In-launch combine of the nbs slabs of this tile (one workgroup = one slice, wpt == kWaves; wave 0 has just stored this slice's slab
+  // with plain stores).  Publish: wave 0 drains its stores, lane 0 releases at agent scope and draws a ticket; the workgroup that draws
+  // the last one acquires at agent scope and all of its waves add the slabs in slice order 0 .. nbs-1 (its own included, re-read from
+  // memory), so the sum does not depend on which slice arrived last: the result is bitwise reproducible.  The counter goes back to zero
+  // for the next launch on the stream.  Correct wherever the slices ran (any CU / XCD).
+  int* flag = reinterpret_cast<int*>(red);   // the reduction buffer is idle by now (last read before the barrier above)
+  if (wave == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int drawn = __hip_atomic_fetch_add(p.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (drawn == p.nbs - 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.tickets[tile] = 0;
+      }
+      *flag = drawn;
+    }
+  }
+  __syncthreads();
+  if (*flag != p.nbs - 1) return;
+  {
+    constexpr int kQuads = 4 * TN;   // float4 columns of the tile; a thread takes one quad of every (kBlock / kQuads)-th row
+    const int jg = j0 + 4 * (threadIdx.x % kQuads);
+    if (jg >= p.J) return;   // J % 4 == 0 (host: no split otherwise)
+    for (int il = threadIdx.x / kQuads; il < 16 * TM; il += kBlock / kQuads) {
+      const int ig = i0 + il;
+      if (ig >= p.I) break;
+      const float* src = p.C + (int64_t)ig * p.ldc + jg;
+      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+      for (int s = 0; s < p.nbs; ++s) {
+        const float4 u = *reinterpret_cast<const float4*>(src + (int64_t)s * p.slice_stride);
+        sum.x += u.x, sum.y += u.y, sum.z += u.z, sum.w += u.w;
+      }
+      if (p.bias) sum.x += p.bias[jg], sum.y += p.bias[jg + 1], sum.z += p.bias[jg + 2], sum.w += p.bias[jg + 3];
+      *reinterpret_cast<float4*>(p.out + (int64_t)ig * p.ldo + jg) = sum;
+    }
   }
 }
 
+// ---- host side --------------------------------------------------------------------------------------------------------------------
+enum { KERNEL_STREAM = 0, KERNEL_LDS = 1 };
 struct Plan {
+  int kernel;            // KERNEL_STREAM (this file) or KERNEL_LDS (lgemm.hip); < 0: invalid forced configuration
+  int tm, tn, kc;        // wave tile (16 tm) x (16 tn), 16 kc reduction steps per chunk
   int tiles_i, tiles_j, ntiles, nchunks, wpt, nbs, cpw;
+  bool combine;          // nbs > 1 and the slabs are summed inside the launch (tickets) instead of by the fold kernel
 };
-// ~2048 waves when the reduction is long enough (>= 1 chunk = 64 MFMAs per wave): up to 8 waves of a block share a tile
-// (summed in LDS), further slices go through partials kept below ~2 MB.  direct: the output cannot take partials.
-// critical: the result is consumed by the next launch (NT forward, NN input gradient), so the fold of a cross-workgroup split
-// sits on the critical path (~6.5 us of launch + kernel): split only when one workgroup per tile would take longer than that
-// saves (a wave issues a 16-step chunk in ~0.85 us).  The weight-gradient op's fold is batched and deferred: it always splits.
-Plan make_plan(int64_t I, int64_t J, int64_t R, bool direct, bool critical) {
-  Plan pl;
-  pl.tiles_i = (int)adnm_cdiv(I, 64);
-  pl.tiles_j = (int)adnm_cdiv(J, 64);
+
+void finish(Plan& pl, int64_t I, int64_t J, int64_t R) {
+  pl.tiles_i = (int)adnm_cdiv(I, 16 * pl.tm);
+  pl.tiles_j = (int)adnm_cdiv(J, 16 * pl.tn);
   pl.ntiles = pl.tiles_i * pl.tiles_j;
-  pl.nchunks = (int)adnm_cdiv(R, 16);
+  pl.nchunks = (int)adnm_cdiv(R, 16 * pl.kc);
+}
+void slice(Plan& pl) {   // chunks per wave for (wpt, nbs), and the slice count that is really needed for it
+  if (pl.nbs < 1) pl.nbs = 1;
+  pl.cpw = (int)adnm_cdiv(pl.nchunks, pl.nbs * pl.wpt);
+  pl.nbs = (int)adnm_cdiv(adnm_cdiv(pl.nchunks, pl.cpw), pl.wpt);
+}
+
+// Weight-gradient op (TN): 64 x 64 tiles, ~2048 waves when the reduction is long enough (>= 1 chunk = 64 MFMAs per wave): up to 8 waves
+// of a block share a tile (summed in LDS), further slices go through partials kept below ~2 MB and the shared fold kernel, whose launch
+// is batched with the other parameter-gradient folds and deferred off the critical path.  direct: the output cannot take partials.
+Plan plan_deferred(int64_t I, int64_t J, int64_t R, bool direct) {
+  Plan pl;
+  pl.kernel = KERNEL_STREAM, pl.combine = false, pl.tm = pl.tn = 4, pl.kc = 1;
+  finish(pl, I, J, R);
   int want = (int)adnm_cdiv(2048, pl.ntiles);
   if (want > pl.nchunks) want = pl.nchunks;
   if (want < 1) want = 1;
@@ -241,13 +344,135 @@ Plan make_plan(int64_t I, int64_t J, int64_t R, bool direct, bool critical) {
   int64_t nbs = adnm_cdiv(want, pl.wpt);
   const int64_t by_mem = (int64_t)(2 << 20) / (I * J * 4);
   if (nbs > by_mem) nbs = by_mem;
-  if (critical && 0.85 * pl.nchunks / pl.wpt <= 13.0) nbs = 1;
   if (nbs < 1 || direct) nbs = 1;
-  pl.cpw = (int)adnm_cdiv(pl.nchunks, nbs * pl.wpt);
-  pl.nbs = (int)adnm_cdiv(adnm_cdiv(pl.nchunks, pl.cpw), pl.wpt);
+  pl.nbs = (int)nbs;
+  slice(pl);
   return pl;
 }
 
+// measurement aid (tools/kbench_gemm.py sweeps it): ADNM_SK_FORCE="kernel,tm,tn,kc,wpt,nbs" overrides the NT / NN plan
+struct Forced {
+  bool on = false;
+  int v[6] = {0, 0, 0, 0, 0, 0};
+  Forced() {
+    const char* e = getenv("ADNM_SK_FORCE");
+    on = e && sscanf(e, "%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6;
+  }
+};
+const Forced& forced() {
+  static const Forced f;
+  return f;
+}
+int use_table() {   // measurement aid: ADNM_SK_TABLE=0 plans every shape by the rules (what shapes outside the table get)
+  static const int v = [] {
+    const char* e = getenv("ADNM_SK_TABLE");
+    return e && e[0] == '0' ? 0 : 1;
+  }();
+  return v;
+}
+bool config_ok(int op, const Plan& pl) {
+  if (pl.kernel == KERNEL_LDS) return op != ADNM_SKGEMM_TN;
+  if (pl.kernel != KERNEL_STREAM || pl.wpt < 1 || pl.wpt > kWaves || (pl.wpt & (pl.wpt - 1))) return false;
+  const int tm = pl.tm, tn = pl.tn, kc = pl.kc;
+  if (op == ADNM_SKGEMM_NT) return (tm == 1 && tn == 1 && kc == 4) || (tm == 2 && tn == 2 && kc == 2) || (tm == 4 && tn == 4 && kc == 1);
+  if (op == ADNM_SKGEMM_NN) return tn == 4 && ((tm == 1 && kc == 2) || (tm == 2 && kc == 2) || (tm == 4 && kc == 1));
+  return tm == 4 && tn == 4 && kc == 1;
+}
+
+// Forward / input-gradient ops (NT, NN): the result is consumed by the next launch, so the whole chip should work on it and no second
+// launch should stand between.  The shapes of BASELINE config 2 take the configuration that measured fastest on an MI355X
+// (skgemm_tuned.inc, made by tools/tune_gemm.py from tools/kbench_gemm.py sweeps); every other shape follows the rules below, which
+// summarise that table:
+//   NT: the LDS-tiled kernel when there are >= 128 tiles of 64 x 64 or the reduction is <= 128 steps; with a reduction >= 1024 steps
+//       and fewer tiles, the LDS-tiled kernel split ~192 / tiles ways (combined in the launch); otherwise the streaming kernel with the
+//       largest of the 32 x 32 / 16 x 16 wave tiles that still gives >= 128 tiles, 8 waves per tile.
+//   NN: the LDS-tiled kernel for >= 256 tiles or a reduction <= 128 steps; otherwise the streaming kernel, 16 (32 for >= 100 tiles of
+//       >= 256 rows) x 64 wave tiles, 8 waves per tile.
+struct Tuned {
+  int op, I, J, R, bf16;
+  int cfg[6];   // kernel, tm, tn, kc, wpt, nbs
+};
+const Tuned kTuned[] = {
+#include "skgemm_tuned.inc"
+};
+const Tuned* tuned(int op, int64_t I, int64_t J, int64_t R, bool bf16) {
+  for (const Tuned& t : kTuned)
+    if (t.op == op && t.I == I && t.J == J && t.R == R && t.bf16 == (int)bf16) return &t;
+  return nullptr;
+}
+Plan plan_critical(int op, int64_t I, int64_t J, int64_t R, bool can_split, bool bf16) {
+  Plan pl;
+  pl.combine = false;
+  const bool force = forced().on;
+  const Tuned* tu = force || use_table() == 0 ? nullptr : tuned(op, I, J, R, bf16);
+  if (force || tu) {
+    const int* v = force ? forced().v : tu->cfg;
+    pl.kernel = v[0], pl.tm = v[1], pl.tn = v[2], pl.kc = v[3], pl.wpt = v[4], pl.nbs = v[5];
+    if (!config_ok(op, pl)) pl.kernel = -1;
+  } else {
+    const int64_t t64 = adnm_cdiv(I, 64) * adnm_cdiv(J, 64);
+    pl.nbs = 1, pl.wpt = kWaves;
+    if (op == ADNM_SKGEMM_NT) {
+      pl.kernel = (t64 >= 128 || R <= 128 || (R >= 1024 && t64 >= 8)) ? KERNEL_LDS : KERNEL_STREAM;
+      if (pl.kernel == KERNEL_LDS && R >= 1024 && t64 <= 128) {
+        int want = (int)(192 / t64);
+        while (pl.nbs * 2 <= want && pl.nbs < 8) pl.nbs *= 2;
+      }
+      pl.tm = pl.tn = 2, pl.kc = 2;
+      if (adnm_cdiv(I, 32) * adnm_cdiv(J, 32) < 128) pl.tm = pl.tn = 1, pl.kc = 4;
+    } else {
+      pl.kernel = (t64 >= 256 || R <= 128) ? KERNEL_LDS : KERNEL_STREAM;
+      pl.tn = 4, pl.kc = 2, pl.tm = (I >= 256 && t64 >= 100) ? 2 : 1;
+    }
+  }
+  if (pl.kernel != KERNEL_STREAM) {
+    if (!can_split || pl.nbs < 1) pl.nbs = 1;
+    return pl;
+  }
+  finish(pl, I, J, R);
+  while (pl.wpt > 1 && pl.wpt > pl.nchunks) pl.wpt >>= 1;
+  if (!can_split || pl.wpt != kWaves) pl.nbs = 1;
+  if (pl.nbs > 32) pl.nbs = 32;
+  slice(pl);
+  pl.combine = pl.nbs > 1;
+  return pl;
+}
+Plan make_plan(int op, int64_t I, int64_t J, int64_t R, bool direct, bool bf16) {
+  return op == ADNM_SKGEMM_TN ? plan_deferred(I, J, R, direct) : plan_critical(op, I, J, R, !direct && J % 4 == 0, bf16);
+}
+
+// Arrival counters of the in-launch combine: a per-device ring of zero-initialised ints owned by the library (allocated on the first
+// split launch of a device, which therefore must not happen under stream capture: every caller here runs eager steps first).  A
+// launch takes the next `ntiles` counters; the workgroup that draws a tile's last ticket puts the counter back to zero, so a slot is
+// clean again when its launch retires, long before the ring (1 M counters) comes round.  A captured launch keeps its slots for every
+// replay, which is safe for the same reason: replays of one graph are ordered on their stream.
+constexpr int kTicketInts = 1 << 20, kMaxDevices = 64;
+struct TicketRing {
+  int* base = nullptr;
+  int next = 0;
+};
+std::mutex ticket_mutex;
+TicketRing ticket_rings[kMaxDevices];
+}  // namespace
+
+int* adnm_take_tickets(int n, hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || n > kTicketInts) return nullptr;
+  std::lock_guard<std::mutex> lock(ticket_mutex);
+  TicketRing& r = ticket_rings[dev];
+  if (!r.base) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    if (hipMalloc((void**)&r.base, sizeof(int) * kTicketInts) != hipSuccess) return r.base = nullptr;
+    if (hipMemset(r.base, 0, sizeof(int) * kTicketInts) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+  }
+  if (r.next + n > kTicketInts) r.next = 0;
+  int* t = r.base + r.next;
+  r.next += n;
+  return t;
+}
+
+namespace {
 int shape_ok(int op, int64_t M, int64_t N, int64_t K) {
   if (M < 1 || N < 4 || K < 4 || M > 65536 || N > 16384 || K > 16384) return 0;
   if (op == ADNM_SKGEMM_NT) return K % 4 == 0;
@@ -260,16 +485,31 @@ void dims(int op, int64_t M, int64_t N, int64_t K, int64_t* I, int64_t* J, int64
   else if (op == ADNM_SKGEMM_NN) *I = M, *J = K, *R = N;
   else *I = N, *J = K, *R = M;
 }
+
+template <bool A_RC, bool B_RC, int TM, int TN, int KC>
+void launch(bool bf16, unsigned grid, hipStream_t st, const SkArgs& p) {
+  if (bf16) skgemm_kernel<A_RC, B_RC, true, TM, TN, KC><<<grid, kBlock, 0, st>>>(p);
+  else skgemm_kernel<A_RC, B_RC, false, TM, TN, KC><<<grid, kBlock, 0, st>>>(p);
+}
 }  // namespace
 
 extern "C" int adnm_skgemm_supported(int op, int64_t M, int64_t N, int64_t K) { return shape_ok(op, M, N, K); }
 
+namespace {
+int64_t ws_need(const Plan& pl, int64_t I, int64_t J, int64_t R) {
+  if (pl.kernel == KERNEL_LDS) return adnm_lgemm_ws_bytes(I, J, R, pl.nbs);
+  if (pl.kernel < 0) return 16;
+  return pl.nbs > 1 ? (int64_t)pl.nbs * (I * J + I) * (int64_t)sizeof(float) : 16;
+}
+}  // namespace
+
+// enough for either precision (the tuned configuration of a shape may differ between them)
 extern "C" int64_t adnm_skgemm_ws_bytes(int op, int64_t M, int64_t N, int64_t K) {
   if (!shape_ok(op, M, N, K)) return -1;
   int64_t I, J, R;
   dims(op, M, N, K, &I, &J, &R);
-  const Plan pl = make_plan(I, J, R, false, op != ADNM_SKGEMM_TN);
-  return pl.nbs > 1 ? (int64_t)pl.nbs * (I * J + I) * (int64_t)sizeof(float) : 16;
+  const int64_t a = ws_need(make_plan(op, I, J, R, false, false), I, J, R), b = ws_need(make_plan(op, I, J, R, false, true), I, J, R);
+  return a > b ? a : b;
 }
 
 extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, float* dbias,
@@ -283,13 +523,26 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   ADNM_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= (op == ADNM_SKGEMM_NT ? K : N) && ldb >= K, "skgemm: bad operand row strides");
   ADNM_REQUIRE(!(bias && op != ADNM_SKGEMM_NT) && !(dbias && op != ADNM_SKGEMM_TN), "skgemm: bias only with NT, dbias only with TN");
   ADNM_REQUIRE(((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) % 16 == 0, "skgemm: operands must be 16-byte aligned");
-  const Plan pl = make_plan(I, J, R, ldc != J, op != ADNM_SKGEMM_TN);   // a strided output (column slice of a wider buffer) takes no partials
+  hipStream_t st = (hipStream_t)stream;
+  const bool bf = prec == ADNM_MFMA_BF16;
+  Plan pl = make_plan(op, I, J, R, false, bf);
+  // the deferred fold writes whole contiguous rows: a strided output (column slice of a wider buffer) takes no partials there
+  if (op == ADNM_SKGEMM_TN && ldc != J) pl = make_plan(op, I, J, R, true, bf);
+  ADNM_REQUIRE(pl.kernel >= 0, "skgemm: ADNM_SK_FORCE names a configuration this op has no kernel for");
+  const char* scope = op == ADNM_SKGEMM_NT ? "skgemm_nt" : (op == ADNM_SKGEMM_NN ? "skgemm_nn" : "skgemm_tn");
+  const double algo_bytes = 4.0 * ((double)M * (K + N) + (double)N * K);
+  if (pl.kernel == KERNEL_LDS) {
+    ADNM_PROF(scope, st, algo_bytes);
+    const int rc = adnm_lgemm_launch(op == ADNM_SKGEMM_NN, a, lda, b, ldb, bias, c, ldc, ws, ws_bytes, I, J, R, pl.nbs, prec, st);
+    if (rc != ADNM_OK) return rc;
+    ADNM_CHECK_LAUNCH("skgemm");
+    return ADNM_OK;
+  }
   const bool split = pl.nbs > 1;
-  if (split && (!ws || ws_bytes < adnm_skgemm_ws_bytes(op, M, N, K))) {
-    adnm_set_error("skgemm: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_skgemm_ws_bytes(op, M, N, K));
+  if (split && (!ws || ws_bytes < ws_need(pl, I, J, R))) {
+    adnm_set_error("skgemm: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)ws_need(pl, I, J, R));
     return ADNM_EWORKSPACE;
   }
-  hipStream_t st = (hipStream_t)stream;
   SkArgs p;
   p.A = a, p.B = b, p.bias = bias;
   if (op == ADNM_SKGEMM_NT) p.sa_i = lda, p.sa_r = 1, p.sb_r = 1, p.sb_j = ldb;
@@ -304,21 +557,28 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   p.slice_stride = split ? rowlen : 0;
   p.bsum = dbias ? (split ? part + I * J : dbias) : nullptr;
   p.bsum_stride = split ? rowlen : 0;
+  p.tickets = nullptr, p.out = c, p.ldo = ldc;
+  if (pl.combine) {
+    p.tickets = adnm_take_tickets(pl.ntiles, st);
+    ADNM_REQUIRE(p.tickets, "skgemm: no arrival counters (first split launch of a device under stream capture, or hipMalloc failed)");
+  }
   const unsigned grid = (unsigned)adnm_cdiv((int64_t)pl.ntiles * pl.nbs, kWaves / pl.wpt);
   {
-    ADNM_PROF(op == ADNM_SKGEMM_NT ? "skgemm_nt" : (op == ADNM_SKGEMM_NN ? "skgemm_nn" : "skgemm_tn"), st, 4.0 * ((double)M * (K + N) + (double)N * K));
-    if (prec == ADNM_MFMA_BF16) {
-      if (op == ADNM_SKGEMM_NT) skgemm_kernel<true, true, true><<<grid, kBlock, 0, st>>>(p);
-      else if (op == ADNM_SKGEMM_NN) skgemm_kernel<true, false, true><<<grid, kBlock, 0, st>>>(p);
-      else skgemm_kernel<false, false, true><<<grid, kBlock, 0, st>>>(p);
+    ADNM_PROF(scope, st, algo_bytes);
+    if (op == ADNM_SKGEMM_NT) {
+      if (pl.tm == 1) launch<true, true, 1, 1, 4>(bf, grid, st, p);
+      else if (pl.tm == 2) launch<true, true, 2, 2, 2>(bf, grid, st, p);
+      else launch<true, true, 4, 4, 1>(bf, grid, st, p);
+    } else if (op == ADNM_SKGEMM_NN) {
+      if (pl.tm == 1) launch<true, false, 1, 4, 2>(bf, grid, st, p);
+      else if (pl.tm == 2) launch<true, false, 2, 4, 2>(bf, grid, st, p);
+      else launch<true, false, 4, 4, 1>(bf, grid, st, p);
     } else {
-      if (op == ADNM_SKGEMM_NT) skgemm_kernel<true, true, false><<<grid, kBlock, 0, st>>>(p);
-      else if (op == ADNM_SKGEMM_NN) skgemm_kernel<true, false, false><<<grid, kBlock, 0, st>>>(p);
-      else skgemm_kernel<false, false, false><<<grid, kBlock, 0, st>>>(p);
+      launch<false, false, 4, 4, 1>(bf, grid, st, p);
     }
   }
   ADNM_CHECK_LAUNCH("skgemm");
-  if (split) {
+  if (split && !pl.combine) {
     adnm_launch_fold("skgemm_fold", part, pl.nbs, (int)rowlen, {c, (int)(I * J)}, {dbias, dbias ? (int)I : 0}, {nullptr, 0}, {nullptr, 0}, st);
     ADNM_CHECK_LAUNCH("skgemm_fold");
   }

@@ -133,7 +133,7 @@ def csrc_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "adnm-unet_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
+        if f.endswith((".hip", ".h", ".inc")):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
@@ -329,9 +329,19 @@ def main():
             ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             tr = None
             if pmc:
-                got = [pmc["kernels"].get(n) for n in names if n in agg]
-                if got and all(g is not None for g in got):
-                    tr = sum(g["hbm_bytes_per_step"] for g in got)
+                # a PMC row is keyed by profiler scope, or by "a|b|c" when one kernel symbol serves several scopes (conv3 fwd/dgrad, the
+                # shared fold kernel): such a row counts only when ALL of its scopes are asked for together
+                left, tr = {n for n in names if n in agg}, 0.0
+                for key, row in pmc["kernels"].items():
+                    members = set(key.split("|"))
+                    if members & left:
+                        if not members <= set(names):
+                            tr = None
+                            break
+                        tr += row["hbm_bytes_per_step"]
+                        left -= members
+                if left:
+                    tr = None
             return {"launches_per_step": round(ln, 1), "ms_per_step": round(ms, 4), "algorithmic_MB_per_step": round(by / 1e6, 2),
                     "GBps": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "traffic_MB_per_step": None if tr is None else round(tr / 1e6, 2),
                     "traffic_over_algorithmic": None if tr is None or by <= 0 else round(tr / by, 3)}

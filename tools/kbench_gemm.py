@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Short-GEMM micro-benchmark: tools/kbench_gemm.py  [op M N K]...   (op in NT NN TN; default: the deep-level shapes of config 2).
-Back-to-back launches of adnm_skgemm in both MFMA precisions and of the library GEMM; run under rocprofv3 --kernel-trace for true
-kernel durations (tools/kstat1.py)."""
+Each (shape, precision) is captured as a hipGraph of REPS back-to-back launches of adnm_skgemm and replayed: device-side time per
+launch without host overhead (as inside the trainer's graph).  The library GEMM is timed the same way for comparison, and every
+result is checked against it (fp32: rel-L2 <= 2e-6; bf16 operands: <= 1e-2)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "adnm-unet_amd"))
@@ -10,46 +11,96 @@ from adnm_hip import ops, lib
 
 dev = "cuda"
 args = sys.argv[1:]
-shapes = [(args[i], int(args[i + 1]), int(args[i + 2]), int(args[i + 3])) for i in range(0, len(args), 4)] or [
-    ("NT", 256, 1024, 512), ("NN", 256, 1024, 512), ("TN", 256, 1024, 512),
-    ("NT", 64, 4672, 1024), ("NN", 64, 4672, 1024), ("TN", 64, 4672, 1024),
-    ("NT", 1024, 512, 2048), ("NN", 1024, 512, 2048), ("TN", 1024, 512, 2048),
-    ("NT", 1024, 2368, 512), ("NT", 64, 512, 2048), ("NT", 4096, 256, 512),
+# environment: SHAPES=<file of "op M N K [count]" lines>  OUT=<json>  NOLIB=1 (skip the library GEMM timing)  PRECS=f32,bf16
+file_shapes = []
+if os.environ.get("SHAPES"):
+    for ln in open(os.environ["SHAPES"]):
+        f = ln.split()
+        if len(f) >= 4 and (not os.environ.get("OPS") or f[0] in os.environ["OPS"].split(",")):
+            file_shapes.append((f[0], int(f[1]), int(f[2]), int(f[3])))
+precs = os.environ.get("PRECS", "f32,bf16").split(",")
+nolib = os.environ.get("NOLIB") == "1"
+shapes = file_shapes or [(args[i], int(args[i + 1]), int(args[i + 2]), int(args[i + 3])) for i in range(0, len(args), 4)] or [
+    ("NT", 4, 1024, 2144), ("NN", 4, 1024, 2144),
+    ("NT", 64, 512, 2048), ("NT", 64, 1024, 2048), ("NN", 64, 1024, 2048), ("TN", 64, 1024, 2048),
+    ("NT", 64, 4096, 1024), ("NN", 64, 4096, 1024), ("NT", 64, 4672, 1024), ("NN", 64, 4672, 1024), ("TN", 64, 4672, 1024),
+    ("NT", 256, 512, 1024), ("NN", 256, 512, 1024), ("NT", 256, 1024, 4096), ("NN", 256, 1024, 4096), ("TN", 256, 1024, 4096),
+    ("NT", 256, 4672, 1024), ("NN", 256, 4672, 1024),
+    ("NT", 1024, 128, 256), ("NN", 1024, 256, 128), ("NT", 1024, 512, 2048), ("NN", 1024, 512, 2048), ("TN", 1024, 512, 2048),
+    ("NT", 1024, 2368, 512), ("NN", 1024, 2368, 512), ("TN", 1024, 2368, 512),
 ]
 OPC = {"NT": ops.SK_NT, "NN": ops.SK_NN, "TN": ops.SK_TN}
-reps = int(os.environ.get("REPS", "30"))
+reps = int(os.environ.get("REPS", "20"))
 
 
-def timeit(fn):
-    for _ in range(3):
+def graph_time(fn):
+    fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
         fn()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(reps):
+                fn()
+    torch.cuda.current_stream().wait_stream(s)
+    g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    e1.synchronize()
-    return 1e3 * e0.elapsed_time(e1) / reps
+    best = 1e9
+    for _ in range(3):
+        e0.record()
+        g.replay()
+        e1.record()
+        e1.synchronize()
+        best = min(best, 1e3 * e0.elapsed_time(e1) / reps)
+    return best
 
 
+tot = {pr: 0.0 for pr in precs}
+tot["lib"] = 0.0
+bad = 0
+rows = []
 for op, M, N, K in shapes:
-    g = lambda *s: torch.randn(*s, device=dev)
+    gen = lambda *s: torch.randn(*s, device=dev)
     if op == "NT":
-        a, b, c = g(M, K), g(N, K), torch.empty(M, N, device=dev)
+        a, b, c = gen(M, K), gen(N, K), torch.empty(M, N, device=dev)
         libf = lambda: torch.mm(a, b.t())
     elif op == "NN":
-        a, b, c = g(M, N), g(N, K), torch.empty(M, K, device=dev)
+        a, b, c = gen(M, N), gen(N, K), torch.empty(M, K, device=dev)
         libf = lambda: torch.mm(a, b)
     else:
-        a, b, c = g(M, N), g(M, K), torch.empty(N, K, device=dev)
+        a, b, c = gen(M, N), gen(M, K), torch.empty(N, K, device=dev)
         libf = lambda: torch.mm(a.t(), b)
-    res = []
-    for prec in ("f32", "bf16"):
+    ref = libf().double()
+    row = {"op": op, "M": M, "N": N, "K": K}
+    txt = []
+    for prec in precs:
         ops.set_mfma_precision(prec)
-        res.append(timeit(lambda: ops._skgemm(OPC[op], a, b, None, c, None, M, N, K)))
+        c.fill_(float("nan"))
+        try:
+            t = graph_time(lambda: ops._skgemm(OPC[op], a, b, None, c, None, M, N, K))
+        except RuntimeError as e:   # a forced configuration this op has no kernel for
+            txt.append(f"sk {prec:4s}    n/a")
+            continue
+        err = ((c.double() - ref).norm() / ref.norm()).item()
+        ok = err <= (2e-6 if prec == "f32" else 1e-2)
+        bad += 0 if ok else 1
+        row[prec] = t if ok else None
+        tot[prec] += t
+        txt.append(f"sk {prec:4s} {t:6.1f} us (err {err:.1e}{'' if ok else ' BAD'})")
     ops.set_mfma_precision("f32")
-    t_lib = timeit(libf)
+    if not nolib:
+        row["lib"] = graph_time(libf)
+        tot["lib"] += row["lib"]
+        txt.append(f"rocBLAS {row['lib']:6.1f} us")
+    rows.append(row)
     flops = 2.0 * M * N * K
     byts = 4.0 * (M * K + N * K + M * N)
-    print(f"{op} M={M:5d} N={N:5d} K={K:5d}: sk f32 {res[0]:7.1f} us  sk bf16 {res[1]:7.1f} us  rocBLAS {t_lib:7.1f} us   | ideal f32-MFMA {flops / 157e6:6.1f} us, HBM {byts / 6.3e6:5.1f} us")
+    print(f"{op} M={M:5d} N={N:5d} K={K:5d}: " + "  ".join(txt) + f" | ideal f32-MFMA {flops / 157e6:5.1f} us, HBM {byts / 6.3e6:4.1f} us", flush=True)
+print("sum: " + ", ".join(f"{k} {v:.1f} us" for k, v in tot.items()) + f"; {bad} results out of tolerance")
+if os.environ.get("OUT"):
+    import json
+    json.dump({"force": os.environ.get("ADNM_SK_FORCE"), "rows": rows}, open(os.environ["OUT"], "w"))
+sys.exit(1 if bad else 0)
