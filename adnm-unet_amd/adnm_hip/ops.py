@@ -1056,7 +1056,7 @@ def k_linear_dx(dy2, w, out=None):
     return dx
 
 
-def colsum(t, out=None):
+def colsum(t, out=None, defer=False):
     """sum over the rows of a contiguous 2-D fp32 matrix (a bias gradient) with the deterministic fold kernel."""
     _need_gpu(t)
     if not (t.dtype == torch.float32 and t.dim() == 2):
@@ -1064,7 +1064,10 @@ def colsum(t, out=None):
     t = t if t.is_contiguous() else t.contiguous()
     if out is None:
         out = torch.empty(t.shape[1], dtype=torch.float32, device=t.device)
-    lib.call("adnm_colsum", t.data_ptr(), out.data_ptr(), t.shape[0], t.shape[1], _stream())
+    nb = lib.query("adnm_colsum_ws_bytes", t.shape[0], t.shape[1])
+    ws = _ws(nb, t.device)
+    with FOLDS.defer(t.device, ws, t) if defer else _NODEFER:
+        lib.call("adnm_colsum", t.data_ptr(), out.data_ptr(), t.shape[0], t.shape[1], ws.data_ptr(), nb, _stream())
     return out
 
 
@@ -1306,8 +1309,7 @@ class ConvT2xFn(torch.autograd.Function):
         db = None
         if has_bias:
             db = grad_dst(b_ptr, (Cout,), dev)
-            with FOLDS.defer(dev, dy2):
-                colsum(dy2, out=db)
+            colsum(dy2, out=db, defer=True)
         return dx, g, db, None, None
 
 

@@ -17,7 +17,7 @@ void adnm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* adnm_last_error(void) { return g_err; }
-extern "C" int adnm_abi_version(void) { return 3; }   // 3: fused LayerNorm epilogue arguments of ssd_reduce_fwd, cast_* entry points
+extern "C" int adnm_abi_version(void) { return 4; }   // 4: adnm_colsum takes a workspace (two-stage sums of tall matrices)
 
 // ---- profiler: OFF by default (one relaxed atomic load per launch).  When bench.py enables it, every kernel
 // launch of the library is bracketed by hipEventRecord on the stream it is launched on; adnm_prof_collect()
@@ -95,7 +95,11 @@ extern "C" int64_t adnm_prof_collect(char* buf, int64_t buflen) {
 // gradients of a backward pass are not read before the optimiser, so their ~200 second-stage launches per step collapse
 // into a few.  The arithmetic per descriptor (slice / unroll order) is identical either way: results do not depend on batching.
 namespace {
-constexpr int kFoldCols = 64, kFoldSlices = 16, kMaxFolds = 16;
+// A workgroup of 1024 threads folds `cols` columns with 1024 / cols row slices: 64 x 16 by default; partial sets with many rows and
+// few columns (per-channel scalars, bias sums: 1024 x 4, 1024 x 131 ...) would leave one or two workgroups walking hundreds of rows
+// each, so they take 16 x 64 or 4 x 256.  The geometry is a function of (rows, n) only: a set is summed in the same order whether it
+// is folded at once or from the queue.
+constexpr int kFoldThreads = 1024, kMaxFolds = 16;
 struct FoldSegs {
   float* ptr[4];
   int end[4];
@@ -103,6 +107,7 @@ struct FoldSegs {
 struct FoldDesc {
   const float* part;
   int rows, n;
+  int lc;   // log2(columns per workgroup): 6, 4 or 2
   FoldSegs segs;
 };
 struct MultiFold {
@@ -110,41 +115,49 @@ struct MultiFold {
   int blk_end[kMaxFolds];   // exclusive prefix of column-block counts
   FoldDesc d[kMaxFolds];
 };
-__global__ __launch_bounds__(kFoldCols* kFoldSlices) void fold_rows_kernel(MultiFold mf_by_value) {
-  __shared__ float sm[kFoldSlices][kFoldCols + 1];
-  // The descriptor table is indexed with a run-time (workgroup-uniform) k.  Indexing the by-value argument makes the compiler copy the
-  // whole 1.1 KB struct into per-thread scratch first (measured: a 3.7 MB fold took 167 us); reading it through the kernarg segment
-  // pointer keeps it in constant memory / scalar loads.  The explicit arguments of a HIP kernel start at offset 0 of that segment.
+int fold_lc(int rows, int n) {
+  if (rows >= 1024 && n <= 64) return 2;
+  if (rows >= 256 && n <= 2048) return 4;
+  return 6;
+}
+__global__ __launch_bounds__(kFoldThreads) void fold_rows_kernel(MultiFold mf_by_value) {
+  __shared__ float sm[kFoldThreads + kFoldThreads / 4];
+  // The descriptor table is indexed with a run-time (workgroup-uniform) k: read it through the kernarg segment pointer (constant
+  // memory / scalar loads).  The explicit arguments of a HIP kernel start at offset 0 of that segment.
   (void)mf_by_value;
   const __attribute__((address_space(4))) MultiFold& mf = *(const __attribute__((address_space(4))) MultiFold*)__builtin_amdgcn_kernarg_segment_ptr();
   int k = 0;
   while (k + 1 < mf.count && (int)blockIdx.x >= mf.blk_end[k]) ++k;
   const __attribute__((address_space(4))) FoldDesc& fd = mf.d[k];
   const float* __restrict__ part = fd.part;
-  const int rows = fd.rows, n = fd.n;
-  const int cl = threadIdx.x & (kFoldCols - 1), sl = threadIdx.x / kFoldCols;
-  const int c = ((int)blockIdx.x - (k ? mf.blk_end[k - 1] : 0)) * kFoldCols + cl;
+  const int rows = fd.rows, n = fd.n, lc = fd.lc;
+  const int cols = 1 << lc, slices = kFoldThreads >> lc;
+  const int cl = threadIdx.x & (cols - 1), sl = threadIdx.x >> lc;
+  const int c = (((int)blockIdx.x - (k ? mf.blk_end[k - 1] : 0)) << lc) + cl;
   float acc = 0.f;
   if (c < n) {
     // independent loads: 8 in flight per lane, two accumulators (fixed order -> still deterministic)
     float acc2 = 0.f;
     int r = sl;
-    for (; r + 7 * kFoldSlices < rows; r += 8 * kFoldSlices) {
+    for (; r + 7 * slices < rows; r += 8 * slices) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(r + u * kFoldSlices) * n + c];
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(r + u * slices) * n + c];
       acc += (v[0] + v[1]) + (v[2] + v[3]);
       acc2 += (v[4] + v[5]) + (v[6] + v[7]);
     }
-    for (; r < rows; r += kFoldSlices) acc += part[(int64_t)r * n + c];
+    for (; r < rows; r += slices) acc += part[(int64_t)r * n + c];
     acc += acc2;
   }
-  sm[sl][cl] = acc;
+  float* const mine = sm + sl * (cols + 1) + cl;
+  *mine = acc;
   __syncthreads();
+  for (int h = slices >> 1; h >= 1; h >>= 1) {   // fixed tree over the row slices
+    if (sl < h) *mine += mine[h * (cols + 1)];
+    __syncthreads();
+  }
   if (sl == 0 && c < n) {
-    float t = 0.f;
-#pragma unroll
-    for (int q = 0; q < kFoldSlices; ++q) t += sm[q][cl];
+    const float t = *mine;
     int begin = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -173,6 +186,14 @@ int fold_batch_limit() {
   return lim;
 }
 
+bool fold_debug() {
+  static const bool v = [] {
+    const char* e = getenv("ADNM_FOLD_DEBUG");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
+
 void launch_folds(const FoldDesc* d, const char* const* names, int count, hipStream_t st) {
   const int lim = fold_batch_limit();
   for (int i0 = 0; i0 < count; i0 += lim) {
@@ -183,13 +204,18 @@ void launch_folds(const FoldDesc* d, const char* const* names, int count, hipStr
     double bytes = 0;
     for (int k = 0; k < m; ++k) {
       mf.d[k] = d[i0 + k];
-      blocks += (int)adnm_cdiv(d[i0 + k].n, kFoldCols);
+      blocks += (int)adnm_cdiv(d[i0 + k].n, 1 << d[i0 + k].lc);
       mf.blk_end[k] = blocks;
       bytes += 4.0 * ((double)d[i0 + k].rows + 1) * d[i0 + k].n;
     }
     for (int k = m; k < kMaxFolds; ++k) mf.blk_end[k] = blocks;
+    if (fold_debug()) {   // measurement aid: ADNM_FOLD_DEBUG=1 lists every fold launch (name: partial rows x columns)
+      fprintf(stderr, "[adnm fold] %d blocks:", blocks);
+      for (int k = 0; k < m; ++k) fprintf(stderr, " %s:%dx%d", names[i0 + k], d[i0 + k].rows, d[i0 + k].n);
+      fprintf(stderr, "\n");
+    }
     ADNM_PROF(m == 1 ? names[i0] : "fold_batch", st, bytes);
-    fold_rows_kernel<<<(unsigned)blocks, kFoldCols * kFoldSlices, 0, st>>>(mf);
+    fold_rows_kernel<<<(unsigned)blocks, kFoldThreads, 0, st>>>(mf);
   }
 }
 }  // namespace
@@ -197,7 +223,7 @@ void launch_folds(const FoldDesc* d, const char* const* names, int count, hipStr
 void adnm_launch_fold(const char* prof_name, const float* part, int rows, int n, AdnmFoldSeg s0, AdnmFoldSeg s1, AdnmFoldSeg s2,
                       AdnmFoldSeg s3, hipStream_t st) {
   FoldDesc fd;
-  fd.part = part, fd.rows = rows, fd.n = n;
+  fd.part = part, fd.rows = rows, fd.n = n, fd.lc = fold_lc(rows, n);
   const AdnmFoldSeg in[4] = {s0, s1, s2, s3};
   int end = 0;
   for (int k = 0; k < 4; ++k) {
@@ -235,12 +261,66 @@ extern "C" int adnm_foldq_flush(void* q, adnm_stream_t stream) {
   return ADNM_OK;
 }
 
-// Column sums of a contiguous (rows, n) fp32 matrix with the deterministic fold kernel: the bias gradient of a Linear whose
-// weight gradient went to the library GEMM (torch's own sum(0) costs 7-11 us on these 64 .. 1024-row matrices).
-extern "C" int adnm_colsum(const float* x, float* out, int64_t rows, int64_t n, adnm_stream_t stream) {
+// Column sums of a contiguous (rows, n) fp32 matrix — a bias gradient whose weight gradient is computed elsewhere (the transposed
+// conv's, ops.ConvT2xFn).  Tall matrices (65 536 x 32 at config 2) first go through colsum_partial_kernel: each workgroup adds a
+// contiguous band of rows (lanes along the columns, 256 / ncol row lanes, LDS tree), then the shared fold adds the bands.
+namespace {
+constexpr int kColsumThreads = 256, kColsumMinRows = 2048;
+__global__ __launch_bounds__(kColsumThreads) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int rows, int n, int band) {
+  __shared__ float sm[kColsumThreads];
+  int ncol = 1;
+  while (ncol < n && ncol < kColsumThreads) ncol <<= 1;   // columns a workgroup pass covers (power of two >= n, or 256)
+  const int lanes = kColsumThreads / ncol, cl = threadIdx.x & (ncol - 1), rl = threadIdx.x / ncol;
+  const int r0 = blockIdx.x * band, r1 = r0 + band < rows ? r0 + band : rows;
+  for (int c0 = 0; c0 < n; c0 += ncol) {
+    const int c = c0 + cl;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < n) {
+      int r = r0 + rl;
+      for (; r + 3 * lanes < r1; r += 4 * lanes) {
+        const float v0 = x[(int64_t)r * n + c], v1 = x[(int64_t)(r + lanes) * n + c], v2 = x[(int64_t)(r + 2 * lanes) * n + c],
+                    v3 = x[(int64_t)(r + 3 * lanes) * n + c];
+        a0 += v0 + v1, a1 += v2 + v3;
+      }
+      for (; r < r1; r += lanes) a0 += x[(int64_t)r * n + c];
+    }
+    sm[threadIdx.x] = a0 + a1;
+    __syncthreads();
+    for (int h = lanes >> 1; h >= 1; h >>= 1) {
+      if (rl < h) sm[threadIdx.x] += sm[threadIdx.x + h * ncol];
+      __syncthreads();
+    }
+    if (rl == 0 && c < n) part[(int64_t)blockIdx.x * n + c] = sm[threadIdx.x];
+    __syncthreads();
+  }
+}
+int colsum_bands(int64_t rows) { return rows < kColsumMinRows ? 0 : (int)(rows / 256 < 256 ? rows / 256 : 256); }
+}  // namespace
+
+extern "C" int64_t adnm_colsum_ws_bytes(int64_t rows, int64_t n) {
+  const int bands = colsum_bands(rows);
+  return bands ? (int64_t)bands * n * (int64_t)sizeof(float) : 16;
+}
+extern "C" int adnm_colsum(const float* x, float* out, int64_t rows, int64_t n, void* ws, int64_t ws_bytes, adnm_stream_t stream) {
   ADNM_REQUIRE(x && out, "colsum: null pointer");
   ADNM_REQUIRE(rows > 0 && n > 0 && rows < (1ll << 31) && n < (1ll << 31), "colsum: bad shape rows=%lld n=%lld", (long long)rows, (long long)n);
-  adnm_launch_fold("colsum", x, (int)rows, (int)n, {out, (int)n}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  const int bands = colsum_bands(rows);
+  if (!bands) {
+    adnm_launch_fold("colsum", x, (int)rows, (int)n, {out, (int)n}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
+    ADNM_CHECK_LAUNCH("colsum");
+    return ADNM_OK;
+  }
+  if (!ws || ws_bytes < adnm_colsum_ws_bytes(rows, n)) {
+    adnm_set_error("colsum: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_colsum_ws_bytes(rows, n));
+    return ADNM_EWORKSPACE;
+  }
+  {
+    ADNM_PROF("colsum_partial", st, 4.0 * (double)rows * n);
+    colsum_partial_kernel<<<bands, kColsumThreads, 0, st>>>(x, (float*)ws, (int)rows, (int)n, (int)adnm_cdiv(rows, bands));
+  }
+  ADNM_CHECK_LAUNCH("colsum_partial");
+  adnm_launch_fold("colsum", (const float*)ws, bands, (int)n, {out, (int)n}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
   ADNM_CHECK_LAUNCH("colsum");
   return ADNM_OK;
 }

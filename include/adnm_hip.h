@@ -254,8 +254,11 @@ int adnm_conv1d3_fwd(const float* x, const float* w, const float* bias, float* y
 int adnm_conv1d3_bwd(const float* dy, const float* x, const float* w, float* dx, float* dwb, int64_t B, int64_t n, adnm_stream_t stream);
 
 /* out[c] = sum_r x[r*n + c] for a contiguous (rows, n) fp32 matrix — nn.Linear's bias gradient (autograd's sum over the token
- * rows) when the weight gradient itself is a library GEMM.  Deterministic (fixed tree), OVERWRITES out. */
-int adnm_colsum(const float* x, float* out, int64_t rows, int64_t n, adnm_stream_t stream);
+ * rows) when the weight gradient is computed elsewhere (the transposed conv's).  Deterministic (fixed tree), OVERWRITES out; matrices
+ * of >= 2048 rows are summed in two stages through `ws` (adnm_colsum_ws_bytes), which must stay alive until a bound fold queue is
+ * flushed. */
+int64_t adnm_colsum_ws_bytes(int64_t rows, int64_t n);
+int adnm_colsum(const float* x, float* out, int64_t rows, int64_t n, void* ws, int64_t ws_bytes, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- short GEMMs of the deep stages (K6b, MFMA)
  * nn.Linear with M <= 65536 token rows and up to 16384 features: Mamba2.in_proj/out_proj (ADNssd.py:309,461),

@@ -503,6 +503,12 @@ def test_rownorm_tap(mean):
     (300, 20, 64, False),       # ragged reduction (K = 20: a chunk of 16 and a quad) forward, ragged N in the input gradient
     (128, 40, 24, True),
     (4096, 128, 544, False),
+    (64, 4096, 1024, True),     # long reduction, few tiles: the LDS-tiled kernel split over workgroups, slabs combined in the launch
+    (64, 1024, 4672, False),    # 73 column tiles forward; 4672-step reduction in the input gradient
+    (256, 1024, 2048, True),
+    (1024, 512, 2368, True),    # >= 128 tiles: LDS-tiled, no split
+    (1024, 128, 256, False),    # short reduction
+    (72, 2144, 100, True),      # ragged in every direction (reduction 2144 = 67 step tiles of 32)
 ])
 def test_skgemm_linear(M, K, N, bias):
     x, w, cot = T(f"sk.x{M}{K}", (M, K)), T(f"sk.w{N}{K}", (N, K), 0.05), T(f"sk.c{M}{N}", (M, N))
@@ -697,6 +703,15 @@ def test_lincomb_scalar_mix_any_channel_count():
 
 
 # ------------------------------------------------------------------------------------------- bf16 MFMA precision (BASELINE's bf16 configs)
+@pytest.mark.parametrize("rows,n", [(65536, 32), (5000, 257), (2048, 4), (1500, 4), (1024, 131), (300, 3000), (7, 5)])
+def test_colsum(rows, n):
+    """bias-gradient column sums: two-stage above 2048 rows, the shared fold (all three workgroup geometries) below"""
+    x = T(f"cs.{rows}.{n}", (rows, n)).to(DEV)
+    out = ops.colsum(x)
+    assert_close(out, x.double().sum(0), 2e-6, "colsum")
+    assert torch.equal(out, ops.colsum(x)), "colsum must be bitwise reproducible"
+
+
 def _bf16_round(t):
     return t.to(torch.bfloat16).to(t.dtype)
 
@@ -708,7 +723,7 @@ def bf16_mfma():
     ops.set_mfma_precision("f32")
 
 
-@pytest.mark.parametrize("M,K,N", [(64, 1024, 512), (1024, 256, 1216), (300, 20, 64)])
+@pytest.mark.parametrize("M,K,N", [(64, 1024, 512), (1024, 256, 1216), (300, 20, 64), (64, 4096, 1024), (256, 1024, 2048), (1024, 512, 2368)])
 def test_skgemm_bf16_mfma(M, K, N, bf16_mfma):
     """prec = ADNM_MFMA_BF16: operands rounded to bf16 (RNE), products and sums in fp32 — i.e. EXACTLY the fp32 GEMM of the rounded
     operands (up to summation order), and within bf16 rounding (2^-9 per operand) of the unrounded one."""
