@@ -5,6 +5,7 @@ torch's caching allocator only, so a whole training step is hipGraph-capturable.
 Layout convention: token tensors are (B, L, C) / (M, C) channels-last; a "row view" is a 2-D
 tensor with stride (ld, 1) — kernels take the row stride, so column slices of wide buffers are
 passed without copies."""
+import os
 import threading
 
 import torch
@@ -983,7 +984,7 @@ def maxpool(x, H, W, kh, kw, stride):
 # Static routing, the same in every process and on every rank: the tall-skinny kernel (csrc/tsgemm.hip) takes the full-resolution
 # projections (>= 2048 token rows, weight <= 8192 elements), the short-GEMM kernel (csrc/skgemm.hip) everything else.  There is
 # no library GEMM behind these: a shape neither kernel takes raises.
-TS_MIN_ROWS = 2048
+TS_MIN_ROWS = int(os.environ.get("ADNM_TS_MIN_ROWS", "32768"))   # the environment override is a measurement aid (tools/kbench_ts.py)
 SK_NT, SK_NN, SK_TN = 0, 1, 2
 
 

@@ -75,7 +75,9 @@ class FlatTrainer:
             used = self.late + self.early
         dev, dt = used[0].device, used[0].dtype
         offs, total = [], 0
-        for p in used:
+        for i, p in enumerate(used):
+            if i == len(self.late):
+                total = (total + 7) // 8 * 8  # the stage boundary is also a bucket boundary of the bf16 wire buffer (16-byte aligned there too)
             offs.append(total)
             total += (p.numel() + 3) // 4 * 4  # keep every tensor 16-byte aligned inside the flat buffers
         self.flat_p = torch.zeros(total, dtype=dt, device=dev)

@@ -222,8 +222,14 @@ __global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const float* __restri
   }
 }
 
+int rows_per_wave(const char* name, int dflt) {   // measurement aid: ADNM_TS_NT_RPW / ADNM_TS_TN_RPW override the row blocks per wave
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  return v > 0 ? v : dflt;
+}
 int nt_blocks(int64_t M) {
-  int64_t b = adnm_cdiv(adnm_cdiv(M, 16), kWaves * 2);  // ~2 row blocks per wave, >= 4 waves per SIMD in flight
+  static const int rpw = rows_per_wave("ADNM_TS_NT_RPW", 2);
+  int64_t b = adnm_cdiv(adnm_cdiv(M, 16), kWaves * rpw);  // ~2 row blocks per wave, >= 4 waves per SIMD in flight
   if (b > 1024) b = 1024;
   return (int)(b < 1 ? 1 : b);
 }

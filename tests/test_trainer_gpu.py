@@ -135,3 +135,28 @@ def test_deferred_folds_are_bitwise_neutral():
         del tr
     assert torch.equal(flats[0][0], flats[1][0])
     assert flats[1][1] < 0.5 * flats[0][1], (flats[0][1], flats[1][1])
+
+
+def test_bf16_wire_casts_on_the_real_bucket_boundaries():
+    """The bf16 wire format of the gradient all-reduce (reduce_dtype="bf16"): the HIP cast kernels need 16-byte aligned ranges on both
+    sides, so the stage boundary of the two-stage layout must fall on a multiple of 8 elements — checked on the benchmarked model's
+    real buckets, with the round trip through the wire buffer (a single process cannot run the collective itself)."""
+    from models.ADNMUNet import create_ADNMUNet
+    from models.loss import enRainfallLoss
+    model = create_ADNMUNet(5, 20, 6, img_size=64)
+    recipe.fill_parameters(model)
+    model = model.to(DEV).train()
+    frames = recipe.radar_batch(1, 25, 64, name="wire").to(DEV)
+    x, tgt = frames[:, :5].contiguous(), frames[:, 5:].contiguous()
+    tr = FlatTrainer(model, enRainfallLoss(0.57, 0.25, gamma=0.0), max_norm=0.025, use_graph=False, overlap=True, reduce_dtype="bf16")
+    tr.prepare(x, tgt)
+    tr._run_eager(x, tgt)
+    assert len(tr.buckets) == 2 and all(lo % 8 == 0 for lo, _ in tr.buckets)
+    comm = torch.empty(tr.n, dtype=torch.bfloat16, device=DEV)
+    back = torch.empty_like(tr.flat_g)
+    for lo, hi in tr.buckets:
+        tr._cast(tr.flat_g[lo:hi], comm[lo:hi])
+        tr._cast(comm[lo:hi], back[lo:hi], 0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(comm, tr.flat_g.to(torch.bfloat16))
+    assert torch.equal(back, comm.float() * 0.5)
