@@ -168,15 +168,16 @@ class FoldRegistry:
         something else references is not adopted by autograd's AccumulateGrad but cloned on the spot, i.e. before the fold ran."""
         ent = self._q.get(device.index)
         if ent is not None and ent.pop("hold", False):
-            ent = None
+            ent = None   # (a call that is not deferred is not moved to the side stream either: SIDE.submit checks deferring())
         return _Deferred(ent, keep, self._lock)
 
     def flush(self, device):
         ent = self._q.get(device.index)
         if ent is None:
             return
-        if lib.query("adnm_foldq_pending", ent["h"]) > 0:
-            with torch.cuda.device(device):
+        with torch.cuda.device(device):
+            SIDE.join(device)   # queued folds (and whoever asked for the flush) read what weight-gradient kernels wrote on the side stream
+            if lib.query("adnm_foldq_pending", ent["h"]) > 0:
                 lib.call("adnm_foldq_flush", ent["h"], _stream())
         with self._lock:
             ent["keep"].clear()
@@ -200,6 +201,9 @@ class _Deferred:
     def __init__(self, ent, keep, lock):
         self.ent, self.keep, self.lock = (ent if ent is not None and ent["on"] else None), keep, lock
 
+    def deferring(self):
+        return self.ent is not None
+
     def __enter__(self):
         if self.ent is not None:
             lib.load().adnm_foldq_bind(self.ent["h"])
@@ -213,12 +217,108 @@ class _Deferred:
         return False
 
 
+class SideStreams:
+    """Weight-gradient kernels off the critical path.  In backward the input-gradient chain (dY -> dX -> the layer below) is one long
+    dependency chain of mostly small grids, while each layer's weight gradient (dW = dY^T X, depthwise / dense conv tap gradients) is
+    a leaf that nothing reads before the optimiser.  A trainer turns this on around its backward pass; the weight-gradient wrappers then
+    SUBMIT their library call instead of making it: calls are collected and, every `batch` of them, launched together on a second HIP
+    stream that forks from the current stream there (one event: every operand of the batch exists by then) and joins it again before
+    anything reads the results: every FOLDS.flush (the second-stage folds read the partials those kernels wrote) and the end of the
+    pass.  Under hipGraph capture the fork / join events become graph edges, i.e. parallel branches of the replayed graph; a fork costs
+    several microseconds on both streams, hence the batching.
+    Operands and workspaces are allocated on the MAIN stream before the fork and kept alive here until the join, so the caching
+    allocator cannot hand their memory to a later main-stream tensor while the side kernel still runs.  The OUTPUTS are never kept (a
+    second reference would make autograd's AccumulateGrad clone a gradient instead of adopting it — on the main stream, before the side
+    kernel ran): they are parameter gradients that stay referenced by autograd, or tap gradients consumed by a parameter-prep node
+    whose first action is FOLDS.flush.
+    Off (the default, plain autograd use): every call is made at once on the current stream."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._s = {}   # device index -> {"stream", "on", "dirty", "keep", "pending"}
+        self.batch = int(os.environ.get("ADNM_SIDE_BATCH", "16"))
+
+    def active(self, device, on=True):
+        return _SideActive(self, device, on and device.type == "cuda" and os.environ.get("ADNM_SIDE_STREAM", "1") != "0")
+
+    def _ent(self, device):
+        with self._lock:
+            ent = self._s.get(device.index)
+            if ent is None:
+                ent = self._s[device.index] = {"stream": torch.cuda.Stream(device=device), "on": False, "dirty": False, "keep": [], "pending": []}
+        return ent
+
+    def submit(self, device, keep, deferred, fn):
+        """fn() makes the library call on torch's CURRENT stream (it must read _stream() itself) inside `deferred` (a FOLDS.defer(...)
+        context, created by the caller so that a pending hold is honoured now)."""
+        ent = self._s.get(device.index)
+        if ent is None or not ent["on"] or not deferred.deferring():
+            with deferred:
+                fn()
+            return
+        with self._lock:
+            ent["pending"].append((deferred, fn))
+            ent["keep"].extend(t for t in keep if t is not None)
+            full = len(ent["pending"]) >= self.batch
+        if full:
+            self._launch(ent)
+
+    def _launch(self, ent):
+        with self._lock:
+            todo, ent["pending"] = ent["pending"], []
+        if not todo:
+            return
+        side = ent["stream"]
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(side.device))   # fork: the operands of every collected call exist on the main stream by now
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            for deferred, fn in todo:
+                with deferred:
+                    fn()
+        ent["dirty"] = True
+
+    def join(self, device):
+        """launch what is still collected, then the current stream waits for everything on the side stream"""
+        ent = self._s.get(device.index)
+        if ent is None:
+            return
+        self._launch(ent)
+        if not ent["dirty"]:
+            return
+        ev = torch.cuda.Event()
+        ev.record(ent["stream"])
+        torch.cuda.current_stream(device).wait_event(ev)
+        with self._lock:
+            ent["dirty"] = False
+            ent["keep"].clear()
+
+
+class _SideActive:
+    def __init__(self, reg, device, on):
+        self.reg, self.device, self.on = reg, device, on
+
+    def __enter__(self):
+        if self.on:
+            self.reg._ent(self.device)["on"] = True
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.reg._ent(self.device)["on"] = False
+            self.reg.join(self.device)
+        return False
+
+
 FOLDS = FoldRegistry()
 GRADS = GradRegistry()
+SIDE = SideStreams()
 grad_dst = GRADS.take
 
 
 class _NoDefer:
+    def deferring(self):
+        return False
+
     def __enter__(self):
         return False
 
@@ -343,9 +443,18 @@ def k_dwconv_bwd(dy, x, wt, bias, B, H, W, C, K, act, dx=None, want_bias=False, 
     pdy, lddy = _rows(dy)
     px, ldx = _rows(x)
     pdx, lddx = _rows(dx)
-    with FOLDS.defer(dev, ws):   # taps / bias gradients: parameters, or prep intermediates flushed at the prep node
-        lib.call("adnm_dwconv_bwd", pdy, lddy, px, ldx, _p(wt), _p(bias), _p(dpre), pdx, lddx, _p(dwt), _p(db), ws.data_ptr(),
+    if not want_w:
+        lib.call("adnm_dwconv_bwd", pdy, lddy, px, ldx, _p(wt), _p(bias), _p(dpre), pdx, lddx, None, None, ws.data_ptr(),
                  nb, B, H, W, C, K, K, act, int(chan_major), _dt(x), _stream())
+        return dx, dwt, db
+    # input gradient (and the pre-activation gradient it needs) on the current stream, the tap / bias gradients as a leaf beside it
+    lib.call("adnm_dwconv_bwd", pdy, lddy, px, ldx, _p(wt), _p(bias), _p(dpre), pdx, lddx, None, None, ws.data_ptr(),
+             nb, B, H, W, C, K, K, act, int(chan_major), _dt(x), _stream())
+    g, ldg = (dpre.data_ptr(), C) if dpre is not None else (pdy, lddy)
+    pdw, pdb, dt_ = _p(dwt), _p(db), _dt(x)
+    # taps / bias gradients: parameters, or prep intermediates flushed at the prep node
+    SIDE.submit(dev, (dy, x, dpre), FOLDS.defer(dev, ws), lambda: lib.call(
+        "adnm_dwconv_wgrad", g, ldg, px, ldx, pdw, pdb, ws.data_ptr(), nb, B, H, W, C, K, K, int(chan_major), dt_, _stream()))
     return dx, dwt, db
 
 
@@ -1007,15 +1116,21 @@ def _sk_operand(t, what):
     return t
 
 
-def _skgemm(op, a, b, bias, c, dbias, M, N, K, defer=False):
+def _skgemm(op, a, b, bias, c, dbias, M, N, K, defer=False, side=False):
     if lib.query("adnm_skgemm_supported", op, M, N, K) != 1:
         raise RuntimeError(f"adnm_hip linear: no kernel takes op={('NT', 'NN', 'TN')[op]} M={M} N={N} K={K} "
                            "(every op needs N % 4 == 0 and K % 4 == 0)")
     nb = lib.query("adnm_skgemm_ws_bytes", op, M, N, K)
     ws = _ws(nb, a.device)
-    with FOLDS.defer(a.device, ws) if defer else _NODEFER:   # only the weight-gradient op (TN) may wait for its split-K fold
-        lib.call("adnm_skgemm", op, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _p(bias), c.data_ptr(), c.stride(0), _p(dbias),
-                 ws.data_ptr(), nb, M, N, K, MFMA_PREC[0], _stream())
+    # only the weight-gradient op (TN) may wait for its split-K fold, and only it leaves the critical path for the side stream
+    pc, ldc, pdb, prec = c.data_ptr(), c.stride(0), _p(dbias), MFMA_PREC[0]   # (the outputs are not captured: see SideStreams)
+    call = lambda: lib.call("adnm_skgemm", op, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _p(bias), pc, ldc, pdb,
+                            ws.data_ptr(), nb, M, N, K, prec, _stream())
+    if side:
+        SIDE.submit(a.device, (a, b), FOLDS.defer(a.device, ws) if defer else _NODEFER, call)
+    else:
+        with FOLDS.defer(a.device, ws) if defer else _NODEFER:
+            call()
 
 
 def _out_view_ok(out):
@@ -1083,12 +1198,12 @@ def k_linear_dw(dy2, x2, want_bias, w_ptr=0, b_ptr=0, dw_out=None):
     if ts_ok_tn(M, N, K, x2):
         nb = lib.query("adnm_tsgemm_tn_ws_bytes", M, N, K)
         ws = _ws(nb, dev)
-        with FOLDS.defer(dev, ws):
-            lib.call("adnm_tsgemm_tn", dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), dw.data_ptr(), _p(db), ws.data_ptr(), nb, M, N, K,
-                     _stream())
+        pdw, pdb = dw.data_ptr(), _p(db)
+        SIDE.submit(dev, (dy2, x2), FOLDS.defer(dev, ws), lambda: lib.call(
+            "adnm_tsgemm_tn", dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), pdw, pdb, ws.data_ptr(), nb, M, N, K, _stream()))
         return dw, db
     dy2, x2 = _sk_operand(dy2, "output gradient"), _sk_operand(x2, "input")
-    _skgemm(SK_TN, dy2, x2, None, dw, db, M, N, K, defer=True)
+    _skgemm(SK_TN, dy2, x2, None, dw, db, M, N, K, defer=True, side=True)
     return dw, db
 
 
@@ -1253,9 +1368,10 @@ class Conv3Fn(torch.autograd.Function):
         db = grad_dst(b_ptr, (N,), dev) if has_bias else None
         nb = lib.query("adnm_conv3_wgrad_ws_bytes", B, H, W, K, N)
         wsb = _ws(nb, dev)
-        with FOLDS.defer(dev, wsb):
-            lib.call("adnm_conv3_wgrad", dy2.data_ptr(), dy2.stride(0), _p(pre), N, act, x2.data_ptr(), x2.stride(0), g.data_ptr(), _p(db),
-                     wsb.data_ptr(), nb, B, H, W, K, N, MFMA_PREC[0], _stream())
+        pg, pdb, prec = g.data_ptr(), _p(db), MFMA_PREC[0]
+        SIDE.submit(dev, (dy2, pre, x2), FOLDS.defer(dev, wsb), lambda: lib.call(
+            "adnm_conv3_wgrad", dy2.data_ptr(), dy2.stride(0), _p(pre), N, act, x2.data_ptr(), x2.stride(0), pg, pdb,
+            wsb.data_ptr(), nb, B, H, W, K, N, prec, _stream()))
         return dx, g, db, None, None, None
 
 

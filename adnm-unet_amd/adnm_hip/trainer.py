@@ -28,9 +28,25 @@ import torch.distributed as dist
 from . import lib, ops
 
 
+class _Both:
+    """enter a then b, leave b then a"""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+    def __enter__(self):
+        self.a.__enter__()
+        self.b.__enter__()
+
+    def __exit__(self, *exc):
+        self.b.__exit__(*exc)
+        self.a.__exit__(*exc)
+        return False
+
+
 class FlatTrainer:
     def __init__(self, model, loss_fn, lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2, max_norm=0.0,
-                 process_group=None, use_graph=True, fused=True, overlap="auto", reduce_dtype="f32", stages=None, defer_folds=True):
+                 process_group=None, use_graph=True, fused=True, overlap="auto", reduce_dtype="f32", stages=None, defer_folds=True, side_stream=False):
         """overlap: cut the backward at model.forward_stage1 / forward_stage2 (ADNM-UNet: encoder | decoder + refiner) and all-reduce
         the late stage's gradients while the early stage's backward runs.  "auto" = whenever there is more than one rank.
         `stages` is the older name of the same switch (True / False)."""
@@ -46,6 +62,10 @@ class FlatTrainer:
         assert reduce_dtype in ("f32", "bf16")
         self.reduce_dtype = reduce_dtype
         self.defer_folds = defer_folds
+        # weight-gradient kernels on a second stream beside the input-gradient chain (ops.SIDE).  Off by default: measured on MI355X /
+        # ROCm 7.2 the forked branches of the replayed hipGraph buy nothing and every fork costs (11.4 ms/step off, 12.1 with a fork per
+        # 16 weight gradients, 13.1 with one per weight gradient); bitwise neutral either way (tests/test_trainer_gpu.py)
+        self.side_stream = side_stream
         self.used = None
         self.graph = self.graph2 = None
         self.buckets = []
@@ -61,8 +81,11 @@ class FlatTrainer:
         return loss
 
     def _deferred(self):
+        """the context of a backward pass: second-stage folds of the parameter gradients batched (ops.FOLDS), weight-gradient kernels
+        on a side stream beside the input-gradient chain (ops.SIDE); both are joined / flushed on the way out"""
         on = self.defer_folds and self.used is not None and self.flat_g.is_cuda
-        return ops.FOLDS.active(self.flat_g.device if self.used is not None else torch.device("cpu"), on)
+        dev = self.flat_g.device if self.used is not None else torch.device("cpu")
+        return _Both(ops.SIDE.active(dev, on and self.side_stream), ops.FOLDS.active(dev, on))
 
     @torch.no_grad()
     def _flatten(self):

@@ -469,3 +469,22 @@ extern "C" int adnm_dwconv_bwd(const void* dy, int64_t lddy, const void* x, int6
   ADNM_CHECK_LAUNCH("dwconv_bwd");
   return ADNM_OK;
 }
+
+// The weight (and bias) gradient alone: g = the gradient at the conv's output BEFORE the fused activation (adnm_dwconv_bwd's dpre, or dy
+// itself without one).  Lets the caller run it on another stream than the input-gradient chain (adnm_dwconv_bwd with dwgt = NULL).
+extern "C" int adnm_dwconv_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, float* dwgt, float* dbias, void* ws, int64_t ws_bytes,
+                                 int64_t B, int64_t H, int64_t W, int64_t C, int KH, int KW, int wlayout, int dtype, adnm_stream_t stream) {
+  if (int rc = check("dwconv_wgrad", x, B, H, W, C, KH, KW, ADNM_ACT_NONE, dtype)) return rc;
+  ADNM_REQUIRE(g && dwgt, "dwconv_wgrad: null pointer");
+  ADNM_REQUIRE(wlayout == 0 || wlayout == 1, "dwconv_wgrad: weight layout %d not in {0 tap-major, 1 channel-major}", wlayout);
+  ADNM_REQUIRE(ldx >= C && ldg >= C && ldx % 4 == 0 && ldg % 4 == 0, "dwconv_wgrad: pixel strides must be >= C and multiples of 4");
+  if (!ws || ws_bytes < adnm_dwconv_bwd_ws_bytes(B, H, W, C, KH, KW)) {
+    adnm_set_error("dwconv_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_dwconv_bwd_ws_bytes(B, H, W, C, KH, KW));
+    return ADNM_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == ADNM_F32) launch_wgrad<float>(g, ldg, x, ldx, (float*)ws, dwgt, dbias, B, H, W, C, KH, wlayout, st);
+  else launch_wgrad<uint16_t>(g, ldg, x, ldx, (float*)ws, dwgt, dbias, B, H, W, C, KH, wlayout, st);
+  ADNM_CHECK_LAUNCH("dwconv_wgrad");
+  return ADNM_OK;
+}

@@ -158,6 +158,10 @@ int adnm_dwconv_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, co
                     const float* bias, void* dpre, void* dx, int64_t lddx, float* dwgt, float* dbias, void* ws,
                     int64_t ws_bytes, int64_t B, int64_t H, int64_t W, int64_t C, int KH, int KW, int act,
                     int wlayout, int dtype, adnm_stream_t stream);
+/* the weight / bias gradient of adnm_dwconv_bwd alone (g = its dpre, or dy when no activation is fused), e.g. on another stream than the
+ * input-gradient chain; adnm_dwconv_bwd with dwgt = NULL then skips it.  Workspace: adnm_dwconv_bwd_ws_bytes. */
+int adnm_dwconv_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, float* dwgt, float* dbias, void* ws, int64_t ws_bytes,
+                      int64_t B, int64_t H, int64_t W, int64_t C, int KH, int KW, int wlayout, int dtype, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- Haar butterflies, NHWC (K3)
  * wavelet_transform / inverse_wavelet_transform with db1 (WTConv2d.py:31-51): per 2x2 block

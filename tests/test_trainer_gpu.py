@@ -160,3 +160,26 @@ def test_bf16_wire_casts_on_the_real_bucket_boundaries():
     torch.cuda.synchronize()
     assert torch.equal(comm, tr.flat_g.to(torch.bfloat16))
     assert torch.equal(back, comm.float() * 0.5)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_side_stream_weight_gradients_are_bitwise_neutral(use_graph):
+    """Launching the weight-gradient kernels on a second stream beside the input-gradient chain (ops.SIDE: fork / join events, parallel
+    branches of the captured graph) must not change a bit of the parameters after several steps — any missing dependency would."""
+    from models.ADNMUNet import create_ADNMUNet
+    from models.loss import enRainfallLoss
+    frames = recipe.radar_batch(2, 25, 64, name="side").to(DEV)
+    x, tgt = frames[:, :5].contiguous(), frames[:, 5:].contiguous()
+    flats = []
+    for side in (False, True):
+        model = create_ADNMUNet(5, 20, 6, img_size=64)
+        recipe.fill_parameters(model)
+        model = model.to(DEV).train()
+        tr = FlatTrainer(model, enRainfallLoss(0.57, 0.25, gamma=0.0), lr=1e-3, max_norm=0.025, use_graph=use_graph, side_stream=side)
+        for _ in range(4):
+            tr.step(x, tgt)
+        torch.cuda.synchronize()
+        flats.append((tr.flat_p.clone(), tr.flat_g.clone()))
+        del tr
+    assert torch.equal(flats[0][1], flats[1][1]), "gradients differ with the side stream on"
+    assert torch.equal(flats[0][0], flats[1][0]), "parameters differ with the side stream on"
