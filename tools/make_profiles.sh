@@ -6,6 +6,7 @@
 #   profiles/<tag>_steady_state_bf16.txt        tools/kstats.py: last 3 steps of that trace, per kernel
 #   profiles/<tag>_small_grids_bf16.txt         tools/kclass.py: launches with <= 64 workgroups
 #   profiles/r02_pmc_traffic.json               tools/pmc_traffic.py from two --pmc passes (FETCH_SIZE, WRITE_SIZE)
+#   profiles/<tag>_bf16_parity.txt              tools/bf16_error.py: measured error of the bf16 mode on the whole model
 # The PMC passes run BEFORE the judged bench line so that the line can carry `traffic` from the same kernel sources.
 set -o pipefail
 tag=${1:-r02}
@@ -21,6 +22,9 @@ tail -n 3 $out/pmc_traffic.txt
 python3 bench.py --dump-prof $out/kernel_shapes_bf16.tsv > $out/bench_bf16.json 2> $out/bench_bf16.err || { echo "bench bf16 failed"; tail -n 5 $out/bench_bf16.err; exit 1; }
 python3 bench.py --dtype f32 --no-cpu-baseline --dump-prof $out/kernel_shapes_f32.tsv > $out/bench_f32.json 2> $out/bench_f32.err || { echo "bench f32 failed"; exit 1; }
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace -o t -- python3 $root/bench.py --steps 20 --warmup 10 --prof-steps 0 --no-cpu-baseline > $root/$out/trace.log 2>&1 ) || { echo "trace pass failed"; tail -n 5 $out/trace.log; exit 1; }
+python3 tools/bf16_error.py > $out/bf16_parity.txt 2>&1
+python3 tools/kbench_ts.py 2>&1 | grep -v amdgpu.ids > $out/tsgemm.txt
+python3 tools/kbench_gemm.py 2>&1 | grep -v amdgpu.ids > $out/gemm_bench.txt
 python3 tools/kstats.py $out/trace 80 3 80 > $out/steady_state_bf16.txt 2>&1
 python3 tools/kclass.py $out/trace 64 > $out/small_grids_bf16.txt 2>&1
 find $out/trace -name "*kernel_stats.csv" | head -n 1 | xargs -I{} cp {} $out/kernel_stats_bf16.csv
