@@ -1144,7 +1144,7 @@ def k_linear(x2, w, bias, out=None):
     _need_gpu(x2)
     if ts_ok_nt(M, N, K, x2):
         y = out if out is not None else torch.empty((M, N), dtype=x2.dtype, device=x2.device)
-        lib.call("adnm_tsgemm_nt", x2.data_ptr(), x2.stride(0), w.data_ptr(), K, 1, _p(bias), y.data_ptr(), y.stride(0), M, N, K, _stream())
+        lib.call("adnm_tsgemm_nt", x2.data_ptr(), x2.stride(0), w.data_ptr(), K, 1, _p(bias), y.data_ptr(), y.stride(0), M, N, K, MFMA_PREC[0], _stream())
         return y
     x2, w = _sk_operand(x2, "input"), _sk_operand(w, "weight")
     y = out if out is not None and _out_view_ok(out) else torch.empty((M, N), dtype=x2.dtype, device=x2.device)
@@ -1161,7 +1161,7 @@ def k_linear_dx(dy2, w, out=None):
     K = w.shape[1]
     if ts_ok_nt(M, K, N, dy2):
         dx = out if out is not None else torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
-        lib.call("adnm_tsgemm_nt", dy2.data_ptr(), dy2.stride(0), w.data_ptr(), 1, K, None, dx.data_ptr(), dx.stride(0), M, K, N, _stream())
+        lib.call("adnm_tsgemm_nt", dy2.data_ptr(), dy2.stride(0), w.data_ptr(), 1, K, None, dx.data_ptr(), dx.stride(0), M, K, N, MFMA_PREC[0], _stream())
         return dx
     dy2, w = _sk_operand(dy2, "output gradient"), _sk_operand(w, "weight")
     dx = out if out is not None and _out_view_ok(out) else torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)

@@ -24,11 +24,14 @@ constexpr int kWaves = 8;
 
 // ---------------------------------------------------------------------------------------------- nt: Y = X . Wp^T
 // Wp[n][k] is read at w[n * ws_n + k * ws_k]  (forward: ws_n=K, ws_k=1; input gradient: ws_n=1, ws_k=K_of_weight)
-template <int KQ, int NB>
+template <int KQ, int NB, bool BF16>
 __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
                                                            int64_t ws_n, int64_t ws_k, const float* __restrict__ bias,
                                                            float* __restrict__ y, int64_t ldy, int64_t M, int N, int K) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];  // [NB][K/4][64]
+  // fp32: [NB][K/4][64] floats, one per (column block, k step, lane).  bf16 (ADNM_MFMA_BF16): [NB][K/16][64] entries of 4 bf16 = the
+  // lane's four reduction steps of one v_mfma_f32_16x16x16_bf16 — a quarter of the MFMAs and LDS reads per row block
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  uint16_t* const wh = reinterpret_cast<uint16_t*>(wl);
   const int ksteps = K >> 2;
   // stage the weight in fragment order: entry (cb, s, lane=(j,kk)) = Wp[cb*16+j][16*(s/4) + 4*kk + (s%4)].
   // Global reads run along the weight's contiguous axis (k for the forward layout, n for the transposed one).
@@ -53,7 +56,8 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
         if (ws_k == 1) { n = idx / K; k = idx - n * K; }
         else { k = idx / (NB * 16); n = idx - k * (NB * 16); }
         const int cb = n >> 4, j = n & 15, q = k >> 4, kk = (k >> 2) & 3, e = k & 3;
-        wl[(cb * ksteps + (q * 4 + e)) * 64 + kk * 16 + j] = v[u];
+        if (BF16) wh[((cb * KQ + q) * 64 + kk * 16 + j) * 4 + e] = (uint16_t)(adnm_pack_bf16(v[u], 0.f, 0.f, 0.f)[0]);
+        else wl[(cb * ksteps + (q * 4 + e)) * 64 + kk * 16 + j] = v[u];
       }
     }
   }
@@ -82,6 +86,15 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
     for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
+      if (BF16) {
+        const adnm_bf16x4 xb = adnm_pack_bf16(xa[q].x, xa[q].y, xa[q].z, xa[q].w);
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+          const uint2 wv = *reinterpret_cast<const uint2*>(wh + ((cb * KQ + q) * 64 + lane) * 4);
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(adnm_bf16x4, wv), xb, acc[cb], 0, 0, 0);
+        }
+        continue;
+      }
       const float ae[4] = {xa[q].x, xa[q].y, xa[q].z, xa[q].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -227,9 +240,12 @@ int rows_per_wave(const char* name, int dflt) {   // measurement aid: ADNM_TS_NT
   const int v = e ? atoi(e) : 0;
   return v > 0 ? v : dflt;
 }
-int nt_blocks(int64_t M) {
-  static const int rpw = rows_per_wave("ADNM_TS_NT_RPW", 2);
-  int64_t b = adnm_cdiv(adnm_cdiv(M, 16), kWaves * rpw);  // ~2 row blocks per wave, >= 4 waves per SIMD in flight
+int nt_blocks(int64_t M, bool bf16) {
+  // fp32: ~2 row blocks per wave.  bf16: one — the kernel needs half the registers, so every row block of the 65 536-token level is
+  // resident at once (4 workgroups per CU) and the whole input is requested in one round trip
+  static const int rpw32 = rows_per_wave("ADNM_TS_NT_RPW", 2), rpw16 = rows_per_wave("ADNM_TS_NT_RPW16", 1);
+  const int rpw = bf16 ? rpw16 : rpw32;
+  int64_t b = adnm_cdiv(adnm_cdiv(M, 16), kWaves * rpw);
   if (b > 1024) b = 1024;
   return (int)(b < 1 ? 1 : b);
 }
@@ -241,10 +257,11 @@ int tn_blocks(int64_t M) {
 
 template <int KQ, int NB>
 int launch_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, float* y, int64_t ldy, int64_t M,
-               int N, int K, hipStream_t st) {
-  const size_t smem = (size_t)NB * (K / 4) * 64 * sizeof(float);
+               int N, int K, bool bf16, hipStream_t st) {
+  const size_t smem = (size_t)NB * (K / 4) * 64 * (bf16 ? sizeof(uint16_t) : sizeof(float));
   ADNM_PROF("tsgemm_nt", st, 4.0 * ((double)M * (K + N) + (double)N * K));
-  tsgemm_nt_kernel<KQ, NB><<<nt_blocks(M), kBlock, smem, st>>>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, N, K);
+  if (bf16) tsgemm_nt_kernel<KQ, NB, true><<<nt_blocks(M, true), kBlock, smem, st>>>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, N, K);
+  else tsgemm_nt_kernel<KQ, NB, false><<<nt_blocks(M, false), kBlock, smem, st>>>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, N, K);
   return ADNM_OK;
 }
 
@@ -288,8 +305,9 @@ extern "C" int adnm_tsgemm_supported(int64_t M, int64_t N, int64_t K) {
 
 // Y[M,N] = X[M,K] . Wp^T (+bias), Wp[n][k] = w[n*ws_n + k*ws_k].  K % 16 == 0, K <= 256, N <= 256.
 extern "C" int adnm_tsgemm_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, float* y,
-                              int64_t ldy, int64_t M, int64_t N, int64_t K, adnm_stream_t stream) {
+                              int64_t ldy, int64_t M, int64_t N, int64_t K, int prec, adnm_stream_t stream) {
   ADNM_REQUIRE(x && w && y, "tsgemm_nt: null pointer");
+  ADNM_REQUIRE(prec == ADNM_MFMA_F32 || prec == ADNM_MFMA_BF16, "tsgemm_nt: bad prec %d", prec);
   ADNM_REQUIRE(adnm_tsgemm_supported(M, N, K), "tsgemm_nt: unsupported shape M=%lld N=%lld K=%lld (need K%%16==0, K<=256, N<=256)", (long long)M,
                (long long)N, (long long)K);
   ADNM_REQUIRE(ldx >= K && ldx % 4 == 0 && ldy >= N, "tsgemm_nt: bad row strides");
@@ -299,7 +317,7 @@ extern "C" int adnm_tsgemm_nt(const float* x, int64_t ldx, const float* w, int64
   // only the variants adnm_tsgemm_supported admits (N*K <= 8192, i.e. KQ*NB <= 32 blocks: <= 64 accumulator + 64 operand VGPRs,
   // no scratch) are instantiated
   int rc = ADNM_EINVAL;
-#define NT(KQ, NB) if (kq == KQ && nb == NB) rc = launch_nt<KQ, NB>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, (int)N, (int)K, st)
+#define NT(KQ, NB) if (kq == KQ && nb == NB) rc = launch_nt<KQ, NB>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, (int)N, (int)K, prec == ADNM_MFMA_BF16, st)
   NT(1, 1); NT(1, 2); NT(1, 4); NT(1, 8); NT(1, 13); NT(1, 16);
   NT(2, 1); NT(2, 2); NT(2, 4); NT(2, 8); NT(2, 13); NT(2, 16);
   NT(4, 1); NT(4, 2); NT(4, 4); NT(4, 8);

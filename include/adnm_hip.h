@@ -399,7 +399,7 @@ int adnm_cast_bf16_f32(const void* src, void* dst, int64_t n, float scale, adnm_
  * *_supported() return 1 when the shape fits the kernels (callers use the library GEMM otherwise). */
 int adnm_tsgemm_supported(int64_t M, int64_t N, int64_t K);
 int adnm_tsgemm_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, float* y,
-                   int64_t ldy, int64_t M, int64_t N, int64_t K, adnm_stream_t stream);
+                   int64_t ldy, int64_t M, int64_t N, int64_t K, int prec, adnm_stream_t stream);
 int adnm_tsgemm_tn_supported(int64_t M, int64_t N, int64_t K);
 int64_t adnm_tsgemm_tn_ws_bytes(int64_t M, int64_t N, int64_t K);
 int adnm_tsgemm_tn(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* dbias, void* ws,

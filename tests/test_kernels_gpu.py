@@ -738,6 +738,22 @@ def test_skgemm_bf16_mfma(M, K, N, bf16_mfma):
     assert_close(wg.grad, cr.t() @ xr, 2e-6, "dw")
 
 
+@pytest.mark.parametrize("M,K,N", [(65536, 32, 128), (65536, 32, 208), (65536, 128, 32), (40000, 64, 20)])
+def test_tsgemm_bf16_mfma(M, K, N, bf16_mfma):
+    """the full-resolution Linears in the bf16 mode: forward and input gradient on bf16 MFMA (exactly the fp32 GEMM of the bf16-rounded
+    operands), the weight gradient stays exact fp32"""
+    x, w, cot = T(f"tb.x{M}{K}", (M, K)), T(f"tb.w{N}{K}", (N, K), 0.05), T(f"tb.c{M}{N}", (M, N))
+    b = T(f"tb.b{N}", (N,))
+    xg, wg, bg = leaf(x, DEV), leaf(w, DEV), leaf(b, DEV)
+    yg = ops.linear(xg, wg, bg)
+    (yg * cot.to(DEV)).sum().backward()
+    xr, wr, cr = _bf16_round(x).double().to(DEV), _bf16_round(w).double().to(DEV), _bf16_round(cot).double().to(DEV)
+    assert_close(yg, xr @ wr.t() + b.double().to(DEV), 2e-6, "y vs the GEMM of bf16-rounded operands")
+    assert_close(xg.grad, cr @ wr, 2e-6, "dx")
+    assert_close(wg.grad, cot.double().to(DEV).t() @ x.double().to(DEV), 1e-5, "dw (fp32 MFMA)")
+    assert_close(bg.grad, cot.double().sum(0), 1e-5, "db")
+
+
 def test_conv3_bf16_mfma(bf16_mfma):
     B, H, W, K, N = 2, 16, 16, 32, 64
     x, w, b, cot = T("bfc.x", (B, H * W, K)), T("bfc.w", (N, K, 3, 3), 0.2), T("bfc.b", (N,)), T("bfc.c", (B, H * W, N))

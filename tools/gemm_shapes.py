@@ -65,7 +65,7 @@ for (op, M, N, K, hb), cnt in sorted(shapes.items(), key=lambda kv: (kv[0][1], k
         libf = (lambda: torch.addmm(b, a, w.t())) if hb else (lambda: torch.mm(a, w.t()))
         c = torch.empty(M, N, device=dev)
         if ops.ts_ok_nt(M, N, K, a):
-            t_ts = timeit(lambda: lib.call("adnm_tsgemm_nt", a.data_ptr(), K, w.data_ptr(), K, 1, ops._p(b), c.data_ptr(), N, M, N, K, ops._stream()))
+            t_ts = timeit(lambda: lib.call("adnm_tsgemm_nt", a.data_ptr(), K, w.data_ptr(), K, 1, ops._p(b), c.data_ptr(), N, M, N, K, ops.MFMA_PREC[0], ops._stream()))
         if lib.query("adnm_skgemm_supported", OPC[op], M, N, K) == 1:
             t_sk = timeit(lambda: ops._skgemm(OPC[op], a, w, b, c, None, M, N, K))
     elif op == "NN":
@@ -73,7 +73,7 @@ for (op, M, N, K, hb), cnt in sorted(shapes.items(), key=lambda kv: (kv[0][1], k
         libf = lambda: torch.mm(a, w)
         c = torch.empty(M, K, device=dev)
         if ops.ts_ok_nt(M, K, N, a):
-            t_ts = timeit(lambda: lib.call("adnm_tsgemm_nt", a.data_ptr(), N, w.data_ptr(), 1, K, None, c.data_ptr(), K, M, K, N, ops._stream()))
+            t_ts = timeit(lambda: lib.call("adnm_tsgemm_nt", a.data_ptr(), N, w.data_ptr(), 1, K, None, c.data_ptr(), K, M, K, N, ops.MFMA_PREC[0], ops._stream()))
         if lib.query("adnm_skgemm_supported", OPC[op], M, N, K) == 1:
             t_sk = timeit(lambda: ops._skgemm(OPC[op], a, w, None, c, None, M, N, K))
     else:

@@ -40,6 +40,8 @@ def graph_time(fn):
     return best
 
 
+ops.set_mfma_precision(os.environ.get("PREC", "f32"))
+print("precision of our kernels:", os.environ.get("PREC", "f32"))
 tot = [0.0] * 6
 for M, N, K in shapes:
     x, w, dy = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) * 0.1, torch.randn(M, N, device=dev)
