@@ -33,7 +33,8 @@ FOLDS = "|".join(["fold_batch", "skgemm_fold", "ssd_head_fold", "lincomb_bwd_fol
 # (regex on the demangled kernel symbol, profiler scope); first match wins
 SCOPES = [
     (r"^skgemm_kernel<true, true", "skgemm_nt"), (r"^skgemm_kernel<true, false", "skgemm_nn"), (r"^skgemm_kernel<false, false", "skgemm_tn"),
-    (r"^lgemm_kernel<0", "skgemm_nt"), (r"^lgemm_kernel<1", "skgemm_nn"), (r"^lgemm_kernel<2", "skgemm_tn"),
+    (r"^lgemm_kernel<false", "skgemm_nt"), (r"^lgemm_kernel<true", "skgemm_nn"),   # the LDS-tiled half of adnm_skgemm (B_OC = op NN)
+    (r"^colsum_partial_kernel", "colsum_partial"),
     (r"^tsgemm_nt_kernel", "tsgemm_nt"), (r"^tsgemm_tn_kernel", "tsgemm_tn"),
     (r"^dwconv_kernel<float, 3", "dwconv_k3"), (r"^dwconv_kernel<float, 5", "dwconv_k5"),
     (r"^dwconv_wgrad3_roll_kernel|^dwconv_wgrad_kernel<float, 3", "dwconv_wgrad_k3"), (r"^dwconv_wgrad_kernel<float, 5", "dwconv_wgrad_k5"),
@@ -100,30 +101,47 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
-def main():
-    fdir, wdir, outp = sys.argv[1:4]
-    commit = sys.argv[4] if len(sys.argv) > 4 else None
-    nf, fetch = per_step(load(fdir, "FETCH_SIZE"), 2.0 * 1024.0)   # x2: the gfx950 FETCH_SIZE correction
-    nw, write = per_step(load(wdir, "WRITE_SIZE"), 1024.0)
-    symbols, kernels = {}, {}
-    for s in sorted(set(fetch) | set(write)):
-        fb, fl = fetch.get(s, [0.0, 0.0])
-        wb, wl = write.get(s, [0.0, 0.0])
-        row = {"hbm_bytes_per_step": fb + wb, "fetch_bytes_per_step": fb, "write_bytes_per_step": wb, "launches_per_step": max(fl, wl)}
-        symbols[s] = row
+def by_scope(symbols):
+    kernels = {}
+    for s, row in symbols.items():
         sc = scope_of(s)
         if sc:
             k = kernels.setdefault(sc, {"hbm_bytes_per_step": 0.0, "fetch_bytes_per_step": 0.0, "write_bytes_per_step": 0.0, "launches_per_step": 0.0})
             for f in k:
                 k[f] += row[f]
-    json.dump({"csrc_hash": csrc_hash(), "commit": commit, "steps_measured": min(nf, nw),
-               "method": "rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and --pmc WRITE_SIZE in separate passes, x1024 B, summed over XCD instances, "
-                         "whole steps cut at adamw_kernel, first step dropped",
-               "kernels": kernels, "symbols": symbols}, open(outp, "w"), indent=1)
+    return kernels
+
+
+def report(out):
+    symbols, kernels = out["symbols"], out["kernels"]
     tot = sum(v["hbm_bytes_per_step"] for v in symbols.values())
-    print(f"{min(nf, nw)} steps; {tot / 1e9:.3f} GB of HBM traffic per step over {sum(v['launches_per_step'] for v in symbols.values()):.0f} launches")
+    print(f"{out['steps_measured']} steps; {tot / 1e9:.3f} GB of HBM traffic per step over {sum(v['launches_per_step'] for v in symbols.values()):.0f} launches")
     for s, v in sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_step"])[:40]:
-        print(f"{v['hbm_bytes_per_step'] / 1e6:10.2f} MB/step  {v['launches_per_step']:7.1f} launches  {s}")
+        print(f"{v['hbm_bytes_per_step'] / 1e6:10.2f} MB/step  {v['launches_per_step']:7.1f} launches  {s[:100]}")
+
+
+def main():
+    if sys.argv[1] == "--rescope":   # re-derive the per-scope table of an existing file from its per-symbol table (SCOPES changed)
+        out = json.load(open(sys.argv[2]))
+        out["kernels"] = by_scope(out["symbols"])
+        json.dump(out, open(sys.argv[2], "w"), indent=1)
+        report(out)
+        return
+    fdir, wdir, outp = sys.argv[1:4]
+    commit = sys.argv[4] if len(sys.argv) > 4 else None
+    nf, fetch = per_step(load(fdir, "FETCH_SIZE"), 2.0 * 1024.0)   # x2: the gfx950 FETCH_SIZE correction
+    nw, write = per_step(load(wdir, "WRITE_SIZE"), 1024.0)
+    symbols = {}
+    for s in sorted(set(fetch) | set(write)):
+        fb, fl = fetch.get(s, [0.0, 0.0])
+        wb, wl = write.get(s, [0.0, 0.0])
+        symbols[s] = {"hbm_bytes_per_step": fb + wb, "fetch_bytes_per_step": fb, "write_bytes_per_step": wb, "launches_per_step": max(fl, wl)}
+    out = {"csrc_hash": csrc_hash(), "commit": commit, "steps_measured": min(nf, nw),
+           "method": "rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and --pmc WRITE_SIZE in separate passes, x1024 B, summed over XCD instances, "
+                     "whole steps cut at adamw_kernel, first step dropped",
+           "kernels": by_scope(symbols), "symbols": symbols}
+    json.dump(out, open(outp, "w"), indent=1)
+    report(out)
 
 
 if __name__ == "__main__":
