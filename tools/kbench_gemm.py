@@ -31,25 +31,34 @@ shapes = file_shapes or [(args[i], int(args[i + 1]), int(args[i + 2]), int(args[
 ]
 OPC = {"NT": ops.SK_NT, "NN": ops.SK_NN, "TN": ops.SK_TN}
 reps = int(os.environ.get("REPS", "20"))
+# COLD=1: the weight operand of every launch comes from HBM, as in a training step (72 M parameters are streamed once per pass, AdamW
+# rewrites them in between): the launches of a graph cycle over enough copies of the weight to exceed the 256 MB Infinity Cache.
+# Without it the 20 launches re-read one weight that stays in L2 / the Infinity Cache — 2-3x faster than the step ever sees.
+cold = os.environ.get("COLD") == "1"
+FLUSH = torch.empty(1 << 28, dtype=torch.float32, device="cuda") if cold else None
 
 
-def graph_time(fn):
-    fn()
+def graph_time(fn, nvar=1):
+    """fn(i): launch with operand copy i (i < nvar)"""
+    fn(0)
     torch.cuda.synchronize()
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
-        fn()
+        fn(0)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
-            for _ in range(reps):
-                fn()
+            for r in range(reps):
+                fn(r % nvar)
     torch.cuda.current_stream().wait_stream(s)
     g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     best = 1e9
     for _ in range(3):
+        if cold:   # evict L2 and the Infinity Cache: 1 GB of writes
+            FLUSH.zero_()
+            torch.cuda.synchronize()
         e0.record()
         g.replay()
         e1.record()
@@ -64,15 +73,24 @@ bad = 0
 rows = []
 for op, M, N, K in shapes:
     gen = lambda *s: torch.randn(*s, device=dev)
+    wshape = (N, K) if op in ("NT", "NN") else (M, K)
+    nvar = 1
+    if cold and op != "TN":
+        nvar = reps   # every launch of a replay reads its own copy; the caches are flushed between replays (graph_time)
+    bs = [gen(*wshape) for _ in range(nvar)]
+    if nvar > 1:
+        for t in bs[1:]:
+            t.copy_(bs[0])
+    b = bs[0]
     if op == "NT":
-        a, b, c = gen(M, K), gen(N, K), torch.empty(M, N, device=dev)
-        libf = lambda: torch.mm(a, b.t())
+        a, c = gen(M, K), torch.empty(M, N, device=dev)
+        libf = lambda i=0: torch.mm(a, bs[i].t())
     elif op == "NN":
-        a, b, c = gen(M, N), gen(N, K), torch.empty(M, K, device=dev)
-        libf = lambda: torch.mm(a, b)
+        a, c = gen(M, N), torch.empty(M, K, device=dev)
+        libf = lambda i=0: torch.mm(a, bs[i])
     else:
-        a, b, c = gen(M, N), gen(M, K), torch.empty(N, K, device=dev)
-        libf = lambda: torch.mm(a.t(), b)
+        a, c = gen(M, N), torch.empty(N, K, device=dev)
+        libf = lambda i=0: torch.mm(a.t(), bs[i])
     ref = libf().double()
     row = {"op": op, "M": M, "N": N, "K": K}
     txt = []
@@ -80,7 +98,7 @@ for op, M, N, K in shapes:
         ops.set_mfma_precision(prec)
         c.fill_(float("nan"))
         try:
-            t = graph_time(lambda: ops._skgemm(OPC[op], a, b, None, c, None, M, N, K))
+            t = graph_time(lambda i: ops._skgemm(OPC[op], a, bs[i], None, c, None, M, N, K), nvar)
         except RuntimeError as e:   # a forced configuration this op has no kernel for
             txt.append(f"sk {prec:4s}    n/a")
             continue
@@ -92,7 +110,7 @@ for op, M, N, K in shapes:
         txt.append(f"sk {prec:4s} {t:6.1f} us (err {err:.1e}{'' if ok else ' BAD'})")
     ops.set_mfma_precision("f32")
     if not nolib:
-        row["lib"] = graph_time(libf)
+        row["lib"] = graph_time(libf, nvar)
         tot["lib"] += row["lib"]
         txt.append(f"rocBLAS {row['lib']:6.1f} us")
     rows.append(row)
