@@ -365,7 +365,7 @@ def main():
                         "hip_kernels_ms_per_step": round(total_ms / ps, 3), "instrumented_step_ms": round(prof_step_ms, 3),
                         "whole_step_frac": round(sum(r_["bytes"] for r_ in agg.values()) / ps / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
         res = {
-            "metric": "sequences/sec training ADNM-UNet 5->20x128x128", "value": round(world * args.batch * args.steps / dt, 3),
+            "metric": f"sequences/sec training ADNM-UNet {args.in_frames}->{args.out_frames}x{args.size}x{args.size}", "value": round(world * args.batch * args.steps / dt, 3),
             "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16",
