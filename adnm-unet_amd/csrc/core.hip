@@ -97,7 +97,7 @@ extern "C" int64_t adnm_prof_collect(char* buf, int64_t buflen) {
 namespace {
 // A workgroup of 1024 threads folds `cols` columns with 1024 / cols row slices: 64 x 16 by default; partial sets with many rows and
 // few columns (per-channel scalars, bias sums: 1024 x 4, 1024 x 131 ...) would leave one or two workgroups walking hundreds of rows
-// each, so they take 16 x 64 or 4 x 256.  The geometry is a function of (rows, n) only: a set is summed in the same order whether it
+// each, so they take 16 x 64 or 4 x 256; sets with few rows take 128 .. 1024 columns.  The geometry is a function of (rows, n) only: a set is summed in the same order whether it
 // is folded at once or from the queue.
 constexpr int kFoldThreads = 1024, kMaxFolds = 16;
 struct FoldSegs {
@@ -107,7 +107,7 @@ struct FoldSegs {
 struct FoldDesc {
   const float* part;
   int rows, n;
-  int lc;   // log2(columns per workgroup): 6, 4 or 2
+  int lc;   // log2(columns per workgroup): 2 .. 10
   FoldSegs segs;
 };
 struct MultiFold {
@@ -118,6 +118,12 @@ struct MultiFold {
 int fold_lc(int rows, int n) {
   if (rows >= 1024 && n <= 64) return 2;
   if (rows >= 256 && n <= 2048) return 4;
+  // few partial rows (the split-K slabs of a weight gradient: 2 .. 16 rows x 100 K+ columns): as many columns per workgroup as rows
+  // allow, or the launch is ~10 K workgroups of 16 waves of which 12 never load anything — wave launch rate, not bandwidth
+  if (rows <= 4) return 10;
+  if (rows <= 8) return 9;
+  if (rows <= 16) return 8;
+  if (rows <= 32) return 7;
   return 6;
 }
 __global__ __launch_bounds__(kFoldThreads) void fold_rows_kernel(MultiFold mf_by_value) {

@@ -703,9 +703,9 @@ def test_lincomb_scalar_mix_any_channel_count():
 
 
 # ------------------------------------------------------------------------------------------- bf16 MFMA precision (BASELINE's bf16 configs)
-@pytest.mark.parametrize("rows,n", [(65536, 32), (5000, 257), (2048, 4), (1500, 4), (1024, 131), (300, 3000), (7, 5)])
+@pytest.mark.parametrize("rows,n", [(65536, 32), (5000, 257), (2048, 4), (1500, 4), (1024, 131), (300, 3000), (7, 5), (3, 5000), (12, 3001), (20, 4000), (2, 263168)])
 def test_colsum(rows, n):
-    """bias-gradient column sums: two-stage above 2048 rows, the shared fold (all three workgroup geometries) below"""
+    """bias-gradient column sums: two-stage above 2048 rows, the shared fold (every workgroup geometry, 4 .. 1024 columns) below"""
     x = T(f"cs.{rows}.{n}", (rows, n)).to(DEV)
     out = ops.colsum(x)
     assert_close(out, x.double().sum(0), 2e-6, "colsum")
