@@ -62,16 +62,18 @@ __device__ __forceinline__ void adn_chain_of(int co, const AdnDims& d, int& chai
   else { chain = odd ? 3 : 1; row = i - nx; }
 }
 
+// The two big matrices (in_proj.weight: a ROW permutation; out_proj.weight: a column permutation of its first half, scaled by alpha1 —
+// 19 + 17 MB at the deepest mixer) move as float4s, one quad per work item; the small tap / norm tensors one element per work item.
 __global__ __launch_bounds__(kBlock) void adn_prep_fwd_kernel(AdnParams p, AdnPrepped o, AdnDims d) {
-  const int cx = d.di + 2 * d.gn, dinp = 2 * d.di + 2 * d.gn + d.nh;
-  const int64_t n0 = (int64_t)dinp * d.dm, n1 = n0 + 9 * cx, n2 = n1 + 9 * d.di, n3 = n2 + 2 * d.di, n4 = n3 + (int64_t)d.dm * 2 * d.di;
+  const int cx = d.di + 2 * d.gn, dinp = 2 * d.di + 2 * d.gn + d.nh, dm4 = d.dm >> 2, oq = d.di >> 1;   // oq: quads per out_proj row (2 di / 4)
+  const int64_t n0 = (int64_t)dinp * dm4, n1 = n0 + 9 * cx, n2 = n1 + 9 * d.di, n3 = n2 + 2 * d.di, n4 = n3 + (int64_t)d.dm * oq;
   const float a1 = *p.alpha1;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
     if (i < n0) {
-      const int r = (int)(i / d.dm), c = (int)(i - (int64_t)r * d.dm);
+      const int r = (int)(i / dm4), c = (int)(i - (int64_t)r * dm4) * 4;
       int src = r;
       if (r >= d.di && r < d.di + cx) src = d.di + adn_fwd_map(r - d.di, d);
-      o.w_in[i] = p.w_in[(int64_t)src * d.dm + c];
+      *reinterpret_cast<float4*>(o.w_in + (int64_t)r * d.dm + c) = *reinterpret_cast<const float4*>(p.w_in + (int64_t)src * d.dm + c);
     } else if (i < n1) {
       const int j = (int)(i - n0), t = j / cx, ch = j - t * cx;
       const int co = adn_fwd_map(ch, d);
@@ -92,9 +94,12 @@ __global__ __launch_bounds__(kBlock) void adn_prep_fwd_kernel(AdnParams p, AdnPr
       else o.ln_b[j - d.di] = p.ln_b[adn_fwd_map(j - d.di, d)];
     } else {
       const int64_t j = i - n3;
-      const int r = (int)(j / (2 * d.di)), k = (int)(j - (int64_t)r * 2 * d.di);
-      const int src = k < d.di ? adn_fwd_map(k, d) : k;
-      o.w_out[j] = a1 * p.w_out[(int64_t)r * 2 * d.di + src];
+      const int r = (int)(j / oq), k = (int)(j - (int64_t)r * oq) * 4;
+      const float* row = p.w_out + (int64_t)r * 2 * d.di;
+      float4 v;
+      if (k >= d.di) v = *reinterpret_cast<const float4*>(row + k);
+      else v = make_float4(row[adn_fwd_map(k, d)], row[adn_fwd_map(k + 1, d)], row[adn_fwd_map(k + 2, d)], row[adn_fwd_map(k + 3, d)]);
+      *reinterpret_cast<float4*>(o.w_out + (int64_t)r * 2 * d.di + k) = make_float4(a1 * v.x, a1 * v.y, a1 * v.z, a1 * v.w);
     }
   }
 }
@@ -105,16 +110,17 @@ __global__ __launch_bounds__(kBlock) void adn_prep_bwd_kernel(AdnParams p, AdnPr
   __shared__ float sm[kBlock / 64];
   const int cx = d.di + 2 * d.gn, dinp = 2 * d.di + 2 * d.gn + d.nh, ce = cx >> 1, nx = d.di >> 2, nbc = d.gn >> 1;
   const int nchain = 2 * (nx + nbc) * 3;  // per kind (c31 / c13): x1,bc1,x2,bc2 rows x 3 taps
-  const int64_t n0 = (int64_t)dinp * d.dm, n1 = n0 + (int64_t)ce * 9, n2 = n1 + 2 * nchain, n3 = n2 + 9 * d.di, n4 = n3 + 2 * d.di,
-                n5 = n4 + (int64_t)d.dm * 2 * d.di;
+  const int dm4 = d.dm >> 2, oq = d.di >> 1;   // the two big matrices as float4 quads (see adn_prep_fwd_kernel)
+  const int64_t n0 = (int64_t)dinp * dm4, n1 = n0 + (int64_t)ce * 9, n2 = n1 + 2 * nchain, n3 = n2 + 9 * d.di, n4 = n3 + 2 * d.di,
+                n5 = n4 + (int64_t)d.dm * oq;
   const float a1 = *p.alpha1;
   float acc = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n5; i += (int64_t)gridDim.x * kBlock) {
     if (i < n0) {
-      const int r = (int)(i / d.dm), c = (int)(i - (int64_t)r * d.dm);
+      const int r = (int)(i / dm4), c = (int)(i - (int64_t)r * dm4) * 4;
       int src = r;
       if (r >= d.di && r < d.di + cx) src = d.di + adn_inv_map(r - d.di, d);
-      dp.w_in[i] = g.w_in[(int64_t)src * d.dm + c];
+      *reinterpret_cast<float4*>(dp.w_in + (int64_t)r * d.dm + c) = *reinterpret_cast<const float4*>(g.w_in + (int64_t)src * d.dm + c);
     } else if (i < n1) {
       const int j = (int)(i - n0), m = j / 9, t = j - m * 9;
       dp.conv2d[j] = g.cw[t * cx + adn_inv_map(2 * m, d)];
@@ -150,11 +156,15 @@ __global__ __launch_bounds__(kBlock) void adn_prep_bwd_kernel(AdnParams p, AdnPr
       else dp.ln_b[j - d.di] = g.ln_b[adn_inv_map(j - d.di, d)];
     } else {
       const int64_t j = i - n4;
-      const int r = (int)(j / (2 * d.di)), k = (int)(j - (int64_t)r * 2 * d.di);
-      const int src = k < d.di ? adn_inv_map(k, d) : k;
-      const float gv = g.w_out[(int64_t)r * 2 * d.di + src];
-      dp.w_out[j] = a1 * gv;
-      acc = fmaf(gv, p.w_out[j], acc);
+      const int r = (int)(j / oq), k = (int)(j - (int64_t)r * oq) * 4;
+      const float* grow = g.w_out + (int64_t)r * 2 * d.di;
+      float4 gv;
+      if (k >= d.di) gv = *reinterpret_cast<const float4*>(grow + k);
+      else gv = make_float4(grow[adn_inv_map(k, d)], grow[adn_inv_map(k + 1, d)], grow[adn_inv_map(k + 2, d)], grow[adn_inv_map(k + 3, d)]);
+      const int64_t at = (int64_t)r * 2 * d.di + k;
+      const float4 w = *reinterpret_cast<const float4*>(p.w_out + at);
+      *reinterpret_cast<float4*>(dp.w_out + at) = make_float4(a1 * gv.x, a1 * gv.y, a1 * gv.z, a1 * gv.w);
+      acc = fmaf(gv.x, w.x, fmaf(gv.y, w.y, fmaf(gv.z, w.z, fmaf(gv.w, w.w, acc))));
     }
   }
   acc = wave_sum(acc);
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void wt_prep_bwd_kernel(WtPtrs p, WtPtrs g,
 }
 
 int adn_check(const char* who, AdnDims d) {
-  ADNM_REQUIRE(d.dm > 0 && d.di > 0 && d.di % 8 == 0 && d.gn > 0 && d.gn % 4 == 0 && d.P > 0 && d.di % d.P == 0 && d.nh == d.di / d.P && d.nh % 2 == 0,
+  ADNM_REQUIRE(d.dm > 0 && d.dm % 4 == 0 && d.di > 0 && d.di % 8 == 0 && d.gn > 0 && d.gn % 4 == 0 && d.P > 0 && d.di % d.P == 0 && d.nh == d.di / d.P && d.nh % 2 == 0,
                "%s: unsupported ADN-SSD dimensions dm=%d di=%d gn=%d P=%d nh=%d", who, d.dm, d.di, d.gn, d.P, d.nh);
   return ADNM_OK;
 }
