@@ -33,6 +33,8 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
   extern __shared__ __attribute__((aligned(16))) float wl[];
   uint16_t* const wh = reinterpret_cast<uint16_t*>(wl);
   const int ksteps = K >> 2;
+  constexpr int kTStride = 68;   // floats per row of a wave's 16 x 64 output staging tile (64 + pad: conflict-free float4 writes)
+  float* const tbuf = wl + ((NB * (K >> 2) * 64 * (BF16 ? 2 : 4) + 15) / 16) * 4;   // behind the weight image
   // stage the weight in fragment order: entry (cb, s, lane=(j,kk)) = Wp[cb*16+j][16*(s/4) + 4*kk + (s%4)].
   // Global reads run along the weight's contiguous axis (k for the forward layout, n for the transposed one).
   {
@@ -105,22 +107,41 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
         for (int cb = 0; cb < NB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(cb * ksteps + s) * 64 + lane], ae[e], acc[cb], 0, 0, 0);
       }
     }
-    // C^T layout: column (lane & 15) -> row of Y, row (lane >> 4) * 4 + reg -> column of Y
-    {
+    // C^T layout: column (lane & 15) -> row of Y, row (lane >> 4) * 4 + reg -> column of Y: a lane holds four consecutive output columns
+    // of row i per column block, so a direct store instruction writes 16 rows x 64 B — half-line pieces, which is what bounds the
+    // output-heavy shapes (32 -> 128 / 208 features).  With 16-byte-aligned rows the tile goes through a wave-private LDS buffer instead,
+    // four column blocks (64 columns) at a time, and is stored as 4 rows x 256 contiguous bytes per instruction (+ bias on the way out).
+    if (vec_ok && (N & 3) == 0) {
+      float* const tb = tbuf + wave * (16 * kTStride);
+#pragma unroll
+      for (int g0 = 0; g0 < NB; g0 += 4) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (g0 + c < NB) *reinterpret_cast<f32x4*>(tb + i * kTStride + c * 16 + kk * 4) = acc[g0 + c];
+        __builtin_amdgcn_wave_barrier();
+        const int col = g0 * 16 + (lane & 15) * 4;
+        if (col < N) {
+          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (bias) bv = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int r = (lane >> 4) + 4 * t;
+            const int64_t orow = rb * 16 + r;
+            const float4 v = *reinterpret_cast<const float4*>(tb + r * kTStride + (lane & 15) * 4);
+            if (orow < M) *reinterpret_cast<float4*>(y + orow * ldy + col) = make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
       const int64_t orow = rb * 16 + i;
       if (orow < M) {
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
           const int n = cb * 16 + kk * 4;
-          if (vec_ok && n + 3 < N) {
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
-            *reinterpret_cast<float4*>(y + orow * ldy + n) = make_float4(acc[cb][0] + bv.x, acc[cb][1] + bv.y, acc[cb][2] + bv.z, acc[cb][3] + bv.w);
-          } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (n + r < N) y[orow * ldy + n + r] = acc[cb][r] + (bias ? bias[n + r] : 0.f);
-          }
+          for (int r = 0; r < 4; ++r)
+            if (n + r < N) y[orow * ldy + n + r] = acc[cb][r] + (bias ? bias[n + r] : 0.f);
         }
       }
     }
@@ -258,10 +279,16 @@ int tn_blocks(int64_t M) {
 template <int KQ, int NB>
 int launch_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, float* y, int64_t ldy, int64_t M,
                int N, int K, bool bf16, hipStream_t st) {
-  const size_t smem = (size_t)NB * (K / 4) * 64 * (bf16 ? sizeof(uint16_t) : sizeof(float));
+  const size_t wbytes = ((size_t)NB * (K / 4) * 64 * (bf16 ? sizeof(uint16_t) : sizeof(float)) + 15) / 16 * 16;
+  const size_t smem = wbytes + (size_t)kWaves * 16 * 68 * sizeof(float);   // weight image + one 16 x 64 output staging tile per wave
   ADNM_PROF("tsgemm_nt", st, 4.0 * ((double)M * (K + N) + (double)N * K));
-  if (bf16) tsgemm_nt_kernel<KQ, NB, true><<<nt_blocks(M, true), kBlock, smem, st>>>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, N, K);
-  else tsgemm_nt_kernel<KQ, NB, false><<<nt_blocks(M, false), kBlock, smem, st>>>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, N, K);
+  if (bf16) {
+    ADNM_ALLOW_LDS((tsgemm_nt_kernel<KQ, NB, true>), smem, "tsgemm_nt");   // > 64 KB of dynamic LDS for the widest weights: per-device opt-in
+    tsgemm_nt_kernel<KQ, NB, true><<<nt_blocks(M, true), kBlock, smem, st>>>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, N, K);
+  } else {
+    ADNM_ALLOW_LDS((tsgemm_nt_kernel<KQ, NB, false>), smem, "tsgemm_nt");
+    tsgemm_nt_kernel<KQ, NB, false><<<nt_blocks(M, false), kBlock, smem, st>>>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, N, K);
+  }
   return ADNM_OK;
 }
 
