@@ -216,22 +216,41 @@ __global__ __launch_bounds__(kBlock) void tokmean_bwd_kernel(const float* __rest
 
 // nn.Conv1d(1, 1, 3, padding=1) over the channel axis of (B, n) (get_all_att, model_untils.py:548,592): one workgroup.
 // fwd: y = w0 x[i-1] + w1 x[i] + w2 x[i+1] + b.  bwd: dx, dw[3], db in the same pass (block reduction, no partials).
-__global__ __launch_bounds__(kBlock) void conv1d3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                         const float* __restrict__ dy, float* __restrict__ y, float* __restrict__ dx,
-                                                         float* __restrict__ dwb, int B, int n) {
-  __shared__ float sm[4][kBlock / 64];
+// One workgroup of 1024 lanes, four elements in flight per lane: this is ~8.5 K elements behind a chain of dependent loads (as a
+// 256-lane loop of 34 trips it took 30 us).
+constexpr int kC1Threads = 1024;
+__global__ __launch_bounds__(kC1Threads) void conv1d3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             const float* __restrict__ dy, float* __restrict__ y, float* __restrict__ dx,
+                                                             float* __restrict__ dwb, int B, int n) {
+  __shared__ float sm[4][kC1Threads / 64];
   const float w0 = w[0], w1 = w[1], w2 = w[2], bv = bias ? bias[0] : 0.f;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, ab = 0.f;
-  for (int idx = threadIdx.x; idx < B * n; idx += kBlock) {
-    const int i = idx % n;
-    if (!dy) {
-      const float xm = i > 0 ? x[idx - 1] : 0.f, xp = i + 1 < n ? x[idx + 1] : 0.f;
-      y[idx] = fmaf(w0, xm, fmaf(w1, x[idx], fmaf(w2, xp, bv)));
-    } else {
-      const float gm = i > 0 ? dy[idx - 1] : 0.f, gp = i + 1 < n ? dy[idx + 1] : 0.f, g = dy[idx];
-      dx[idx] = fmaf(w0, gp, fmaf(w1, g, w2 * gm));
-      const float xm = i > 0 ? x[idx - 1] : 0.f, xp = i + 1 < n ? x[idx + 1] : 0.f;
-      a0 = fmaf(g, xm, a0); a1 = fmaf(g, x[idx], a1); a2 = fmaf(g, xp, a2); ab += g;
+  const int total = B * n;
+  for (int base = threadIdx.x; base < total; base += 4 * kC1Threads) {
+    float xm[4], xc[4], xp[4], gm[4], gc[4], gp[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {   // all loads of the four elements first
+      const int idx = base + u * kC1Threads, i = idx % n;
+      const bool ok = idx < total;
+      xm[u] = ok && i > 0 ? x[idx - 1] : 0.f;
+      xc[u] = ok ? x[idx] : 0.f;
+      xp[u] = ok && i + 1 < n ? x[idx + 1] : 0.f;
+      if (dy) {
+        gm[u] = ok && i > 0 ? dy[idx - 1] : 0.f;
+        gc[u] = ok ? dy[idx] : 0.f;
+        gp[u] = ok && i + 1 < n ? dy[idx + 1] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * kC1Threads;
+      if (idx >= total) break;
+      if (!dy) {
+        y[idx] = fmaf(w0, xm[u], fmaf(w1, xc[u], fmaf(w2, xp[u], bv)));
+      } else {
+        dx[idx] = fmaf(w0, gp[u], fmaf(w1, gc[u], w2 * gm[u]));
+        a0 = fmaf(gc[u], xm[u], a0); a1 = fmaf(gc[u], xc[u], a1); a2 = fmaf(gc[u], xp[u], a2); ab += gc[u];
+      }
     }
   }
   if (!dy) return;
@@ -242,7 +261,12 @@ __global__ __launch_bounds__(kBlock) void conv1d3_kernel(const float* __restrict
     if ((threadIdx.x & 63) == 0) sm[k][threadIdx.x >> 6] = acc[k];
   }
   __syncthreads();
-  if (threadIdx.x < 4) dwb[threadIdx.x] = (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]);
+  if (threadIdx.x < 4) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < kC1Threads / 64; ++q) t += sm[threadIdx.x][q];
+    dwb[threadIdx.x] = t;
+  }
 }
 
 unsigned grid_for(int64_t total) {
@@ -446,7 +470,7 @@ extern "C" int adnm_conv1d3_fwd(const float* x, const float* w, const float* bia
   ADNM_REQUIRE(B > 0 && n > 0 && B * n <= (1 << 20), "conv1d3_fwd: B*n = %lld outside (0, 2^20]", (long long)(B * n));
   hipStream_t st = (hipStream_t)stream;
   ADNM_PROF("conv1d3", st, 8.0 * B * n);
-  conv1d3_kernel<<<1, kBlock, 0, st>>>(x, w, bias, nullptr, y, nullptr, nullptr, (int)B, (int)n);
+  conv1d3_kernel<<<1, kC1Threads, 0, st>>>(x, w, bias, nullptr, y, nullptr, nullptr, (int)B, (int)n);
   ADNM_CHECK_LAUNCH("conv1d3_fwd");
   return ADNM_OK;
 }
@@ -456,7 +480,7 @@ extern "C" int adnm_conv1d3_bwd(const float* dy, const float* x, const float* w,
   ADNM_REQUIRE(B > 0 && n > 0 && B * n <= (1 << 20), "conv1d3_bwd: B*n = %lld outside (0, 2^20]", (long long)(B * n));
   hipStream_t st = (hipStream_t)stream;
   ADNM_PROF("conv1d3_bwd", st, 12.0 * B * n);
-  conv1d3_kernel<<<1, kBlock, 0, st>>>(x, w, nullptr, dy, nullptr, dx, dwb, (int)B, (int)n);
+  conv1d3_kernel<<<1, kC1Threads, 0, st>>>(x, w, nullptr, dy, nullptr, dx, dwb, (int)B, (int)n);
   ADNM_CHECK_LAUNCH("conv1d3_bwd");
   return ADNM_OK;
 }
