@@ -329,27 +329,6 @@ void slice(Plan& pl) {   // chunks per wave for (wpt, nbs), and the slice count 
   pl.nbs = (int)adnm_cdiv(adnm_cdiv(pl.nchunks, pl.cpw), pl.wpt);
 }
 
-// Weight-gradient op (TN): 64 x 64 tiles, ~2048 waves when the reduction is long enough (>= 1 chunk = 64 MFMAs per wave): up to 8 waves
-// of a block share a tile (summed in LDS), further slices go through partials kept below ~2 MB and the shared fold kernel, whose launch
-// is batched with the other parameter-gradient folds and deferred off the critical path.  direct: the output cannot take partials.
-Plan plan_deferred(int64_t I, int64_t J, int64_t R, bool direct) {
-  Plan pl;
-  pl.kernel = KERNEL_STREAM, pl.combine = false, pl.tm = pl.tn = 4, pl.kc = 1;
-  finish(pl, I, J, R);
-  int want = (int)adnm_cdiv(2048, pl.ntiles);
-  if (want > pl.nchunks) want = pl.nchunks;
-  if (want < 1) want = 1;
-  pl.wpt = 1;
-  while (pl.wpt * 2 <= want && pl.wpt < kWaves) pl.wpt *= 2;
-  int64_t nbs = adnm_cdiv(want, pl.wpt);
-  const int64_t by_mem = (int64_t)(2 << 20) / (I * J * 4);
-  if (nbs > by_mem) nbs = by_mem;
-  if (nbs < 1 || direct) nbs = 1;
-  pl.nbs = (int)nbs;
-  slice(pl);
-  return pl;
-}
-
 // measurement aid (tools/kbench_gemm.py sweeps it): ADNM_SK_FORCE="kernel,tm,tn,kc,wpt,nbs" overrides the NT / NN plan
 struct Forced {
   bool on = false;
@@ -389,7 +368,7 @@ bool config_ok(int op, const Plan& pl) {
 //   NN: the LDS-tiled kernel for >= 256 tiles or a reduction <= 128 steps; otherwise the streaming kernel, 16 (32 for >= 100 tiles of
 //       >= 256 rows) x 64 wave tiles, 8 waves per tile.
 struct Tuned {
-  int op, I, J, R, bf16;
+  int op, I, J, R, bf16;   // op 0 NT, 1 NN, 2 TN
   int cfg[6];   // kernel, tm, tn, kc, wpt, nbs
 };
 const Tuned kTuned[] = {
@@ -399,6 +378,42 @@ const Tuned* tuned(int op, int64_t I, int64_t J, int64_t R, bool bf16) {
   for (const Tuned& t : kTuned)
     if (t.op == op && t.I == I && t.J == J && t.R == R && t.bf16 == (int)bf16) return &t;
   return nullptr;
+}
+// Weight-gradient op (TN): 64 x 64 tiles (both operands are contiguous along their output axes).  The (waves per tile, slices) pair of a
+// config-2 shape comes from the measured table; otherwise ~2048 waves when the reduction is long enough (>= 1 chunk = 64 MFMAs per wave):
+// up to 8 waves of a block share a tile (summed in LDS), further slices go through partials kept below ~2 MB and the shared fold
+// kernel, whose launch is batched with the other parameter-gradient folds and deferred off the critical path.
+// direct: the output cannot take partials.
+Plan plan_deferred(int64_t I, int64_t J, int64_t R, bool direct, bool bf16) {
+  Plan pl;
+  pl.kernel = KERNEL_STREAM, pl.combine = false, pl.tm = pl.tn = 4, pl.kc = 1;
+  finish(pl, I, J, R);
+  const bool force = forced().on;
+  const Tuned* tu = force || use_table() == 0 ? nullptr : tuned(ADNM_SKGEMM_TN, I, J, R, bf16);
+  if (force || tu) {
+    const int* v = force ? forced().v : tu->cfg;
+    pl.wpt = v[4], pl.nbs = v[5];
+    if (v[0] != KERNEL_STREAM || v[1] != 4 || v[2] != 4 || v[3] != 1 || pl.wpt < 1 || pl.wpt > kWaves || (pl.wpt & (pl.wpt - 1))) {
+      pl.kernel = -1;
+      return pl;
+    }
+    while (pl.wpt > 1 && pl.wpt > pl.nchunks) pl.wpt >>= 1;
+  } else {
+    int want = (int)adnm_cdiv(2048, pl.ntiles);
+    if (want > pl.nchunks) want = pl.nchunks;
+    if (want < 1) want = 1;
+    pl.wpt = 1;
+    while (pl.wpt * 2 <= want && pl.wpt < kWaves) pl.wpt *= 2;
+    pl.nbs = (int)adnm_cdiv(want, pl.wpt);
+  }
+  if (!force && !tu) {
+    const int64_t by_mem = (int64_t)(2 << 20) / (I * J * 4);
+    if (pl.nbs > by_mem) pl.nbs = (int)by_mem;
+  }
+  if (pl.nbs > 64) pl.nbs = 64;
+  if (pl.nbs < 1 || direct) pl.nbs = 1;
+  slice(pl);
+  return pl;
 }
 Plan plan_critical(int op, int64_t I, int64_t J, int64_t R, bool can_split, bool bf16) {
   Plan pl;
@@ -438,7 +453,7 @@ Plan plan_critical(int op, int64_t I, int64_t J, int64_t R, bool can_split, bool
   return pl;
 }
 Plan make_plan(int op, int64_t I, int64_t J, int64_t R, bool direct, bool bf16) {
-  return op == ADNM_SKGEMM_TN ? plan_deferred(I, J, R, direct) : plan_critical(op, I, J, R, !direct && J % 4 == 0, bf16);
+  return op == ADNM_SKGEMM_TN ? plan_deferred(I, J, R, direct, bf16) : plan_critical(op, I, J, R, !direct && J % 4 == 0, bf16);
 }
 
 // Arrival counters of the in-launch combine: a per-device ring of zero-initialised ints owned by the library (allocated on the first

@@ -38,7 +38,7 @@ cold = os.environ.get("COLD") == "1"
 FLUSH = torch.empty(1 << 28, dtype=torch.float32, device="cuda") if cold else None
 
 
-def graph_time(fn, nvar=1):
+def graph_time(fn, nvar=1, defer=False):
     """fn(i): launch with operand copy i (i < nvar)"""
     fn(0)
     torch.cuda.synchronize()
@@ -48,8 +48,10 @@ def graph_time(fn, nvar=1):
         fn(0)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
-            for r in range(reps):
-                fn(r % nvar)
+            # the weight-gradient op defers its split-K folds exactly as under the trainer: queued, batched, flushed at the end
+            with ops.FOLDS.active(torch.device(dev, torch.cuda.current_device()), defer):
+                for r in range(reps):
+                    fn(r % nvar)
     torch.cuda.current_stream().wait_stream(s)
     g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -98,12 +100,13 @@ for op, M, N, K in shapes:
         ops.set_mfma_precision(prec)
         c.fill_(float("nan"))
         try:
-            t = graph_time(lambda i: ops._skgemm(OPC[op], a, bs[i], None, c, None, M, N, K), nvar)
+            t = graph_time(lambda i: ops._skgemm(OPC[op], a, bs[i], None, c, None, M, N, K, defer=(op == "TN")), nvar, defer=(op == "TN"))
         except RuntimeError as e:   # a forced configuration this op has no kernel for
             txt.append(f"sk {prec:4s}    n/a")
             continue
         err = ((c.double() - ref).norm() / ref.norm()).item()
-        ok = err <= (2e-6 if prec == "f32" else 1e-2)
+        red = K if op == "NT" else (N if op == "NN" else M)   # fp32 summation noise grows with the reduction length
+        ok = err <= ((2e-6 if red <= 4096 else 1e-5) if prec == "f32" else 1e-2)
         bad += 0 if ok else 1
         row[prec] = t if ok else None
         tot[prec] += t
