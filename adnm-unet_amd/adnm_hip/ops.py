@@ -835,26 +835,30 @@ class ADNMixerFn(torch.autograd.Function):
       w_in   (d_in_proj, dm): in_proj rows reordered to [z | x' | B' | C' | dt]; x' pairs the even/odd
              channel halves as alternating heads (head 2j+e <- half e, head j), B'/C' = [even | odd], so the
              reference's index_select gathers (ADNssd.py:329-341,375-386) vanish and K1 runs ONCE with G=2.
-      cw     (9, di+2gN) tap-major effective 3x3 taps of every xBC channel in that order: conv2d taps for the
-             even channels, outer(conv_31, conv_13) for the four asymmetric chains (ADNssd.py:343-346; with
-             no bias and zero padding a 3x1 o 1x3 chain IS a separable 3x3).
-      czw    (9, di) taps of conv2d_z;  ln_w/ln_b permuted like x';  w_out (dm, 2di) = alpha1 * out_proj
+      taps   (9, 2di+2gN) = [czw | cw], tap-major: czw (9, di) the taps of conv2d_z; cw (9, di+2gN) the effective 3x3 taps of
+             every xBC channel in kernel order: conv2d taps for the even channels, outer(conv_31, conv_13) for the four
+             asymmetric chains (ADNssd.py:343-346; with no bias and zero padding a 3x1 o 1x3 chain IS a separable 3x3).
+             z and xBC are adjacent column ranges of in_proj's output, so one depthwise launch applies both tap sets.
+      tb     the matching (2di+2gN) bias or None (the reference configuration has conv_bias=False);
+      ln_w/ln_b permuted like x';  w_out (dm, 2di) = alpha1 * out_proj
              with its y-columns permuted alike (ADNssd.py:459: alpha1 scales both halves).
     """
 
     @staticmethod
-    def forward(ctx, u, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk=0, scan_groups=2):
+    def forward(ctx, u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk=0, scan_groups=2):
         Bsz, L, dm = u.shape
         M = Bsz * L
-        di = czw.shape[1]
-        cx = cw.shape[1]  # di + 2gN
+        di = w_out.shape[1] // 2
+        cx = taps.shape[1] - di  # di + 2gN
         nh = di // P
         u2 = u.reshape(M, dm)
         u2 = u2 if u2.is_contiguous() else u2.contiguous()
-        proj = k_linear(u2, w_in, None)  # (M, 2di+2gN+nh): MFMA tall-skinny kernel at full resolution, library GEMM when tiny
-        cat = torch.empty((M, 2 * di), dtype=u.dtype, device=u.device)  # [LN(y) | silu(conv_z(z))]
-        k_dwconv_fwd(proj[:, :di], czw, czb, Bsz, H, W, di, 3, lib.ACT_SILU, y=cat[:, di:])
-        xbc = k_dwconv_fwd(proj[:, di:di + cx], cw, cb, Bsz, H, W, cx, 3, lib.ACT_SILU)
+        proj = k_linear(u2, w_in, None)  # (M, 2di+2gN+nh) = [z | xBC | dt]
+        # one wide buffer [LN(y) | silu(conv_z(z)) | silu(conv(xBC))]: its first 2di columns are out_proj's input, the rest K1's operands;
+        # z and xBC are adjacent in `proj` and their conv outputs adjacent here, so ONE depthwise launch (taps = [czw | cw]) does both
+        wide = torch.empty((M, 2 * di + cx), dtype=u.dtype, device=u.device)
+        cat, xbc = wide[:, :2 * di], wide[:, 2 * di:]
+        k_dwconv_fwd(proj[:, :di + cx], taps, tb, Bsz, H, W, di + cx, 3, lib.ACT_SILU, y=wide[:, di:])
         if scan_chunk == 0:   # linear_attn_duality=True: the global reduction (K1), both halves in one launch
             if di == 64:   # the token row is one head block: LayerNorm(y) (ADNssd.py:456) rides in pass 2's epilogue (refiner mixers)
                 y, kv, mu, rstd = k_ssd_fwd(xbc[:, :di], xbc[:, di:di + 2 * N], xbc[:, di + 2 * N:], proj[:, di + cx:], dt_bias, A_log, D,
@@ -873,22 +877,26 @@ class ADNMixerFn(torch.autograd.Function):
         if mu is None:
             _, mu, rstd = k_rownorm_fwd(y, ln_w, ln_b, None, None, 1e-5, True, out=cat[:, :di])
         out = k_linear(cat, w_out, None)
-        ctx.save_for_backward(u2, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, proj, xbc, y, kv, mu, rstd, cat)
+        ctx.save_for_backward(u2, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, proj, wide, y, kv, mu, rstd)
         ctx.dims = (Bsz, L, dm, H, W, P, N, di, cx, nh, scan_chunk, scan_groups)
         return out.view(Bsz, L, dm)
 
     @staticmethod
     def backward(ctx, dout):
-        (u2, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, proj, xbc, y, kv, mu, rstd, cat) = ctx.saved_tensors
+        (u2, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, proj, wide, y, kv, mu, rstd) = ctx.saved_tensors
         Bsz, L, dm, H, W, P, N, di, cx, nh, scan_chunk, scan_groups = ctx.dims
         M = Bsz * L
+        cat, xbc = wide[:, :2 * di], wide[:, 2 * di:]
         do = dout.reshape(M, dm)
         do = do if do.is_contiguous() else do.contiguous()
         dw_out, _ = k_linear_dw(do, cat, False)
-        dcat = k_linear_dx(do, w_out)  # (M, 2di)
+        # the gradient of `wide`, laid out alike: out_proj's input gradient fills the first 2di columns, K1's backward the rest, and the
+        # merged depthwise backward reads [d zc | d xbc] as one column range
+        dwide = torch.empty_like(wide)
+        dcat, dxbc = dwide[:, :2 * di], dwide[:, 2 * di:]
+        k_linear_dx(do, w_out, out=dcat)
         dy, dln_w, dln_b, _, _ = k_rownorm_bwd(dcat[:, :di], y, ln_w, ln_b, None, mu, rstd, True, True, False, defer=True)
         dproj = torch.empty_like(proj)
-        dxbc = torch.empty_like(xbc)
         if scan_chunk == 0:
             ddtb, dA, dD = k_ssd_bwd(dy, xbc[:, :di], xbc[:, di:di + 2 * N], xbc[:, di + 2 * N:], proj[:, di + cx:], dt_bias, A_log, D, kv,
                                      dxbc[:, :di], dxbc[:, di:di + 2 * N], dxbc[:, di + 2 * N:], dproj[:, di + cx:], Bsz, L, nh, P, N, 2)
@@ -900,17 +908,15 @@ class ADNMixerFn(torch.autograd.Function):
                                     dxbc[:, di + 2 * N + e * N:di + 2 * N + (e + 1) * N], dproj[:, di + cx + e:], 2, Bsz, L, nh // 2, P, Ns,
                                     scan_groups, scan_chunk, e == 1) for e in (0, 1)]
             ddtb, dA, dD = (torch.stack((parts[0][k], parts[1][k]), dim=1).reshape(nh) for k in range(3))
-        _, dcw, dcb = k_dwconv_bwd(dxbc, proj[:, di:di + cx], cw, cb, Bsz, H, W, cx, 3, lib.ACT_SILU, dx=dproj[:, di:di + cx],
-                                   want_bias=cb is not None)
-        _, dczw, dczb = k_dwconv_bwd(dcat[:, di:], proj[:, :di], czw, czb, Bsz, H, W, di, 3, lib.ACT_SILU, dx=dproj[:, :di],
-                                     want_bias=czb is not None)
+        _, dtaps, dtb = k_dwconv_bwd(dwide[:, di:], proj[:, :di + cx], taps, tb, Bsz, H, W, di + cx, 3, lib.ACT_SILU, dx=dproj[:, :di + cx],
+                                     want_bias=tb is not None)
         du = k_linear_dx(dproj, w_in)
         dw_in, _ = k_linear_dw(dproj, u2, False)
-        return (du.view(Bsz, L, dm), dw_in, dcw, dcb, dczw, dczb, ddtb, dA, dD, dln_w, dln_b, dw_out, None, None, None, None, None, None)
+        return (du.view(Bsz, L, dm), dw_in, dtaps, dtb, ddtb, dA, dD, dln_w, dln_b, dw_out, None, None, None, None, None, None)
 
 
-def adn_mixer(u, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk=0, scan_groups=2):
-    return ADNMixerFn.apply(u, w_in, cw, cb, czw, czb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk, scan_groups)
+def adn_mixer(u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk=0, scan_groups=2):
+    return ADNMixerFn.apply(u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk, scan_groups)
 
 
 class LinCombFn(torch.autograd.Function):
@@ -985,7 +991,9 @@ def lincomb(xs, scalars, gamma=None):
 
 class AdnPrepFn(torch.autograd.Function):
     """Reference-layout ADN-SSD parameters -> the kernel-layout tensors ADNMixerFn consumes (one HIP launch each way;
-    see csrc/paramprep.hip).  Argument order = the `params[15]` table of include/adnm_hip.h."""
+    see csrc/paramprep.hip).  Argument order = the `params[15]` table of include/adnm_hip.h.
+    Returns (w_in, taps, ln_w, ln_b, w_out): `taps` (9, 2di+2gN) = [czw | cw], the tap-major 3x3 taps of conv2d_z and of every xBC
+    channel side by side, so that z and xBC — adjacent column ranges of in_proj's output — go through ONE depthwise launch."""
 
     @staticmethod
     def forward(ctx, dm, di, gn, P, *params):
@@ -994,24 +1002,27 @@ class AdnPrepFn(torch.autograd.Function):
         _need_gpu(params[0])
         nh, cx = di // P, di + 2 * gn
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-        outs = [f(2 * di + 2 * gn + nh, dm), f(9, cx), f(9, di), f(di), f(di), f(dm, 2 * di)]
-        lib.call("adnm_adnprep_fwd", lib.ptr_table(params), lib.ptr_table(outs), dm, di, gn, P, _stream())
+        w_in, taps, ln_w, ln_b, w_out = f(2 * di + 2 * gn + nh, dm), f(9, di + cx), f(di), f(di), f(dm, 2 * di)
+        outs = [w_in, taps[:, di:], taps[:, :di], ln_w, ln_b, w_out]   # the ABI's table: {w_in, cw, czw, ln_w, ln_b, w_out}
+        lib.call("adnm_adnprep_fwd", lib.ptr_table(params), lib.ptr_table(outs), dm, di, gn, P, di + cx, _stream())
         ctx.save_for_backward(*params)
         ctx.dims = (dm, di, gn, P)
-        return tuple(outs)
+        return w_in, taps, ln_w, ln_b, w_out
 
     @staticmethod
-    def backward(ctx, *gouts):
+    def backward(ctx, g_w_in, g_taps, g_ln_w, g_ln_b, g_w_out):
         params = ctx.saved_tensors
         dm, di, gn, P = ctx.dims
+        cx = di + 2 * gn
         FOLDS.flush(params[0].device)   # the incoming gradients are (deferred) fold results of the mixer's backward
-        gouts = [g.contiguous() for g in gouts]
+        g_w_in, g_taps, g_ln_w, g_ln_b, g_w_out = (g.contiguous() for g in (g_w_in, g_taps, g_ln_w, g_ln_b, g_w_out))
+        gouts = [g_w_in, g_taps[:, di:], g_taps[:, :di], g_ln_w, g_ln_b, g_w_out]
         dparams = [grad_dst(p.data_ptr(), p.shape, p.device, p.dtype) for p in params]
         nb = lib.query("adnm_adnprep_bwd_ws_bytes")
         ws = _ws(nb, params[0].device)
-        with FOLDS.defer(params[0].device, ws, *gouts):
-            lib.call("adnm_adnprep_bwd", lib.ptr_table(params), lib.ptr_table(gouts), lib.ptr_table(dparams), dm, di, gn, P, ws.data_ptr(), nb,
-                     _stream())
+        with FOLDS.defer(params[0].device, ws, g_w_in, g_taps, g_ln_w, g_ln_b, g_w_out):
+            lib.call("adnm_adnprep_bwd", lib.ptr_table(params), lib.ptr_table(gouts), lib.ptr_table(dparams), dm, di, gn, P, di + cx,
+                     ws.data_ptr(), nb, _stream())
         return (None, None, None, None, *dparams)
 
 

@@ -17,7 +17,7 @@ void adnm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* adnm_last_error(void) { return g_err; }
-extern "C" int adnm_abi_version(void) { return 5; }   // 5: adnm_tsgemm_nt takes `prec`; 4: adnm_colsum takes a workspace
+extern "C" int adnm_abi_version(void) { return 6; }   // 6: tap_ld of adnm_adnprep_*; 5: `prec` of adnm_tsgemm_nt; 4: workspace of adnm_colsum
 
 // ---- profiler: OFF by default (one relaxed atomic load per launch).  When bench.py enables it, every kernel
 // launch of the library is bracketed by hipEventRecord on the stream it is launched on; adnm_prof_collect()

@@ -20,6 +20,8 @@ constexpr int kMaxBlocks = 1024;
 
 struct AdnDims {
   int dm, di, gn, P, nh;  // d_model, d_inner, ngroups*d_state, headdim, nheads
+  int ldcw, ldcz;         // row strides (floats) of the two tap images cw (9, di + 2 gn) and czw (9, di): their widths, or one common
+                          // stride when both live side by side in a (9, 2 di + 2 gn) image [czw | cw] (one stencil launch for z and xBC)
 };
 
 // kernel-order xBC channel -> reference xBC channel, and back
@@ -84,10 +86,10 @@ __global__ __launch_bounds__(kBlock) void adn_prep_fwd_kernel(AdnParams p, AdnPr
         adn_chain_of(co, d, chain, row);
         v = p.c31[chain][row * 3 + t / 3] * p.c13[chain][row * 3 + t % 3];
       }
-      o.cw[j] = v;
+      o.cw[t * d.ldcw + ch] = v;
     } else if (i < n2) {
       const int j = (int)(i - n1), t = j / d.di, c = j - t * d.di;
-      o.czw[j] = p.conv2d_z[c * 9 + t];
+      o.czw[t * d.ldcz + c] = p.conv2d_z[c * 9 + t];
     } else if (i < n3) {
       const int j = (int)(i - n2);
       if (j < d.di) o.ln_w[j] = p.ln_w[adn_fwd_map(j, d)];
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void adn_prep_bwd_kernel(AdnParams p, AdnPr
       *reinterpret_cast<float4*>(dp.w_in + (int64_t)r * d.dm + c) = *reinterpret_cast<const float4*>(g.w_in + (int64_t)src * d.dm + c);
     } else if (i < n1) {
       const int j = (int)(i - n0), m = j / 9, t = j - m * 9;
-      dp.conv2d[j] = g.cw[t * cx + adn_inv_map(2 * m, d)];
+      dp.conv2d[j] = g.cw[t * d.ldcw + adn_inv_map(2 * m, d)];
     } else if (i < n2) {
       int j = (int)(i - n1);
       const int kind = j / nchain;  // 0: conv_31 (3x1, tap a = row), 1: conv_13 (1x3, tap b = column)
@@ -140,16 +142,16 @@ __global__ __launch_bounds__(kBlock) void adn_prep_bwd_kernel(AdnParams p, AdnPr
       float s = 0.f;
       if (kind == 0) {
 #pragma unroll
-        for (int b = 0; b < 3; ++b) s += g.cw[(tap * 3 + b) * cx + ch] * p.c13[chain][row * 3 + b];
+        for (int b = 0; b < 3; ++b) s += g.cw[(tap * 3 + b) * d.ldcw + ch] * p.c13[chain][row * 3 + b];
         dp.c31[chain][row * 3 + tap] = s;
       } else {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) s += g.cw[(a * 3 + tap) * cx + ch] * p.c31[chain][row * 3 + a];
+        for (int a = 0; a < 3; ++a) s += g.cw[(a * 3 + tap) * d.ldcw + ch] * p.c31[chain][row * 3 + a];
         dp.c13[chain][row * 3 + tap] = s;
       }
     } else if (i < n3) {
       const int j = (int)(i - n2), c = j / 9, t = j - c * 9;
-      dp.conv2d_z[j] = g.czw[t * d.di + c];
+      dp.conv2d_z[j] = g.czw[t * d.ldcz + c];
     } else if (i < n4) {
       const int j = (int)(i - n3);
       if (j < d.di) dp.ln_w[j] = g.ln_w[adn_inv_map(j, d)];
@@ -265,11 +267,13 @@ static AdnPrepped adn_prepped(float* const* a) {
 }
 
 extern "C" int adnm_adnprep_fwd(float* const* params, float* const* prepped, int64_t d_model, int64_t d_inner, int64_t gn, int64_t headdim,
-                                adnm_stream_t stream) {
+                                int64_t tap_ld, adnm_stream_t stream) {
   ADNM_REQUIRE(params && prepped, "adnprep_fwd: null table");
   for (int k = 0; k < 15; ++k) ADNM_REQUIRE(params[k], "adnprep_fwd: params[%d] is null", k);
   for (int k = 0; k < 6; ++k) ADNM_REQUIRE(prepped[k], "adnprep_fwd: prepped[%d] is null", k);
-  AdnDims d{(int)d_model, (int)d_inner, (int)gn, (int)headdim, (int)(d_inner / (headdim > 0 ? headdim : 1))};
+  ADNM_REQUIRE(tap_ld == 0 || tap_ld >= d_inner + 2 * gn, "adnprep: tap_ld %lld < the width of the tap image", (long long)tap_ld);
+  AdnDims d{(int)d_model, (int)d_inner, (int)gn, (int)headdim, (int)(d_inner / (headdim > 0 ? headdim : 1)),
+            (int)(tap_ld ? tap_ld : d_inner + 2 * gn), (int)(tap_ld ? tap_ld : d_inner)};
   if (int rc = adn_check("adnprep_fwd", d)) return rc;
   const int64_t n = (int64_t)(2 * d.di + 2 * d.gn + d.nh) * d.dm + 9 * (d.di + 2 * d.gn) + 9 * d.di + 2 * d.di + (int64_t)d.dm * 2 * d.di;
   hipStream_t st = (hipStream_t)stream;
@@ -281,7 +285,7 @@ extern "C" int adnm_adnprep_fwd(float* const* params, float* const* prepped, int
 extern "C" int64_t adnm_adnprep_bwd_ws_bytes(void) { return kMaxBlocks * (int64_t)sizeof(float); }
 
 extern "C" int adnm_adnprep_bwd(float* const* params, float* const* gprepped, float* const* dparams, int64_t d_model, int64_t d_inner,
-                                int64_t gn, int64_t headdim, void* ws, int64_t ws_bytes, adnm_stream_t stream) {
+                                int64_t gn, int64_t headdim, int64_t tap_ld, void* ws, int64_t ws_bytes, adnm_stream_t stream) {
   ADNM_REQUIRE(params && gprepped && dparams, "adnprep_bwd: null table");
   for (int k = 0; k < 15; ++k) ADNM_REQUIRE(params[k] && dparams[k], "adnprep_bwd: params/dparams[%d] is null", k);
   for (int k = 0; k < 6; ++k) ADNM_REQUIRE(gprepped[k], "adnprep_bwd: gprepped[%d] is null", k);
@@ -289,7 +293,9 @@ extern "C" int adnm_adnprep_bwd(float* const* params, float* const* gprepped, fl
     adnm_set_error("adnprep_bwd: workspace too small");
     return ADNM_EWORKSPACE;
   }
-  AdnDims d{(int)d_model, (int)d_inner, (int)gn, (int)headdim, (int)(d_inner / (headdim > 0 ? headdim : 1))};
+  ADNM_REQUIRE(tap_ld == 0 || tap_ld >= d_inner + 2 * gn, "adnprep: tap_ld %lld < the width of the tap image", (long long)tap_ld);
+  AdnDims d{(int)d_model, (int)d_inner, (int)gn, (int)headdim, (int)(d_inner / (headdim > 0 ? headdim : 1)),
+            (int)(tap_ld ? tap_ld : d_inner + 2 * gn), (int)(tap_ld ? tap_ld : d_inner)};
   if (int rc = adn_check("adnprep_bwd", d)) return rc;
   const int cx = d.di + 2 * d.gn;
   const int64_t n = (int64_t)(2 * d.di + 2 * d.gn + d.nh) * d.dm + (int64_t)(cx / 2) * 9 + 2 * 2 * (d.di / 4 + d.gn / 2) * 3 + 9 * d.di + 2 * d.di +

@@ -157,10 +157,10 @@ class Mamba2(nn.Module):
         if self.learnable_init_states:
             raise NotImplementedError("learnable_init_states is only meaningful on the chunked-scan branch")
         # one HIP launch builds the kernel-layout tensors (csrc/paramprep.hip); _effective_taps()/_rows_in state the same map in torch
-        w_in, cw, czw, ln_w, ln_b, w_out = ops.adn_prep(
+        w_in, taps, ln_w, ln_b, w_out = ops.adn_prep(
             self.d_model, self.d_inner, self.ngroups * self.d_state, self.headdim,
             [self.in_proj.weight, self.conv2d.weight, self.conv_31_x1.weight, self.conv_31_bc1.weight, self.conv_31_x2.weight,
              self.conv_31_bc2.weight, self.conv_13_x1.weight, self.conv_13_bc1.weight, self.conv_13_x2.weight, self.conv_13_bc2.weight,
              self.conv2d_z.weight, self.norm.weight, self.norm.bias, self.out_proj.weight, self.alpha1])
-        return ops.adn_mixer(u, w_in, cw, None, czw, None, self.dt_bias, self.A_log, self.D, ln_w, ln_b, w_out, H, W,
+        return ops.adn_mixer(u, w_in, taps, None, self.dt_bias, self.A_log, self.D, ln_w, ln_b, w_out, H, W,
                              self.headdim, self.ngroups * self.d_state // 2, scan_chunk, self.ngroups)

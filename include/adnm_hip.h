@@ -412,12 +412,15 @@ int adnm_tsgemm_tn(const float* dy, int64_t lddy, const float* x, int64_t ldx, f
  *   params[15]  = {in_proj.weight, conv2d.weight, conv_31_x1, conv_31_bc1, conv_31_x2, conv_31_bc2, conv_13_x1,
  *                  conv_13_bc1, conv_13_x2, conv_13_bc2, conv2d_z.weight, norm.weight, norm.bias, out_proj.weight, alpha1}
  *   prepped[6]  = {w_in (d_in_proj,dm), cw (9,di+2gn), czw (9,di), ln_w (di), ln_b (di), w_out (dm,2di)}
- * All fp32 device pointers; the tables themselves are host arrays.  gn = ngroups*d_state. */
+ * All fp32 device pointers; the tables themselves are host arrays.  gn = ngroups*d_state.
+ * tap_ld: row stride (floats) of BOTH tap images, 0 = dense (di+2gn resp. di).  With tap_ld = 2di+2gn, czw = T and cw = T + di are
+ * the two column ranges of ONE (9, 2di+2gn) image T = [czw | cw]: the taps of a single depthwise launch over [z | xBC]. */
 int adnm_adnprep_fwd(float* const* params, float* const* prepped, int64_t d_model, int64_t d_inner, int64_t gn,
-                     int64_t headdim, adnm_stream_t stream);
+                     int64_t headdim, int64_t tap_ld, adnm_stream_t stream);
 int64_t adnm_adnprep_bwd_ws_bytes(void);
 int adnm_adnprep_bwd(float* const* params, float* const* gprepped, float* const* dparams, int64_t d_model,
-                     int64_t d_inner, int64_t gn, int64_t headdim, void* ws, int64_t ws_bytes, adnm_stream_t stream);
+                     int64_t d_inner, int64_t gn, int64_t headdim, int64_t tap_ld, void* ws, int64_t ws_bytes,
+                     adnm_stream_t stream);
 /* WTConv2d: taps[k] (K*K, Cgp) = tap-major( w[k] (Cg,K*K) * s[k] (Cg) ), zero-padded from C to Cp channels
  * (Cg = C for k = 0, the base conv; 4C for the level convs k = 1..levels), bias_t = bias * s[0]
  * (WTConv2d.py:123,146).  bwd: dw, ds, dbias from the tap gradients. */
