@@ -22,10 +22,14 @@ class RadarIngest:
         self.ready = [torch.cuda.Event() for _ in range(2)]
         self.consumed = [torch.cuda.Event() for _ in range(2)]
         self._slot = 0
-        self._pending = None
+        self._pending = []            # FIFO of submitted, not yet taken slots (prefetch depth <= 2 = the number of slots)
 
     def submit(self, batch_u8):
-        """Start moving a (B, T, H0, W0) uint8 batch (numpy array or CPU tensor) to the device; returns at once."""
+        """Start moving a (B, T, H0, W0) uint8 batch (numpy array or CPU tensor) to the device; returns at once.
+        At most two batches may be in flight (one per slot): a third submit() without a take() raises instead of overwriting a
+        staging buffer whose host-to-device copy may still be running."""
+        if len(self._pending) >= 2:
+            raise RuntimeError("RadarIngest.submit(): both staging slots hold batches that were never taken (prefetch depth is 2)")
         s = self._slot
         self._slot ^= 1
         src = torch.from_numpy(batch_u8) if isinstance(batch_u8, np.ndarray) else batch_u8
@@ -36,14 +40,13 @@ class RadarIngest:
         with torch.cuda.stream(self.copy_stream):
             self.dev[s].copy_(self.pinned[s], non_blocking=True)
             self.ready[s].record(self.copy_stream)
-        self._pending = s
+        self._pending.append(s)
 
     def take(self):
         """-> (imgs (B, T_in, 1, S, S), targets (B, T_out, 1, S, S)) fp32 on the device, as train.py:133 splits them."""
-        s = self._pending
-        if s is None:
+        if not self._pending:
             raise RuntimeError("RadarIngest.take() without a submitted batch")
-        self._pending = None
+        s = self._pending.pop(0)
         B, T, H0, W0 = self.shape
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(self.ready[s])

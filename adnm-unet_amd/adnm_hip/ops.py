@@ -76,30 +76,40 @@ class GradRegistry:
     through here at once and must not see each other's claims."""
 
     def __init__(self):
-        self._lock = threading.Lock()
+        # re-entrant: register() / take() allocate GC-tracked objects under the lock, so the cyclic collector can run there and
+        # finalise a dead trainer whose __del__ comes back in through drop() on the SAME thread
+        self._lock = threading.RLock()
         self._dst = {}       # data_ptr -> (owner id, view into the owner's flat gradient buffer)
         self._claimed = {}   # owner id -> set of data_ptrs claimed in the running backward pass
         self._multi = {}     # owner id -> data_ptrs claimed more than once (autograd summed several contributions)
+        self._dead = []      # owner ids dropped from a finaliser: list.append is atomic, no lock taken there
+
+    def _drain(self):
+        """(lock held) forget the owners whose trainers have been finalised since the last call"""
+        while self._dead:
+            owner = self._dead.pop()
+            for ptr in [k for k, (o, _) in self._dst.items() if o == owner]:
+                del self._dst[ptr]
+            self._claimed.pop(owner, None)
+            self._multi.pop(owner, None)
 
     def register(self, owner, mapping):
         with self._lock:
-            self.drop(owner, locked=True)
+            self._dead.append(owner)
+            self._drain()
             for ptr, view in mapping.items():
                 self._dst[ptr] = (owner, view)
             self._claimed[owner] = set()
             self._multi[owner] = set()
 
-    def drop(self, owner, locked=False):
-        if not locked:
-            with self._lock:
-                return self.drop(owner, locked=True)
-        for ptr in [k for k, (o, _) in self._dst.items() if o == owner]:
-            del self._dst[ptr]
-        self._claimed.pop(owner, None)
-        self._multi.pop(owner, None)
+    def drop(self, owner):
+        """Lock-free (callable from __del__, i.e. from inside the collector on any thread): the owner is queued and its
+        entries disappear at the next register / take / reset_claims."""
+        self._dead.append(owner)
 
     def reset_claims(self, owner):
         with self._lock:
+            self._drain()
             if owner in self._claimed:
                 self._claimed[owner].clear()
                 self._multi[owner].clear()
@@ -109,13 +119,17 @@ class GradRegistry:
         with self._lock:
             return set(self._claimed.get(owner, ())) - self._multi.get(owner, set())
 
-    def take(self, ptr, shape, device, dtype=torch.float32):
+    def take(self, ptr, shape, device, dtype=torch.float32, strides=None):
+        """strides: the memory layout the caller is going to WRITE (element strides of `shape`); a registered slice laid out
+        differently is refused WITHOUT being recorded as claimed, so the trainer's gather still copies that gradient."""
         second = False
         with self._lock:
+            self._drain()
             ent = self._dst.get(ptr)
             if ent is not None:
                 owner, g = ent
-                if ptr not in self._claimed[owner] and tuple(g.shape) == tuple(shape) and g.dtype == dtype:
+                fits = tuple(g.shape) == tuple(shape) and g.dtype == dtype and (strides is None or tuple(g.stride()) == tuple(strides))
+                if ptr not in self._claimed[owner] and fits:
                     self._claimed[owner].add(ptr)
                     # a fresh tensor object on the same memory: AccumulateGrad only keeps ("steals") a gradient nobody else references
                     return g.detach()
@@ -170,6 +184,22 @@ class FoldRegistry:
         if ent is not None and ent.pop("hold", False):
             ent = None   # (a call that is not deferred is not moved to the side stream either: SIDE.submit checks deferring())
         return _Deferred(ent, keep, self._lock)
+
+    def abort(self, device):
+        """after an exception inside a backward pass / capture: deferral off, nothing launched, queued entries and kept workspaces
+        dropped (the C-side queue is emptied by a flush into a throw-away state only if something is still pending)"""
+        ent = self._q.get(device.index)
+        if ent is None:
+            return
+        ent["on"] = False
+        ent.pop("hold", None)
+        try:
+            lib.load().adnm_foldq_bind(None)
+            if lib.query("adnm_foldq_pending", ent["h"]) > 0:
+                lib.load().adnm_foldq_clear(ent["h"])
+        finally:
+            with self._lock:
+                ent["keep"].clear()
 
     def flush(self, device):
         ent = self._q.get(device.index)
@@ -277,6 +307,16 @@ class SideStreams:
                 with deferred:
                     fn()
         ent["dirty"] = True
+
+    def abort(self, device):
+        """after an exception: forget what was collected (nothing is launched), switch off"""
+        ent = self._s.get(device.index)
+        if ent is None:
+            return
+        with self._lock:
+            ent["on"] = False
+            ent["pending"] = []
+            ent["keep"].clear()
 
     def join(self, device):
         """launch what is still collected, then the current stream waits for everything on the side stream"""
@@ -1373,7 +1413,8 @@ class Conv3Fn(torch.autograd.Function):
                      wsb.data_ptr(), nb, B, H, W, K, N, MFMA_PREC[0], _stream())
             dx = dx.view(B, H * W, K)
         # the weight gradient is produced in (Cout, 3, 3, Cin) memory order: the flat trainer's channels-last slice takes it as it lies
-        g = grad_dst(w.data_ptr(), (N, K, 3, 3), dev)
+        # (a registered slice in any other layout is refused without being claimed: the trainer's gather then copies the gradient)
+        g = grad_dst(w.data_ptr(), (N, K, 3, 3), dev, strides=(9 * K, 1, 3 * K, K))
         if not g.permute(0, 2, 3, 1).is_contiguous():
             g = torch.empty((N, 3, 3, K), dtype=torch.float32, device=dev).permute(0, 3, 1, 2)
         db = grad_dst(b_ptr, (N,), dev) if has_bias else None
@@ -1429,8 +1470,9 @@ class ConvT2xFn(torch.autograd.Function):
         dcols = torch.empty((M, 9 * Cout), dtype=torch.float32, device=dev)
         lib.call("adnm_convt_im2col", dy2.data_ptr(), Cout, dcols.data_ptr(), 9 * Cout, ct, cc, B, H, W, Cout, _stream())
         dx = k_linear(dcols, wf, None).view(B, H * W, Cin) if ctx.needs_input_grad[0] else None
-        g = grad_dst(w_ptr, (Cin, Cout, 3, 3), dev)         # the trainer's slice has the weight's own memory order
-        if g.stride() != ((9 * Cout, 1, 3 * Cout, Cout) if cc == 1 else (9 * Cout, 9, 3, 1)):
+        want = (9 * Cout, 1, 3 * Cout, Cout) if cc == 1 else (9 * Cout, 9, 3, 1)
+        g = grad_dst(w_ptr, (Cin, Cout, 3, 3), dev, strides=want)   # the slice is taken only if it has the weight's own memory order
+        if g.stride() != want:
             g = torch.empty((Cin, 3, 3, Cout), dtype=torch.float32, device=dev).permute(0, 3, 1, 2) if cc == 1 else \
                 torch.empty((Cin, Cout, 3, 3), dtype=torch.float32, device=dev)
         k_linear_dw(x2, dcols, False, dw_out=torch.as_strided(g, (Cin, 9 * Cout), (9 * Cout, 1)))   # dWf = X^T . dcols
@@ -1536,6 +1578,47 @@ def igate(x, enhance, threshold):
     return IGateFn.apply(x, enhance, threshold)
 
 
+class IGateResFn(torch.autograd.Function):
+    """EncoderToDecoder's entry (model_untils.py:761-763): IntensityGate(x + gama * res), res the (B, 1, C) bridge gate broadcast over
+    the tokens — one pass each way (csrc/elementwise.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gama, enhance, threshold):
+        _need_gpu(x)
+        B, L, C = x.shape
+        x, r = x.contiguous(), res.reshape(B, C).contiguous()
+        y = torch.empty_like(x)
+        lib.call("adnm_igate_res_fwd", x.data_ptr(), r.data_ptr(), gama.data_ptr(), enhance.data_ptr(), threshold.data_ptr(), y.data_ptr(), B, L, C,
+                 _stream())
+        ctx.save_for_backward(x, r, gama, enhance, threshold)
+        ctx.rshape = res.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, r, gama, enhance, threshold = ctx.saved_tensors
+        B, L, C = x.shape
+        dev = x.device
+        dy = dy.contiguous()
+        dx, dres = torch.empty_like(x), torch.empty_like(r)
+        dg, de, dt = (grad_dst(p.data_ptr(), p.shape, dev) for p in (gama, enhance, threshold))
+        nb = lib.query("adnm_igate_res_bwd_ws_bytes", B, L, C)
+        ws = _ws(nb, dev)
+        with FOLDS.defer(dev, ws):   # d res is complete when the launch ends; only the three scalar gradients go through the fold
+            lib.call("adnm_igate_res_bwd", dy.data_ptr(), x.data_ptr(), r.data_ptr(), gama.data_ptr(), enhance.data_ptr(), threshold.data_ptr(),
+                     dx.data_ptr(), dres.data_ptr(), dg.data_ptr(), de.data_ptr(), dt.data_ptr(), ws.data_ptr(), nb, B, L, C, _stream())
+        return dx, dres.view(ctx.rshape), dg, de, dt
+
+
+def igate_res(x, res, gama, enhance, threshold):
+    _need_gpu(x)
+    B, L, C = x.shape
+    if x.dtype != torch.float32 or C % 4 or res.numel() != B * C or any(p.numel() != 1 for p in (gama, enhance, threshold)):
+        _unsupported("igate_res", f"needs fp32 (B, L, C) tokens with 4 | C, a (B, 1, C) gate and 1-element scalars, got {x.dtype} {tuple(x.shape)}, "
+                                  f"gate {tuple(res.shape)}")
+    return IGateResFn.apply(x, res, gama, enhance, threshold)
+
+
 class SkipGateFn(torch.autograd.Function):
     """EncoderToDecoder's three pooled, gated branches + their mix in 2 launches forward / 5-6 backward
     (csrc/skipgate.hip).  params: the 18 tensors in the order include/adnm_hip.h documents."""
@@ -1582,11 +1665,10 @@ class SkipGateFn(torch.autograd.Function):
         return (dx, None, None, dw0, db0, dw1, db1, dw2, db2, dfw13, dfb13, dfw33, dfb33, de13, dt13, de33, dt33, da[0], da[1], da[2], dgamma)
 
 
-def skipgate_supported(x):
-    return x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 256 == 0
-
-
 def skipgate(x, h, w, params):
+    _need_gpu(x)
+    if x.dtype != torch.float32 or x.dim() != 3 or x.shape[-1] % 4 or x.shape[1] != h * w:
+        _unsupported("skipgate", f"needs fp32 (B, H*W, C) tokens with 4 | C, got {x.dtype} {tuple(x.shape)} for a {h}x{w} map")
     return SkipGateFn.apply(x, h, w, *params)
 
 
@@ -1716,9 +1798,9 @@ class Attn4Fn(torch.autograd.Function):
         return dqkv, None, None
 
 
-def attn4_supported(qkv, heads):
-    return qkv.is_cuda and qkv.dtype == torch.float32 and qkv.dim() == 3 and qkv.shape[-1] == 12 * heads and qkv.shape[1] <= 2048
-
-
 def attn4(qkv, heads, scale):
+    _need_gpu(qkv)
+    if qkv.dtype != torch.float32 or qkv.dim() != 3 or qkv.shape[-1] != 12 * heads or qkv.shape[1] > 2048:
+        _unsupported("attn4", f"is soft-max attention with 4-wide heads over <= 2048 tokens on fp32 (B, L, 12*heads) qkv, got {qkv.dtype} "
+                              f"{tuple(qkv.shape)} for {heads} heads")
     return Attn4Fn.apply(qkv, heads, scale)

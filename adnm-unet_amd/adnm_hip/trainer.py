@@ -22,6 +22,8 @@ overlap=False) graphs A and B are ONE graph and there is one bucket.
   * reduce_dtype="bf16": the wire format of the collective is bf16 (146 MB instead of 292 MB); sums are formed by RCCL in
     bf16, the 1/world average and the return to fp32 happen in one HIP pass.
 """
+import gc
+
 import torch
 import torch.distributed as dist
 
@@ -68,6 +70,8 @@ class FlatTrainer:
         self.side_stream = side_stream
         self.used = None
         self.graph = self.graph2 = None
+        self.static_loss = self._carry = self.sx = self.st = None
+        self.flat_g = None
         self.buckets = []
         self._steps = 0
 
@@ -138,9 +142,27 @@ class FlatTrainer:
         if self.fused:
             self.ws = torch.empty(int(lib.query("adnm_adamw_ws_bytes")), dtype=torch.uint8, device=dev)
 
+    def close(self):
+        """Give back everything this trainer owns on the device, in a fixed order, NOW (not whenever the cyclic collector gets to
+        it): the captured graphs first (they reference graph-pool memory), then the tensors that live in that pool (the static loss
+        with its autograd graph, the stage hand-over, the static inputs), then the gradient-destination registration.  Idempotent;
+        __del__ calls it.  A round-2 run aborted (rc 134) because dead trainers of failed tests — kept alive by their tracebacks —
+        were finalised by the cyclic GC in the middle of a NEW trainer's warm-up / stream capture: destroying a hipGraph (and
+        freeing its private pool) while another capture is in flight on the device is not allowed by the runtime.  prepare()
+        therefore also collects BEFORE it starts and keeps the collector off until both captures have ended."""
+        self.graph2 = None
+        self.graph = None
+        self.static_loss = None
+        self._carry = None
+        self.sx = self.st = None
+        try:
+            ops.GRADS.drop(id(self))   # lock-free for a finaliser: queued, drained by the next register / take
+        except Exception:
+            pass
+
     def __del__(self):
         try:
-            ops.GRADS.drop(id(self))   # do not leave destinations of a dead trainer behind
+            self.close()
         except Exception:
             pass
 
@@ -188,7 +210,43 @@ class FlatTrainer:
         self._gather(len(self.late), len(self.used))
 
     def prepare(self, x, tgt):
-        """Dry-run backward (finds the parameters that receive gradients), flatten, and capture the graph(s)."""
+        """Dry-run backward (finds the parameters that receive gradients), flatten, and capture the graph(s).
+        Ownership: objects with device-side destructors that died earlier (old trainers, graphs of failed runs) are collected
+        BEFORE anything starts, and the cyclic collector stays off until the last capture has ended (see close()); an exception
+        on the way — inside a capture included — unbinds the fold queue, drops the half-built graphs and re-raises."""
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            self._prepare(x, tgt)
+        except BaseException:
+            self._abort_prepare()
+            raise
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _abort_prepare(self):
+        """After an exception in prepare(): torch.cuda.graph's __exit__ has already ended a capture in flight; what is left is
+        OUR state — the thread's fold-queue binding (a kernel wrapper may have died between bind and unbind), the deferral /
+        side-stream switches of this device, and the graph objects, which must not survive half-captured."""
+        try:
+            lib.load().adnm_foldq_bind(None)
+        except Exception:
+            pass
+        dev = self.flat_g.device if getattr(self, "flat_g", None) is not None else None
+        if dev is not None and dev.type == "cuda":
+            for reg in (ops.FOLDS, ops.SIDE):
+                try:
+                    reg.abort(dev)
+                except Exception:
+                    pass
+        self.graph2 = None
+        self.graph = None
+        self.static_loss = None
+        self._carry = None
+
+    def _prepare(self, x, tgt):
         self.model.zero_grad(set_to_none=True)
         self._fwd_bwd(x, tgt)
         self._flatten()

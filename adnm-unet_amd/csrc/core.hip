@@ -256,6 +256,12 @@ extern "C" int adnm_foldq_bind(void* q) {
   return ADNM_OK;
 }
 extern "C" int64_t adnm_foldq_pending(void* q) { return q ? (int64_t)((FoldQueue*)q)->pending.size() : 0; }
+extern "C" int adnm_foldq_clear(void* q) {   // forget what is queued without launching it (the caller's error path)
+  ADNM_REQUIRE(q, "foldq_clear: null queue");
+  ((FoldQueue*)q)->pending.clear();
+  ((FoldQueue*)q)->names.clear();
+  return ADNM_OK;
+}
 extern "C" int adnm_foldq_flush(void* q, adnm_stream_t stream) {
   ADNM_REQUIRE(q, "foldq_flush: null queue");
   FoldQueue* fq = (FoldQueue*)q;

@@ -9,8 +9,8 @@
 // The reference runs ~30 library launches forward and ~70 backward for this on 4x4 .. 16x16 feature maps with
 // 256..1024 channels — pure launch latency on MI355X.  Here: 2 launches forward, 5-6 backward.  Tokens are channels-last
 // (B, H, W, C) fp32; a lane owns one conv GROUP (4 channels = one float4), so the grouped conv is a 4x4 matrix per tap
-// in registers, read straight from PyTorch's (C, 4, kh, kw) weight layout.  C % 256 == 0 (a wave never straddles
-// two pixels, which the in-wave scalar reductions rely on).
+// in registers, read straight from PyTorch's (C, 4, kh, kw) weight layout.  C % 4 == 0: lanes past the last (slice, group) pair
+// stay in their wave (the in-wave reductions need every lane) and contribute zeros.
 #include "adnm_common.h"
 
 namespace {
@@ -219,8 +219,8 @@ __global__ __launch_bounds__(kBlock) void skip_branch_bwd_kernel(const float* __
                                                                  float* __restrict__ dc1, float* __restrict__ dc2, float* __restrict__ dxa,
                                                                  float* __restrict__ vpart, float* __restrict__ spart, int S, Geo g) {
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (tid >= (int64_t)S * g.C4) return;
-  const int cg = (int)(tid % g.C4), s = (int)(tid / g.C4);
+  const bool valid = tid < (int64_t)S * g.C4;   // an idle lane keeps going: its wave's scalar sums are shuffled across all 64 lanes
+  const int cg = valid ? (int)(tid % g.C4) : 0, s = (int)(tid / g.C4);
   float gam[4], fw[2][4], fb[2][4], enh[2], thr[2], al[3];
   f4(ld4(P.gamma + cg * 4), gam);
 #pragma unroll
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void skip_branch_bwd_kernel(const float* __
   for (int j = 0; j < kScal; ++j) sacc[j] = 0.f;
   const float* cs[3] = {c0, c1, c2};
   float* dcs[3] = {dc0, dc1, dc2};
-  for (int64_t pix = s; pix < g.npix; pix += S) {
+  for (int64_t pix = valid ? s : g.npix; pix < g.npix; pix += S) {
     const int64_t off = (pix * g.C4 + cg) * 4;
     float G[4], xv[4], dxv[4] = {0.f, 0.f, 0.f, 0.f}, ysum[4] = {0.f, 0.f, 0.f, 0.f};
     f4(ld4(dout + off), G);
@@ -274,8 +274,11 @@ __global__ __launch_bounds__(kBlock) void skip_branch_bwd_kernel(const float* __
   }
   sacc[4] *= -enh[0];
   sacc[6] *= -enh[1];
+  if (valid) {
 #pragma unroll
-  for (int j = 0; j < kVec; ++j) st4(vpart + ((int64_t)s * kVec + j) * g.C + cg * 4, vacc[j]);
+    for (int j = 0; j < kVec; ++j) st4(vpart + ((int64_t)s * kVec + j) * g.C + cg * 4, vacc[j]);
+  }
+  // one partial row per WAVE (whatever slices its lanes belong to: the rows are only ever summed)
 #pragma unroll
   for (int j = 0; j < kScal; ++j) sacc[j] = wave_sum(sacc[j]);
   if ((threadIdx.x & 63) == 0) {
@@ -315,11 +318,13 @@ __device__ __forceinline__ void wgrad_block(const float* __restrict__ dc, const 
                                             int gchunk, int outer, int SW) {
   constexpr int T = Taps<K>::T;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane & 15, cg = gchunk * 16 + wave * 4 + (lane >> 4);
+  const int sub = lane & 15, cg_raw = gchunk * 16 + wave * 4 + (lane >> 4);
+  const bool valid = cg_raw < g.C4;   // the last chunk of a narrow map (C4 % 16 != 0): whole 16-lane rows idle, shuffles stay in-row
+  const int cg = valid ? cg_raw : 0;
   float acc[16 * T];
 #pragma unroll
   for (int e = 0; e < 16 * T; ++e) acc[e] = 0.f;
-  for (int64_t pix = sub + 16 * (int64_t)outer; pix < g.npix; pix += 16 * (int64_t)SW) {
+  for (int64_t pix = valid ? sub + 16 * (int64_t)outer : g.npix; pix < g.npix; pix += 16 * (int64_t)SW) {
     const int w = (int)(pix % g.W), h = (int)((pix / g.W) % g.H);
     float dv[4];
     f4(ld4(dc + pix * g.C + cg * 4), dv);
@@ -338,7 +343,7 @@ __device__ __forceinline__ void wgrad_block(const float* __restrict__ dc, const 
   }
 #pragma unroll
   for (int e = 0; e < 16 * T; ++e) acc[e] = group_sum(acc[e], 16);
-  if (sub == 0) {
+  if (sub == 0 && valid) {
     float* out = dw + (int64_t)cg * 16 * T;
 #pragma unroll
     for (int e = 0; e < 16 * T; e += 4) *reinterpret_cast<float4*>(out + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void skip_conv_bwd_kernel(const float* __re
     return;
   }
   // weight-gradient role: block -> (branch, chunk of 16 groups, outer pixel slice); partial row `outer` of (SW, 60 C)
-  const int nchunk = g.C4 / 16;
+  const int nchunk = (g.C4 + 15) / 16;
   int r = (int)blockIdx.x - ndg;
   const int k = r / (nchunk * SW);
   r -= k * nchunk * SW;
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(kBlock) void skip_conv_bwd_kernel(const float* __re
 // ------------------------------------------------------------------------------------------------ host side
 int make_geo(const char* who, int64_t B, int64_t H, int64_t W, int64_t C, Geo* g) {
   ADNM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "%s: empty shape", who);
-  ADNM_REQUIRE(C % 256 == 0, "%s: C=%lld must be a multiple of 256", who, (long long)C);
+  ADNM_REQUIRE(C % 4 == 0, "%s: C=%lld must be a multiple of 4 (one lane per 4-channel conv group)", who, (long long)C);
   ADNM_REQUIRE(B * H * W * C < (1ll << 31), "%s: tensor too large", who);
   g->B = (int)B, g->H = (int)H, g->W = (int)W, g->C = (int)C, g->C4 = (int)(C / 4);
   g->npix = B * H * W;
@@ -396,6 +401,7 @@ int load_params(const char* who, const float* const* params, Params* P) {
   return ADNM_OK;
 }
 int slices_pointwise(const Geo& g) { return (int)(g.npix < 4 ? 1 : (g.npix / 4 > 512 ? 512 : g.npix / 4)); }
+int64_t scal_rows(const Geo& g, int S) { return adnm_cdiv((int64_t)S * g.C4, kBlock) * (kBlock / 64); }   // one per launched wave
 int slices_wgrad(const Geo& g) { return (int)(g.npix / 64 < 1 ? 1 : (g.npix / 64 > 16 ? 16 : g.npix / 64)); }   // x 16 in-wave sub-slices
 struct WsLayout {
   int64_t tensors, vpart, spart, wpart, total;   // float offsets
@@ -407,7 +413,7 @@ WsLayout ws_layout(const Geo& g) {
   L.tensors = 0;
   L.vpart = 7 * n;
   L.spart = L.vpart + (int64_t)S * kVec * g.C;
-  L.wpart = L.spart + (int64_t)S * (g.C4 / 64) * kScal;
+  L.wpart = L.spart + scal_rows(g, S) * kScal;
   L.total = L.wpart + (SW > 1 ? (int64_t)SW * g.C * kWeightsPerChannel : 0);
   return L;
 }
@@ -470,11 +476,11 @@ extern "C" int adnm_skipgate_bwd(const float* dout, const float* x, const float*
                                                                                              dxa, vpart, spart, S, g);
   }
   adnm_launch_fold("skip_vec_fold", vpart, S, kVec * g.C, {dvec, kVec * g.C}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
-  adnm_launch_fold("skip_scal_fold", spart, S * (g.C4 / 64), kScal, {dscal, kScal}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
+  adnm_launch_fold("skip_scal_fold", spart, (int)scal_rows(g, S), kScal, {dscal, kScal}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
   const int ndg = (int)adnm_cdiv(g.npix * g.C4, kBlock);
   {
     ADNM_PROF("skip_conv_bwd", st, 4.0 * (9 * n + 2.0 * nwt));
-    skip_conv_bwd_kernel<<<(unsigned)(ndg + 3 * (g.C4 / 16) * SW), kBlock, 0, st>>>(
+    skip_conv_bwd_kernel<<<(unsigned)(ndg + 3 * ((g.C4 + 15) / 16) * SW), kBlock, 0, st>>>(
         dc0, dc1, dc2, pooled, pooled + n, pooled + 2 * n, P, g0, g1, g2, SW > 1 ? wpart : dwgt, ndg, SW, g);
   }
   if (SW > 1) adnm_launch_fold("skip_wgrad_fold", wpart, SW, nwt, {dwgt, nwt}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);

@@ -22,8 +22,8 @@ from adnm_hip import ops
 
 
 class StandardAttention(nn.Module):
-    """Soft-max attention with head_dim 4 (ADNssd.py:26-47 of the reference).  Tiny (L <= 256 here):
-    batched library GEMMs + softmax."""
+    """Soft-max attention with head_dim 4 (ADNssd.py:26-47 of the reference): to_qkv / to_out on the short-GEMM MFMA kernel,
+    the attention itself fused per head in LDS (csrc/attn4.hip)."""
 
     def __init__(self, dim, heads=8, dim_head=64, dropout=0., **kwargs):
         super().__init__()
@@ -37,14 +37,11 @@ class StandardAttention(nn.Module):
 
     def forward(self, x, H, W):
         b, n, _ = x.shape
+        if self.dropout.p != 0.0 and self.training:
+            raise RuntimeError("StandardAttention: the HIP attention kernel has no dropout (the reference configuration uses dropout=0)")
         qkv = ops.linear(x, self.to_qkv.weight, None)
-        if self.dropout.p == 0.0 and ops.attn4_supported(qkv, self.heads):   # 4-wide heads: fused, no (L, L) score tensor
-            return ops.linear(ops.attn4(qkv, self.heads, self.scale), self.to_out.weight, self.to_out.bias)
-        q, k, v = qkv.chunk(3, dim=-1)
-        sp = lambda t: t.reshape(b, n, self.heads, -1).transpose(1, 2)
-        att = self.dropout(torch.softmax(torch.matmul(sp(q), sp(k).transpose(-1, -2)) * self.scale, dim=-1))
-        out = torch.matmul(att, sp(v)).transpose(1, 2).reshape(b, n, self.inner_dim)
-        return ops.linear(out, self.to_out.weight, self.to_out.bias)
+        # 4-wide heads: fused, no (L, L) score tensor; any other head width raises (one code path, no PyTorch fallback)
+        return ops.linear(ops.attn4(qkv, self.heads, self.scale), self.to_out.weight, self.to_out.bias)
 
 
 def _dw(channels, k, pad, bias):

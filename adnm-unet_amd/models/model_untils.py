@@ -2,12 +2,12 @@
 (same class names, constructor arguments, forward signatures and state_dict keys).
 
 What runs where (DESIGN.md has the table): depthwise convs, the Haar wavelet pyramid (WTConv2d),
-InstanceNorm(+scalar affine, +GELU), BiasFree/Layer/RMS norms and the gated-FFN activation are
-hand-written HIP kernels working directly on the channels-last token layout (B, H*W, C) that the
-reference keeps between stages; dense 3x3 / transposed convs and the 1x1 / Linear projections are
-plain library GEMM/conv calls (rocBLAS / MIOpen through torch) on channels-last views.  Modules whose
-reference forward takes NCHW keep accepting NCHW; parents call the `*_tokens` methods so no
-BLD<->BCHW copies (13.5 % of the reference's CPU step) remain on the token path.
+InstanceNorm(+scalar affine, +GELU), BiasFree/Layer/RMS norms, the gated-FFN activation, the dense
+3x3 / transposed convs and the 1x1 / Linear projections are all hand-written HIP kernels (MFMA for the
+GEMM-shaped ones) working directly on the channels-last token layout (B, H*W, C) that the reference
+keeps between stages.  There is ONE code path: a configuration no kernel takes raises (no torch / library
+fallback).  Modules whose reference forward takes NCHW keep accepting NCHW; parents call the `*_tokens`
+methods so no BLD<->BCHW copies (13.5 % of the reference's CPU step) remain on the token path.
 """
 import math
 import numbers
@@ -114,7 +114,7 @@ class Mlp(nn.Module):
     def forward(self, x):
         h = ops.linear(x, self.fc1.weight, self.fc1.bias)
         code = _act_code(self.act1)
-        h = self.drop(ops.act(h, code) if code in (lib.ACT_GELU, lib.ACT_SILU) else self.act1(h))
+        h = self.drop(_apply_act(self.act1, h))
         return self.drop(ops.linear(h, self.fc2.weight, self.fc2.bias))
 
 
@@ -125,6 +125,16 @@ class Swish(nn.Module):
 
     def forward(self, x):
         return ops.swish(x, self.beta)   # one HIP pass each way (d beta through partials + the fold)
+
+
+def _apply_act(act, x):
+    """an activation that was not fused into the producing kernel: GELU / SiLU / Swish have HIP kernels, anything else raises"""
+    code = _act_code(act)
+    if code in (lib.ACT_GELU, lib.ACT_SILU):
+        return ops.act(x, code)
+    if isinstance(act, Swish):
+        return act(x)
+    raise RuntimeError(f"no HIP kernel for the activation {act} (GELU, SiLU and Swish are implemented; the HIP path has no PyTorch fallback)")
 
 
 def _act_code(act):
@@ -192,7 +202,7 @@ class Conv2dLayer(nn.Module):
         if self.norm:
             x, fused_act = self._norm_tokens(x, h, w, code)
         if self.act and not fused_act:
-            x = self.act(x)
+            x = _apply_act(self.act, x)
         return x
 
     def _norm_tokens(self, x, h, w, code):
@@ -200,7 +210,8 @@ class Conv2dLayer(nn.Module):
         if isinstance(n, nn.InstanceNorm2d) and not n.affine and not n.track_running_stats and x.shape[-1] % 4 == 0:
             fuse = code in (lib.ACT_NONE, lib.ACT_GELU)
             return ops.instnorm(x, self.scale, self.shift, n.eps, code if fuse else lib.ACT_NONE), fuse
-        return self.scale * tokens_of(n(nchw_view(x, h, w))) + self.shift, False
+        raise RuntimeError(f"Conv2dLayer: no HIP kernel for the norm {n} on {x.shape[-1]} channels (affine-less InstanceNorm2d on a multiple "
+                           "of 4 channels is implemented; the HIP path has no PyTorch fallback)")
 
     def _keeps_shape(self):
         c = self.conv
@@ -211,13 +222,9 @@ class Conv2dLayer(nn.Module):
         return all(2 * p == d * (k - 1) for p, d, k in zip(c.padding, c.dilation, c.kernel_size))
 
     def forward(self, x):
-        if not self._keeps_shape():  # shape-changing conv: generic library path, NCHW as the reference
-            if self.dropout:
-                x = self.dropout(x)
-            x = self.conv(x)
-            if self.norm:
-                x = self.scale * self.norm(x) + self.shift
-            return self.act(x) if self.act else x
+        if not self._keeps_shape():
+            raise RuntimeError(f"Conv2dLayer: no HIP kernel for the shape-changing conv {self.conv} (stride-1 'same' convs are implemented; the HIP "
+                               "path has no PyTorch fallback)")
         b, c, h, w = x.shape
         return nchw_view(self.forward_tokens(tokens_of(x), h, w), h, w)
 
@@ -248,9 +255,10 @@ class WTConvLayer(nn.Module):
                 x = ops.instnorm(x, self.scale, self.shift, n.eps, code)  # IN + scalar affine + GELU in one pass
                 fused = True
             else:
-                x = self.scale * tokens_of(n(nchw_view(x, h, w))) + self.shift
+                raise RuntimeError(f"WTConvLayer: no HIP kernel for the norm {n} with activation {self.act} on {x.shape[-1]} channels "
+                                   "(affine-less InstanceNorm2d [+ GELU] on a multiple of 4 channels is implemented; no PyTorch fallback)")
         if self.act and not fused:
-            x = self.act(x)
+            x = _apply_act(self.act, x)
         return x
 
     def forward(self, x):
@@ -283,14 +291,14 @@ class DeConv2dLayer(nn.Module):
         return [self.trans_conv.weight]
 
     def forward(self, x):
-        if self.dropout is not None:
-            x = self.dropout(x)
-        x = self.trans_conv(x)
-        if self.norm:
-            x = self.scale * self.norm(x) + self.shift
-        if self.act:
-            x = self.act(x)
-        return x
+        """x: (B, Cin, H, W) as the reference (model_untils.py:150-158) — runs the token kernel behind UpSample's configuration."""
+        c = self.trans_conv
+        if (c.stride != (2, 2) or c.kernel_size != (3, 3) or c.padding != (1, 1) or c.output_padding != (1, 1) or c.groups != 1 or self.norm
+                or self.act or self.dropout is not None):
+            raise RuntimeError(f"DeConv2dLayer: the HIP transposed conv is k=3, s=2, p=1, output_padding=1 without norm/act, got {c} "
+                               "(the HIP path has no PyTorch fallback)")
+        b, ci, h, w = x.shape
+        return nchw_view(ops.convt2x(tokens_of(x), c.weight, c.bias, h, w), 2 * h, 2 * w)
 
 
 class FeedForward(nn.Module):
@@ -390,7 +398,7 @@ class WTLayer(nn.Module):
         if residual is not None:
             x = ops.catmix(x, residual, None, self.gama1, self.gama2)
         elif features is not None:
-            x = x + self.gama3 * features
+            x = ops.lincomb([x, features], [None, self.gama3])
         b, l, d = x.shape
         h, w = _hw(l)
         x = ops.lincomb([self.wtconv.forward_tokens(x, h, w), x], [self.alpha, self.beta])
@@ -480,8 +488,9 @@ class Channel_Att_Bridge(nn.Module):
 
 
 class EncoderToDecoder(nn.Module):
-    """Skip-connection gating block (model_untils.py:620-794 of the reference).  Pools / grouped convs
-    run through the library on channels-last views; norm, FFN and ConvFFD use the HIP token kernels."""
+    """Skip-connection gating block (model_untils.py:620-794 of the reference): gate + InstanceNorm, the pooled / grouped-conv gating
+    core (csrc/skipgate.hip), FeedForward and ConvFFD — all HIP token kernels.  The nn.MaxPool2d / nn.AvgPool2d members only keep the
+    reference's module tree; nothing calls them."""
 
     def __init__(self, embed_dim=256, InstanceNorm=True):
         super().__init__()
@@ -516,57 +525,23 @@ class EncoderToDecoder(nn.Module):
         self.scale = nn.Parameter(torch.tensor(1.))
         self.shift = nn.Parameter(torch.tensor(0.))
 
-    def _avg_pools(self, x, h, w):
-        """AvgPool2d(k, stride 1, zero pad, count_include_pad=True) (model_untils.py:696-725) is a depthwise
-        conv with constant taps 1/|k|: runs on the HIP stencil, on tokens.  (torch-ROCm 2.10's avg_pool2d
-        backward is also wrong for channels-last views — measured rel. error 1.2-1.6 — one more reason.)"""
-        d = x.shape[-1]
-        if d % 4:
-            xi = nchw_view(x, h, w).contiguous()
-            return self.avg_pool_31(xi), self.avg_pool_13(xi), self.avg_pool_33(xi)
-        key = (x.device, x.dtype)
-        taps = self.__dict__.setdefault("_pool_taps", {}).get(key)
-        if taps is None:  # constants: built once per device
-            taps = torch.zeros((3, d, 1, 3, 3), dtype=torch.float32, device=x.device)
-            taps[0, :, 0, :, 1] = 1.0 / 3.0   # (3,1): a column
-            taps[1, :, 0, 1, :] = 1.0 / 3.0   # (1,3): a row
-            taps[2] = 1.0 / 9.0
-            self.__dict__["_pool_taps"][key] = taps
-        return tuple(nchw_view(ops.dwconv(x, taps[i], None, h, w, lib.ACT_NONE), h, w) for i in range(3))
-
-    @staticmethod
-    def _pw(layer, x):
-        """ffd13/ffd33: a 1x1 conv with groups == channels is a per-channel scale + bias."""
-        return x * layer.conv.weight.reshape(-1) + layer.conv.bias
-
     def forward(self, x, res):
         """x: (B, L, d) skip; res: the bridge gate, (B, 1, d) or (B, L, d)."""
         b, l, d = x.shape
         h, w = _hw(l)
-        x = self.act(x + self.gama * res)
-        if isinstance(self.norm, nn.InstanceNorm2d) and d % 4 == 0:
-            x = ops.instnorm(x, self.scale, self.shift, self.norm.eps, lib.ACT_NONE)
-        else:
-            x = self.scale * tokens_of(self.norm(nchw_view(x, h, w))) + self.shift
-        if ops.skipgate_supported(x):  # pools + grouped convs + gates + mix: 2 launches forward, 5-6 backward
-            f13, f33 = self.ffd13.conv, self.ffd33.conv
-            xp = ops.skipgate(x, h, w, (
-                self.conv13pool.conv.weight, self.conv13pool.conv.bias, self.conv31pool.conv.weight, self.conv31pool.conv.bias,
-                self.conv33pool.conv.weight, self.conv33pool.conv.bias, f13.weight.reshape(-1), f13.bias, f33.weight.reshape(-1), f33.bias,
-                self.act_func13.enhance, self.act_func13.threshold, self.act_func33.enhance, self.act_func33.threshold,
-                self.alpha1, self.alpha2, self.alpha3, self.gamma))
-            return self.mlp(self.ffd.forward_tokens(xp, h, w))
-        a31, a13, a33 = self._avg_pools(x, h, w)
-        if d % 4 == 0:
-            m31, m13, m33 = (nchw_view(ops.maxpool(x, h, w, kh, kw, 1), h, w) for kh, kw in ((3, 1), (1, 3), (3, 3)))
-        else:
-            xi = nchw_view(x, h, w)
-            m31, m13, m33 = self.max_pool_31(xi), self.max_pool_13(xi), self.max_pool_33(xi)
-        # the reference applies ffd13/act_func13 to both the 1x3 and the 3x1 branch (:770-777)
-        x1 = self.act_func13(self._pw(self.ffd13, x * tokens_of(self.conv13pool.act(self.conv13pool.conv(m31 + a31)))))
-        x2 = self.act_func13(self._pw(self.ffd13, x * tokens_of(self.conv31pool.act(self.conv31pool.conv(m13 + a13)))))
-        x3 = self.act_func33(self._pw(self.ffd33, x * tokens_of(self.conv33pool.act(self.conv33pool.conv(m33 + a33)))))
-        xp = ops.lincomb([x1, x2, x3], [self.alpha1, self.alpha2, self.alpha3], self.gamma)
+        if not (isinstance(self.norm, nn.InstanceNorm2d) and d % 4 == 0):
+            raise RuntimeError(f"EncoderToDecoder: the HIP kernels take InstanceNorm2d and a multiple of 4 channels, got {self.norm}, dim {d} "
+                               "(the HIP path has no PyTorch fallback)")
+        x = ops.igate_res(x, res, self.gama, self.act.enhance, self.act.threshold)   # act(x + gama * res), one pass each way
+        x = ops.instnorm(x, self.scale, self.shift, self.norm.eps, lib.ACT_NONE)
+        # pools + grouped convs + gates + mix: 2 launches forward, 5-6 backward (csrc/skipgate.hip).  The reference applies
+        # ffd13 / act_func13 to both the 1x3 and the 3x1 branch (:770-777); ffd31 / act_func31 / conv33 are never used.
+        f13, f33 = self.ffd13.conv, self.ffd33.conv
+        xp = ops.skipgate(x, h, w, (
+            self.conv13pool.conv.weight, self.conv13pool.conv.bias, self.conv31pool.conv.weight, self.conv31pool.conv.bias,
+            self.conv33pool.conv.weight, self.conv33pool.conv.bias, f13.weight.reshape(-1), f13.bias, f33.weight.reshape(-1), f33.bias,
+            self.act_func13.enhance, self.act_func13.threshold, self.act_func33.enhance, self.act_func33.threshold,
+            self.alpha1, self.alpha2, self.alpha3, self.gamma))
         return self.mlp(self.ffd.forward_tokens(xp, h, w))
 
 

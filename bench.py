@@ -90,24 +90,83 @@ def parse():
 
 # ------------------------------------------------------------------------------------------------ multi-GPU entry
 def spawn_ranks(args):
-    """`python bench.py --gpus N` outside a launcher: start N ranks of this script.  The parent never initialises HIP (a
-    process that has may not exec/fork GPU children safely, and must not hold a context on device 0)."""
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this script as fresh child processes and SUPERVISE them.
+    The parent never initialises HIP (a process that has may not exec/fork GPU children safely, and must not hold a context on
+    device 0).  All children are polled: the first one that exits non-zero (import error, device fault, a missing device) takes the
+    others down with it — terminate(), then kill() after a grace period — because its peers would otherwise wait in RCCL for ever;
+    that rank's stderr tail is printed and the parent exits non-zero.  An overall time limit (ADNM_BENCH_TIMEOUT, default 1500 s)
+    bounds the whole job.  Rendezvous: the parent binds port 0 to get a free port and hands it to the children; a rank that cannot
+    bind it fails within the init_process_group timeout and is reported like any other failing rank."""
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    limit = float(os.environ.get("ADNM_BENCH_TIMEOUT", "1500"))
+    procs, logs = [], []
+    out0 = tempfile.TemporaryFile()
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         if os.environ.get("ADNM_PIN_DEVICES") == "1":   # one visible device per rank (what an unmodified train.py needs, INTEGRATION.md §1.3)
             env["HIP_VISIBLE_DEVICES"], env["LOCAL_RANK"] = str(r), "0"
+        err = tempfile.TemporaryFile()
+        logs.append(err)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=err))
+
+    def tail(f, n=3000):
+        f.seek(0, os.SEEK_END)
+        size = f.tell()
+        f.seek(max(0, size - n))
+        return f.read().decode(errors="replace")
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    t0, failed, shown = time.time(), None, [0] * len(procs)
+    while True:
+        rcs = [p.poll() for p in procs]
+        f0 = logs[0]   # relay rank 0's progress lines as they come (the driver watches for output)
+        f0.seek(shown[0])
+        chunk = f0.read()
+        if chunk:
+            shown[0] += len(chunk)
+            sys.stderr.write(chunk.decode(errors="replace"))
+            sys.stderr.flush()
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = (bad[0], rcs[bad[0]])
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.time() - t0 > limit:
+            failed = (-1, 124)
+            break
+        time.sleep(0.2)
+    if failed is not None:
+        stop_all()
+        r, rc = failed
+        if r < 0:
+            print(f"[bench] the {args.gpus}-rank job exceeded {limit:.0f} s and was stopped", file=sys.stderr)
+        else:
+            print(f"[bench] rank {r} exited with status {rc}; the other ranks were stopped.  Its stderr tail:", file=sys.stderr)
+            if r != 0:
+                print(tail(logs[r]), file=sys.stderr)
+        sys.stderr.flush()
+        return abs(rc) or 1
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return 0
 
 
 # ------------------------------------------------------------------------------------------------ profiler table
@@ -229,10 +288,12 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import datetime
+        tmo = datetime.timedelta(seconds=float(os.environ.get("ADNM_DIST_TIMEOUT", "300")))   # a missing peer raises instead of hanging
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
         assert dist.get_world_size() == world
 
     from adnm_hip import lib, recipe

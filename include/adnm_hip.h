@@ -64,6 +64,7 @@ int adnm_foldq_destroy(void* q);
 int adnm_foldq_bind(void* q); /* NULL unbinds */
 int64_t adnm_foldq_pending(void* q);
 int adnm_foldq_flush(void* q, adnm_stream_t stream);
+int adnm_foldq_clear(void* q); /* drop the queued folds without launching them (error path of the caller) */
 
 /* ---------------------------------------------------------------- row norms (K2, K7)
  * y = scale * ( xhat * w + b ) + shift,  xhat = (x - mu) * rstd
@@ -213,9 +214,22 @@ int adnm_igate_fwd(const void* x, const float* enhance, const float* threshold, 
 int64_t adnm_igate_bwd_ws_bytes(int64_t n);
 int adnm_igate_bwd(const void* dy, const void* x, const float* enhance, const float* threshold, void* dx, float* denhance,
                    float* dthreshold, void* ws, int64_t ws_bytes, int64_t n, int dtype, adnm_stream_t stream);
+/* EncoderToDecoder's entry, fused (model_untils.py:761-763: x = self.act(x + self.gama * res), act = IntensityGate):
+ *   y[b,l,c] = silu(enhance * (x[b,l,c] + gama * res[b,c] - threshold)),   x, y:(B,L,C) fp32 contiguous, res:(B,C) — the
+ * channel-attention gate of Channel_Att_Bridge, one value per (sample, channel), which the reference expands over the tokens
+ * (model_untils.py:604-613).  gama / enhance / threshold: 1-element fp32.  C % 4 == 0.
+ * Backward: dx:(B,L,C), dres:(B,C) (complete when the launch ends), dgama/denhance/dthreshold:(1) through per-workgroup partials
+ * + one fold (deferrable: parameter gradients).  All OVERWRITTEN. */
+int adnm_igate_res_fwd(const float* x, const float* res, const float* gama, const float* enhance, const float* threshold, float* y,
+                       int64_t B, int64_t L, int64_t C, adnm_stream_t stream);
+int64_t adnm_igate_res_bwd_ws_bytes(int64_t B, int64_t L, int64_t C);
+int adnm_igate_res_bwd(const float* dy, const float* x, const float* res, const float* gama, const float* enhance,
+                       const float* threshold, float* dx, float* dres, float* dgama, float* denhance, float* dthreshold, void* ws,
+                       int64_t ws_bytes, int64_t B, int64_t L, int64_t C, adnm_stream_t stream);
+
 
 /* ---------------------------------------------------------------- EncoderToDecoder's pooled gating core (K12)
- * model_untils.py:767-787 of the reference, x = the block's normalised tokens (B, H, W, C) fp32 contiguous, C % 256 == 0:
+ * model_untils.py:767-787 of the reference, x = the block's normalised tokens (B, H, W, C) fp32 contiguous, C % 4 == 0:
  *   p_k = MaxPool_k(x) + AvgPool_k(x)      k = 0: (3,1) window, 1: (1,3), 2: (3,3); stride 1, count_include_pad
  *   c_k = conv_k(p_k)                      conv13pool (1,3) / conv31pool (3,1) / conv33pool (3,3), groups = C/4, with bias
  *   y_k = IntensityGate_k(ffd_k(x * GELU(c_k)))    ffd13 + act_func13 for k = 0 AND 1 (as the reference), ffd33 + act_func33 for k = 2

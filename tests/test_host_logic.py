@@ -1,0 +1,107 @@
+"""Host-side logic that needs no GPU: the trainer's ownership / error path, the gradient-destination registry's
+finaliser safety, the supervised multi-rank launcher of bench.py, RadarIngest's slot bookkeeping."""
+import gc
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.a, self.b = nn.Linear(8, 16), nn.Linear(16, 4)
+
+    def forward(self, x):
+        return self.b(torch.tanh(self.a(x)))
+
+
+def test_prepare_exception_path_restores_state():
+    """An exception inside prepare() (here: a loss function that raises on the second call, i.e. after the dry run) must leave the
+    collector enabled, no graph objects behind and the trainer reusable; close() is idempotent and drops the registration."""
+    from adnm_hip import ops
+    from adnm_hip.trainer import FlatTrainer
+    calls = [0]
+
+    def loss_fn(o, t):
+        calls[0] += 1
+        if calls[0] == 2:
+            raise ValueError("boom")
+        return (o - t).pow(2).mean()
+
+    model = _Toy()
+    tr = FlatTrainer(model, loss_fn, use_graph=False, fused=False)
+    x, t = torch.randn(5, 8), torch.randn(5, 4)
+    assert gc.isenabled()
+    tr.prepare(x, t)            # first call of loss_fn: fine
+    with pytest.raises(ValueError):
+        tr.step(x, t)           # second call raises inside the eager step
+    assert gc.isenabled()
+    tr2 = FlatTrainer(_Toy(), loss_fn, use_graph=False, fused=False)
+    calls[0] = 1
+    with pytest.raises(ValueError):
+        tr2.prepare(x, t)       # raises inside prepare's dry run
+    assert gc.isenabled() and tr2.graph is None and tr2.graph2 is None and tr2.static_loss is None
+    calls[0] = 10
+    tr2.prepare(x, t)           # and the same object can be prepared again
+    tr2.step(x, t)
+    owner = id(tr2)
+    tr2.close()
+    tr2.close()
+    ops.GRADS.reset_claims(owner)   # drains the finaliser queue
+    assert owner not in ops.GRADS._claimed and not any(o == owner for o, _ in ops.GRADS._dst.values())
+
+
+def test_grad_registry_drop_is_lock_free_and_reentrant():
+    """drop() is what a finaliser calls: it must not take the registry lock (the cyclic collector can run while register() / take()
+    hold it on the same thread)."""
+    from adnm_hip.ops import GradRegistry
+    reg = GradRegistry()
+    g = torch.zeros(4)
+    reg.register(1, {g.data_ptr(): g})
+    with reg._lock:            # as if the collector fired inside take()
+        reg.drop(1)            # must return at once
+        with reg._lock:        # and the lock is re-entrant for the same thread
+            pass
+    t = reg.take(g.data_ptr(), (4,), g.device)
+    assert t.data_ptr() != g.data_ptr()   # owner 1 was forgotten before the lookup
+    # a slice whose layout differs from what the caller writes is refused WITHOUT being claimed
+    w = torch.zeros(2, 3, 3, 5).permute(0, 3, 1, 2)   # (2, 5, 3, 3) logical, channels-last memory
+    reg.register(2, {w.data_ptr(): w})
+    got = reg.take(w.data_ptr(), (2, 5, 3, 3), w.device, strides=(45, 9, 3, 1))
+    assert got.data_ptr() != w.data_ptr() and w.data_ptr() not in reg.born_in_place(2)
+    got = reg.take(w.data_ptr(), (2, 5, 3, 3), w.device, strides=tuple(w.stride()))
+    assert got.data_ptr() == w.data_ptr() and w.data_ptr() in reg.born_in_place(2)
+
+
+def test_bench_multi_rank_launcher_reports_a_dead_rank():
+    """`python bench.py --gpus 2` on a box without GPUs: both ranks exit at once ("needs a GPU"); the parent must notice, stop the
+    job and exit non-zero within seconds instead of waiting for a rendezvous that never happens."""
+    env = dict(os.environ, ADNM_BENCH_TIMEOUT="120")
+    env.pop("WORLD_SIZE", None)
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU (on a GPU box the 2-rank job would really start)")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "exited with status" in r.stderr and "needs a GPU" in r.stderr
+    assert time.time() - t0 < 240
+
+
+def test_radar_ingest_slot_bookkeeping():
+    """submit, submit, take, take works; a third submit without a take raises (no staging buffer is overwritten under a copy)."""
+    from adnm_hip import dataio
+    ing = dataio.RadarIngest.__new__(dataio.RadarIngest)   # the bookkeeping alone: no pinned memory / device here
+    ing._pending, ing._slot = [], 0
+    ing._pending.append(0), ing._pending.append(1)
+    with pytest.raises(RuntimeError):
+        dataio.RadarIngest.submit(ing, None)
+    assert ing._pending.pop(0) == 0 and ing._pending.pop(0) == 1

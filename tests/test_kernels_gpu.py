@@ -409,11 +409,32 @@ def test_igate():
     assert_close(tg.grad, to.grad, GRAD_TOL, "dthreshold", atol=1e-5)
 
 
+@pytest.mark.parametrize("B,L,C", [(4, 16, 1024), (2, 64, 512), (3, 256, 256), (2, 77, 36), (1, 4096, 32)])
+def test_igate_res(B, L, C):
+    """EncoderToDecoder's entry IntensityGate(x + gama * res) with the (B, 1, C) bridge gate broadcast over the tokens
+    (model_untils.py:761-763) vs the same maths in fp64 torch ops."""
+    tag = f"igr{B}{L}{C}"
+    x, r, cot = T(tag + "x", (B, L, C), 2.0), T(tag + "r", (B, 1, C)), T(tag + "c", (B, L, C))
+    g, e, t = torch.tensor(0.8), torch.tensor(1.2), torch.tensor(0.15)
+    lo = [leaf(v.double()) for v in (x, r, g, e, t)]
+    yo = O.silu(lo[3] * (lo[0] + lo[2] * lo[1] - lo[4]))
+    (yo * cot.double()).sum().backward()
+    lg = [leaf(v, DEV) for v in (x, r, g, e, t)]
+    yg = ops.igate_res(*lg)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, OUT_TOL, "igate_res")
+    for n, a, b in zip(("dx", "dres", "dgama", "denhance", "dthreshold"), lg, lo):
+        assert_close(a.grad, b.grad, GRAD_TOL, n, atol=1e-5)
+
+
 # ------------------------------------------------------------------------------------------- EncoderToDecoder core (K12)
-@pytest.mark.parametrize("B,H,W,C", [(2, 4, 4, 256), (1, 8, 8, 512), (4, 2, 2, 1024), (2, 16, 16, 256), (1, 40, 40, 256)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 4, 4, 256), (1, 8, 8, 512), (4, 2, 2, 1024), (2, 16, 16, 256), (1, 40, 40, 256),
+                                     (1, 32, 32, 128), (2, 9, 7, 64), (1, 64, 64, 32), (3, 5, 5, 36)])
 def test_skipgate(B, H, W, C):
     """pools + grouped convs + gates + mix vs the same maths in fp64 torch ops (model_untils.py:767-787).
-    The last shape has > 1 pixel slice in the weight-gradient pass (partials + fold)."""
+    (1, 40, 40, 256) has > 1 pixel slice in the weight-gradient pass (partials + fold); the last four are the narrow maps of
+    e2ds[3..6] (C = 128 / 64 / 32: waves that straddle pixel slices, a partly idle last chunk of conv groups) and a width that is
+    no multiple of 16 groups."""
     tag = f"sg{B}{H}{C}"
     x, cot = T(tag + "x", (B, H * W, C), 1.5), T(tag + "c", (B, H * W, C))
     shapes = [(C, 4, 1, 3), (C,), (C, 4, 3, 1), (C,), (C, 4, 3, 3), (C,), (C,), (C,), (C,), (C,)]
@@ -604,6 +625,24 @@ def test_unsupported_shapes_raise():
     from models.model_untils import DownSample
     with pytest.raises(RuntimeError, match="max-pool"):
         DownSample(dim=6)(torch.zeros(1, 16, 6, device=DEV))
+    # the branches that used to fall back to torch / library ops now raise like everything else
+    import torch.nn as nn
+    from models.model_untils import Conv2dLayer, WTConvLayer, DeConv2dLayer, EncoderToDecoder
+    from models.ADNssd import StandardAttention
+    with pytest.raises(RuntimeError, match="no PyTorch fallback"):       # GroupNorm has no HIP kernel
+        Conv2dLayer(8, 8, norm=nn.GroupNorm(4, 8)).to(DEV).forward_tokens(torch.zeros(1, 16, 8, device=DEV), 4, 4)
+    with pytest.raises(RuntimeError, match="no PyTorch fallback"):       # shape-changing conv
+        Conv2dLayer(8, 8, kernel_size=(3, 3), stride=(2, 2)).to(DEV)(torch.zeros(1, 8, 4, 4, device=DEV))
+    with pytest.raises(RuntimeError, match="no PyTorch fallback"):
+        WTConvLayer(8, 8, kernel_size=5, wt_levels=1, norm=nn.GroupNorm(4, 8)).to(DEV).forward_tokens(torch.zeros(1, 16, 8, device=DEV), 4, 4)
+    with pytest.raises(RuntimeError, match="no PyTorch fallback"):       # ratio-4 transposed conv
+        DeConv2dLayer(8, 8, ratio=4).to(DEV)(torch.zeros(1, 8, 4, 4, device=DEV))
+    with pytest.raises(RuntimeError, match="no PyTorch fallback"):       # 6 channels: no conv group of 4 per lane
+        EncoderToDecoder(embed_dim=8, InstanceNorm=False).to(DEV)(torch.zeros(1, 16, 8, device=DEV), torch.zeros(1, 1, 8, device=DEV))
+    with pytest.raises(RuntimeError, match="no PyTorch fallback"):       # 8-wide heads
+        StandardAttention(32, heads=4, dim_head=8).to(DEV)(torch.zeros(1, 16, 32, device=DEV), 4, 4)
+    with pytest.raises(RuntimeError, match="no PyTorch fallback"):
+        ops.skipgate(odd, 2, 4, [one] * 18)
 
 
 # ------------------------------------------------------------------------------------------- dense 3x3 conv (K5)
