@@ -14,19 +14,156 @@ from . import lib
 
 _DT = {torch.float32: lib.F32, torch.bfloat16: lib.BF16}
 
-# Matrix-core precision of the GEMM-shaped kernels (short GEMMs, dense 3x3 convs; include/adnm_hip.h ADNM_MFMA_*): "f32" = exact fp32
-# MFMA (the parity path), "bf16" = operands rounded to bf16 into the bf16 MFMA with fp32 accumulation (BASELINE's bf16 configs).
+# Matrix-core precision of the GEMM-shaped kernels (short / tall-skinny GEMMs, dense 3x3 convs; include/adnm_hip.h ADNM_MFMA_*):
+#   "f32"  exact fp32 MFMA (the parity path);
+#   "bf16" operands rounded to bf16 into v_mfma_f32_16x16x32_bf16, fp32 accumulation (BASELINE configs 2-4);
+#   "fp8"  BASELINE config 5: per-tensor scaled OCP fp8 operands (e4m3 activations / weights, e5m2 output gradients) into
+#          v_mfma_f32_16x16x32_{fp8,bf8}_fp8 for the forward and input-gradient GEMMs / convs; weight gradients stay on bf16 operands.
+#          Scales are delayed (QUANT below): a call site's scale comes from the amax its kernel saw in an earlier step.
 # A process-wide setting like torch's autocast state; kernels take it as an explicit argument.
 MFMA_PREC = [0]
+_PREC_NAMES = {"f32": 0, "fp32": 0, "bf16": 1, "fp8": 2}
 
 
 def set_mfma_precision(name):
-    MFMA_PREC[0] = {"f32": 0, "fp32": 0, "bf16": 1}[name]
+    MFMA_PREC[0] = _PREC_NAMES[name]
 
 
 def mfma_precision():
-    return "bf16" if MFMA_PREC[0] else "f32"
+    return ("f32", "bf16", "fp8")[MFMA_PREC[0]]
 
+
+class QuantTable:
+    """Quantisation records of the fp8 configuration (include/adnm_hip.h: `q` of the GEMM-shaped entry points, adnm_quant_update): one
+    32-byte device record per GEMM call site, keyed by (stable key of the weight, role), role "f" = forward (first operand = activation
+    rows, e4m3) or "g" = input-gradient (first operand = output gradient, e5m2).  Delayed per-tensor scaling: while a record's `record`
+    flag is set the kernels collect max |value| of both operands; update() — one launch per training step — turns those into the next
+    scales every `period` steps.  Records are created eagerly (a host -> device write): every call site must have run once before a
+    hipGraph capture (FlatTrainer.prepare's calibration step does that, on bf16 operands).
+    The table is per device; lookups are lock-guarded (autograd's engine threads)."""
+    CAP = 2048
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._dev = {}        # device index -> {"tab": (CAP, 8) fp32, "state": (2,), "keys": {key: row}}
+        self.calibrating = False
+        self.bf16_keys = set()   # weights (stable keys) whose GEMMs stay on bf16 operands in the fp8 configuration
+        # GEMMs / convs over more token rows than this keep bf16 operands in the fp8 configuration.  At config 2 (B = 4) that is the
+        # 128x128 and 64x64 levels (65 536 / 16 384 rows: refiner, encoder1-2, decoder5-6, the output head): their weights are tiny
+        # (<= 26 k elements: the activations are the byte stream, fp8 operands save nothing) and their reductions short (K = 32 .. 128:
+        # no averaging of the 2^-4 rounding steps), and they touch the data directly.  Measured (tools/fp8_error.py,
+        # profiles/r03_fp8_error.txt): output rel-L2 vs fp32 0.20 with every GEMM on fp8, 0.11 with this rule, 0.06 fp8 below 32x32 only.
+        self.max_rows = int(os.environ.get("ADNM_FP8_MAX_ROWS", "8192"))
+        self.period = int(os.environ.get("ADNM_FP8_PERIOD", "16"))
+        self.headroom = float(os.environ.get("ADNM_FP8_HEADROOM", "2.0"))
+
+    def active(self):
+        return MFMA_PREC[0] == 2 or self.calibrating
+
+    def _ent(self, device):
+        ent = self._dev.get(self._idx(device))
+        if ent is None:
+            ent = self._dev[self._idx(device)] = {"tab": torch.zeros((self.CAP, 8), dtype=torch.float32, device=device),
+                                            "state": torch.tensor([0.0, float(self.period)], dtype=torch.float32, device=device), "keys": {}}
+        return ent
+
+    def keep_bf16(self, keys):
+        """the GEMMs / convs of these weights (data_ptr keys) run on bf16 operands in the fp8 configuration: the customary exemption of
+        the layers that touch the data directly (VisionMamba.fp8_exempt_parameters names the input embedding and the output head)"""
+        self.bf16_keys = set(keys)
+
+    @staticmethod
+    def _idx(device):
+        return device.index if device.index is not None else torch.cuda.current_device()
+
+    def record(self, device, key, role, rows=0):
+        """-> device pointer of the call site's record, or None when neither fp8 nor a calibration pass is on, or the call site is exempt
+        (more than max_rows token rows, or a weight named by keep_bf16): it then runs on bf16 operands."""
+        if not self.active() or rows > self.max_rows or key in self.bf16_keys:
+            return None
+        with self._lock:
+            ent = self._ent(device)
+            row = ent["keys"].get((key, role))
+            if row is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("adnm_hip fp8: a GEMM call site ran for the first time inside a hipGraph capture (no quantisation record yet); "
+                                       "run the step eagerly once before capturing (FlatTrainer.prepare does)")
+                row = len(ent["keys"])
+                if row >= self.CAP:
+                    raise RuntimeError(f"adnm_hip fp8: more than {self.CAP} GEMM call sites")
+                ent["keys"][(key, role)] = row
+                ent["tab"][row] = torch.tensor([1.0, 1.0, 0.0, 0.0, 57344.0 if role[0] == "g" else 448.0, 448.0, 1.0, 0.0])
+            return ent["tab"].data_ptr() + 32 * row
+
+    def explicit(self, device, scale_a, scale_b, grad_a=False, record=False):
+        """a stand-alone record with given scales (tests / callers that manage their own scaling): (8,) fp32 tensor, pass its data_ptr"""
+        return torch.tensor([scale_a, scale_b, 0.0, 0.0, 57344.0 if grad_a else 448.0, 448.0, 1.0 if record else 0.0, 0.0], dtype=torch.float32,
+                            device=device)
+
+    ROLES = {"linear_fwd": "fnt", "linear_dgrad": "gnn", "conv3_fwd": "fc3", "conv3_dgrad": "gc3", "convt_fwd": "fnn", "convt_dgrad": "gnt"}
+
+    def set(self, device, key, site, scale_a, scale_b, record=False):
+        """create / overwrite the record of call site (key, site) with explicit scales (tests, callers that manage their own scaling);
+        site: one of ROLES.  Needs active() (fp8 mode or a calibration pass)."""
+        role = self.ROLES[site]
+        with self._lock:
+            ent = self._ent(device)
+            row = ent["keys"].get((key, role))
+            if row is None:
+                row = len(ent["keys"])
+                ent["keys"][(key, role)] = row
+            ent["tab"][row] = torch.tensor([scale_a, scale_b, 0.0, 0.0, 57344.0 if role[0] == "g" else 448.0, 448.0, 1.0 if record else 0.0, 0.0])
+            return ent["tab"][row]
+
+    def update(self, device):
+        """once per training step, after it: amax -> scales on calibration steps, set the record flags of the next step"""
+        ent = self._dev.get(self._idx(device))
+        if ent is None:
+            return
+        lib.call("adnm_quant_update", ent["tab"].data_ptr(), len(ent["keys"]), ent["state"].data_ptr(), float(self.headroom), _stream())
+
+    def reset(self, device=None):
+        with self._lock:
+            if device is None:
+                self._dev.clear()
+            else:
+                self._dev.pop(self._idx(device), None)
+
+    def dump(self, device):
+        ent = self._dev.get(self._idx(device))
+        if ent is None:
+            return {}
+        tab = ent["tab"].cpu()
+        return {k: tab[r].tolist() for k, r in ent["keys"].items()}
+
+
+QUANT = QuantTable()
+
+
+def fp8_calibrate(device, fn):
+    """Run fn() once on bf16 operands with every GEMM call site collecting its operands' amax, then turn those into fp8 scales (what
+    FlatTrainer.prepare does for a training step; this is the stand-alone form for a forward-only / evaluation use).  Leaves the
+    precision at "fp8"."""
+    QUANT.reset(device)
+    set_mfma_precision("bf16")
+    QUANT.calibrating = True
+    try:
+        out = fn()
+    finally:
+        QUANT.calibrating = False
+    QUANT.update(device)
+    set_mfma_precision("fp8")
+    return out
+
+
+def _gemm_prec(q, role):
+    """(prec, q pointer) of a GEMM-shaped call: the fp8 modes need a record; a calibration pass runs bf16 operands WITH the record."""
+    p = MFMA_PREC[0]
+    if p == 2:
+        if q is None:   # an exempt weight (QUANT.keep_bf16)
+            return 1, None
+        return (3 if role == "g" else 2), q
+    return (1 if QUANT.calibrating else p), q
 
 
 def _dt(t):
@@ -885,7 +1022,7 @@ class ADNMixerFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk=0, scan_groups=2):
+    def forward(ctx, u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk=0, scan_groups=2, qkeys=(None, None)):
         Bsz, L, dm = u.shape
         M = Bsz * L
         di = w_out.shape[1] // 2
@@ -893,7 +1030,7 @@ class ADNMixerFn(torch.autograd.Function):
         nh = di // P
         u2 = u.reshape(M, dm)
         u2 = u2 if u2.is_contiguous() else u2.contiguous()
-        proj = k_linear(u2, w_in, None)  # (M, 2di+2gN+nh) = [z | xBC | dt]
+        proj = k_linear(u2, w_in, None, qkey=qkeys[0])  # (M, 2di+2gN+nh) = [z | xBC | dt]
         # one wide buffer [LN(y) | silu(conv_z(z)) | silu(conv(xBC))]: its first 2di columns are out_proj's input, the rest K1's operands;
         # z and xBC are adjacent in `proj` and their conv outputs adjacent here, so ONE depthwise launch (taps = [czw | cw]) does both
         wide = torch.empty((M, 2 * di + cx), dtype=u.dtype, device=u.device)
@@ -916,9 +1053,10 @@ class ADNMixerFn(torch.autograd.Function):
             mu = None
         if mu is None:
             _, mu, rstd = k_rownorm_fwd(y, ln_w, ln_b, None, None, 1e-5, True, out=cat[:, :di])
-        out = k_linear(cat, w_out, None)
+        out = k_linear(cat, w_out, None, qkey=qkeys[1])
         ctx.save_for_backward(u2, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, proj, wide, y, kv, mu, rstd)
         ctx.dims = (Bsz, L, dm, H, W, P, N, di, cx, nh, scan_chunk, scan_groups)
+        ctx.qkeys = qkeys
         return out.view(Bsz, L, dm)
 
     @staticmethod
@@ -934,7 +1072,7 @@ class ADNMixerFn(torch.autograd.Function):
         # merged depthwise backward reads [d zc | d xbc] as one column range
         dwide = torch.empty_like(wide)
         dcat, dxbc = dwide[:, :2 * di], dwide[:, 2 * di:]
-        k_linear_dx(do, w_out, out=dcat)
+        k_linear_dx(do, w_out, out=dcat, qkey=ctx.qkeys[1])
         dy, dln_w, dln_b, _, _ = k_rownorm_bwd(dcat[:, :di], y, ln_w, ln_b, None, mu, rstd, True, True, False, defer=True)
         dproj = torch.empty_like(proj)
         if scan_chunk == 0:
@@ -950,13 +1088,15 @@ class ADNMixerFn(torch.autograd.Function):
             ddtb, dA, dD = (torch.stack((parts[0][k], parts[1][k]), dim=1).reshape(nh) for k in range(3))
         _, dtaps, dtb = k_dwconv_bwd(dwide[:, di:], proj[:, :di + cx], taps, tb, Bsz, H, W, di + cx, 3, lib.ACT_SILU, dx=dproj[:, :di + cx],
                                      want_bias=tb is not None)
-        du = k_linear_dx(dproj, w_in)
+        du = k_linear_dx(dproj, w_in, qkey=ctx.qkeys[0])
         dw_in, _ = k_linear_dw(dproj, u2, False)
-        return (du.view(Bsz, L, dm), dw_in, dtaps, dtb, ddtb, dA, dD, dln_w, dln_b, dw_out, None, None, None, None, None, None)
+        return (du.view(Bsz, L, dm), dw_in, dtaps, dtb, ddtb, dA, dD, dln_w, dln_b, dw_out, None, None, None, None, None, None, None)
 
 
-def adn_mixer(u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk=0, scan_groups=2):
-    return ADNMixerFn.apply(u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk, scan_groups)
+def adn_mixer(u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk=0, scan_groups=2, qkeys=(None, None)):
+    """qkeys: stable identities (data_ptr of in_proj.weight / out_proj.weight) of the two projections for the fp8 call-site records —
+    w_in / w_out themselves are per-step temporaries."""
+    return ADNMixerFn.apply(u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk, scan_groups, qkeys)
 
 
 class LinCombFn(torch.autograd.Function):
@@ -1167,16 +1307,20 @@ def _sk_operand(t, what):
     return t
 
 
-def _skgemm(op, a, b, bias, c, dbias, M, N, K, defer=False, side=False):
+def _skgemm(op, a, b, bias, c, dbias, M, N, K, defer=False, side=False, q=None, role="f"):
     if lib.query("adnm_skgemm_supported", op, M, N, K) != 1:
         raise RuntimeError(f"adnm_hip linear: no kernel takes op={('NT', 'NN', 'TN')[op]} M={M} N={N} K={K} "
                            "(every op needs N % 4 == 0 and K % 4 == 0)")
     nb = lib.query("adnm_skgemm_ws_bytes", op, M, N, K)
     ws = _ws(nb, a.device)
     # only the weight-gradient op (TN) may wait for its split-K fold, and only it leaves the critical path for the side stream
-    pc, ldc, pdb, prec = c.data_ptr(), c.stride(0), _p(dbias), MFMA_PREC[0]   # (the outputs are not captured: see SideStreams)
+    pc, ldc, pdb = c.data_ptr(), c.stride(0), _p(dbias)   # (the outputs are not captured: see SideStreams)
+    if op == SK_TN:   # the weight gradient: bf16 operands in the fp8 configuration, no record
+        prec, qp = (1 if MFMA_PREC[0] == 2 or QUANT.calibrating else MFMA_PREC[0]), None
+    else:
+        prec, qp = _gemm_prec(q, role)
     call = lambda: lib.call("adnm_skgemm", op, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _p(bias), pc, ldc, pdb,
-                            ws.data_ptr(), nb, M, N, K, prec, _stream())
+                            ws.data_ptr(), nb, M, N, K, prec, qp, _stream())
     if side:
         SIDE.submit(a.device, (a, b), FOLDS.defer(a.device, ws) if defer else _NODEFER, call)
     else:
@@ -1188,35 +1332,43 @@ def _out_view_ok(out):
     return out.stride(-1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0
 
 
-def k_linear(x2, w, bias, out=None):
-    """Y = X W^T (+bias) for row views X (M,K) [stride (ld,1)], W (N,K) contiguous."""
+def k_linear(x2, w, bias, out=None, qkey=None, role="f"):
+    """Y = X W^T (+bias) for row views X (M,K) [stride (ld,1)], W (N,K) contiguous.
+    qkey: stable identity of the weight for the fp8 call-site record (default: its data_ptr — right for parameters, wrong for
+    per-step temporaries such as the mixer's prepared weights, whose callers pass the parameter's); role "f": X are activations,
+    "g": X is an output gradient (this GEMM computes an input gradient)."""
     M, K = x2.shape
     N = w.shape[0]
     _need_gpu(x2)
+    q = QUANT.record(x2.device, w.data_ptr() if qkey is None else qkey, role + "nt", M)
     if ts_ok_nt(M, N, K, x2):
         y = out if out is not None else torch.empty((M, N), dtype=x2.dtype, device=x2.device)
-        lib.call("adnm_tsgemm_nt", x2.data_ptr(), x2.stride(0), w.data_ptr(), K, 1, _p(bias), y.data_ptr(), y.stride(0), M, N, K, MFMA_PREC[0], _stream())
+        prec, qp = _gemm_prec(q, role)
+        lib.call("adnm_tsgemm_nt", x2.data_ptr(), x2.stride(0), w.data_ptr(), K, 1, _p(bias), y.data_ptr(), y.stride(0), M, N, K, prec, qp, _stream())
         return y
     x2, w = _sk_operand(x2, "input"), _sk_operand(w, "weight")
     y = out if out is not None and _out_view_ok(out) else torch.empty((M, N), dtype=x2.dtype, device=x2.device)
-    _skgemm(SK_NT, x2, w, bias, y, None, M, N, K)
+    _skgemm(SK_NT, x2, w, bias, y, None, M, N, K, q=q, role=role)
     if out is not None and y is not out:
         out.copy_(y)
         return out
     return y
 
 
-def k_linear_dx(dy2, w, out=None):
-    """dX = dY W for dY (M,N) row view, W (N,K) contiguous."""
+def k_linear_dx(dy2, w, out=None, qkey=None, role="g"):
+    """dX = dY W for dY (M,N) row view, W (N,K) contiguous.  (qkey / role: see k_linear; the transposed conv's FORWARD is this product
+    with activations as the first operand, role "f".)"""
     M, N = dy2.shape
     K = w.shape[1]
+    q = QUANT.record(dy2.device, w.data_ptr() if qkey is None else qkey, role + "nn", M)
     if ts_ok_nt(M, K, N, dy2):
         dx = out if out is not None else torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
-        lib.call("adnm_tsgemm_nt", dy2.data_ptr(), dy2.stride(0), w.data_ptr(), 1, K, None, dx.data_ptr(), dx.stride(0), M, K, N, MFMA_PREC[0], _stream())
+        prec, qp = _gemm_prec(q, role)
+        lib.call("adnm_tsgemm_nt", dy2.data_ptr(), dy2.stride(0), w.data_ptr(), 1, K, None, dx.data_ptr(), dx.stride(0), M, K, N, prec, qp, _stream())
         return dx
     dy2, w = _sk_operand(dy2, "output gradient"), _sk_operand(w, "weight")
     dx = out if out is not None and _out_view_ok(out) else torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
-    _skgemm(SK_NN, dy2, w, None, dx, None, M, N, K)
+    _skgemm(SK_NN, dy2, w, None, dx, None, M, N, K, q=q, role=role)
     if out is not None and dx is not out:
         out.copy_(dx)
         return out
@@ -1262,13 +1414,14 @@ class LinearFn(torch.autograd.Function):
     """nn.Linear / 1x1 conv on tokens."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, qkey=None):
         shp = x.shape
         K = shp[-1]
         x2 = x.reshape(-1, K)
         x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
         w = w.contiguous()
-        y = k_linear(x2, w, bias)
+        ctx.qkey = w.data_ptr() if qkey is None else qkey
+        y = k_linear(x2, w, bias, qkey=ctx.qkey)
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
         ctx.ptrs = (w.data_ptr(), bias.data_ptr() if bias is not None else 0)
@@ -1281,9 +1434,9 @@ class LinearFn(torch.autograd.Function):
         N = w.shape[0]
         dy2 = dy.reshape(-1, N)
         dy2 = dy2 if dy2.stride(-1) == 1 else dy2.contiguous()
-        dx = k_linear_dx(dy2, w).view(ctx.shp) if ctx.needs_input_grad[0] else None
+        dx = k_linear_dx(dy2, w, qkey=ctx.qkey).view(ctx.shp) if ctx.needs_input_grad[0] else None
         dw, db = k_linear_dw(dy2, x2, ctx.has_bias, *ctx.ptrs)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 def linear(x, w, bias=None):
@@ -1294,9 +1447,10 @@ def linear(x, w, bias=None):
     N = w.shape[0]
     if N % 4:   # the GEMM kernels move 16-byte vectors along N: run them on the weight padded with zero rows (a frame count like 6)
         pad = 4 - N % 4
+        key = w.data_ptr()   # the padded copy is a per-step temporary: the parameter identifies the call site
         w = torch.nn.functional.pad(w, (0, 0, 0, pad))
         bias = torch.nn.functional.pad(bias, (0, pad)) if bias is not None else None
-        return LinearFn.apply(x, w, bias)[..., :N]
+        return LinearFn.apply(x, w, bias, key)[..., :N]
     return LinearFn.apply(x, w, bias)
 
 
@@ -1391,8 +1545,9 @@ class Conv3Fn(torch.autograd.Function):
         pre = torch.empty((B * L, N), dtype=torch.float32, device=dev) if act != lib.ACT_NONE else None
         nb = lib.query("adnm_conv3_ws_bytes", B, H, W, K, N)
         wsb = _ws(nb, dev)
+        prec, qp = _gemm_prec(QUANT.record(dev, w.data_ptr(), "fc3", B * L), "f")
         lib.call("adnm_conv3_fwd", x2.data_ptr(), x2.stride(0), w.data_ptr(), ws_[0], ws_[1], ws_[2], _p(bias), y.data_ptr(), N, _p(pre), N,
-                 wsb.data_ptr(), nb, B, H, W, K, N, act, MFMA_PREC[0], _stream())
+                 wsb.data_ptr(), nb, B, H, W, K, N, act, prec, qp, _stream())
         ctx.save_for_backward(x2, w, pre)
         ctx.meta = (B, H, W, K, N, act, ws_, bias.data_ptr() if bias is not None else 0, bias is not None)
         return y.view(B, L, N)
@@ -1409,8 +1564,9 @@ class Conv3Fn(torch.autograd.Function):
             dx = torch.empty((B * H * W, K), dtype=torch.float32, device=dev)
             nb = lib.query("adnm_conv3_ws_bytes", B, H, W, N, K)
             wsb = _ws(nb, dev)
+            prec, qp = _gemm_prec(QUANT.record(dev, w.data_ptr(), "gc3", B * H * W), "g")
             lib.call("adnm_conv3_dgrad", dy2.data_ptr(), dy2.stride(0), _p(pre), N, act, w.data_ptr(), ws_[0], ws_[1], ws_[2], dx.data_ptr(), K,
-                     wsb.data_ptr(), nb, B, H, W, K, N, MFMA_PREC[0], _stream())
+                     wsb.data_ptr(), nb, B, H, W, K, N, prec, qp, _stream())
             dx = dx.view(B, H * W, K)
         # the weight gradient is produced in (Cout, 3, 3, Cin) memory order: the flat trainer's channels-last slice takes it as it lies
         # (a registered slice in any other layout is refused without being claimed: the trainer's gather then copies the gradient)
@@ -1420,7 +1576,7 @@ class Conv3Fn(torch.autograd.Function):
         db = grad_dst(b_ptr, (N,), dev) if has_bias else None
         nb = lib.query("adnm_conv3_wgrad_ws_bytes", B, H, W, K, N)
         wsb = _ws(nb, dev)
-        pg, pdb, prec = g.data_ptr(), _p(db), MFMA_PREC[0]
+        pg, pdb, prec = g.data_ptr(), _p(db), (1 if MFMA_PREC[0] == 2 or QUANT.calibrating else MFMA_PREC[0])   # fp8 configuration: bf16 operands here
         SIDE.submit(dev, (dy2, pre, x2), FOLDS.defer(dev, wsb), lambda: lib.call(
             "adnm_conv3_wgrad", dy2.data_ptr(), dy2.stride(0), _p(pre), N, act, x2.data_ptr(), x2.stride(0), pg, pdb,
             wsb.data_ptr(), nb, B, H, W, K, N, prec, _stream()))
@@ -1452,7 +1608,7 @@ class ConvT2xFn(torch.autograd.Function):
         wf = torch.as_strided(w, (Cin, 9 * Cout), (9 * Cout, 1))
         x2 = x.reshape(B * L, Cin)
         x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
-        cols = k_linear_dx(x2, wf)                           # (M, Cin) . (Cin, 9 Cout)
+        cols = k_linear_dx(x2, wf, qkey=w.data_ptr(), role="f")   # (M, Cin) . (Cin, 9 Cout): activations x weight
         out = torch.empty((B * 4 * L, Cout), dtype=torch.float32, device=x.device)
         lib.call("adnm_convt_col2im", cols.data_ptr(), 9 * Cout, ct, cc, _p(bias), out.data_ptr(), Cout, B, H, W, Cout, _stream())
         ctx.save_for_backward(x2, wf)
@@ -1469,7 +1625,7 @@ class ConvT2xFn(torch.autograd.Function):
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
         dcols = torch.empty((M, 9 * Cout), dtype=torch.float32, device=dev)
         lib.call("adnm_convt_im2col", dy2.data_ptr(), Cout, dcols.data_ptr(), 9 * Cout, ct, cc, B, H, W, Cout, _stream())
-        dx = k_linear(dcols, wf, None).view(B, H * W, Cin) if ctx.needs_input_grad[0] else None
+        dx = k_linear(dcols, wf, None, qkey=w_ptr, role="g").view(B, H * W, Cin) if ctx.needs_input_grad[0] else None
         want = (9 * Cout, 1, 3 * Cout, Cout) if cc == 1 else (9 * Cout, 9, 3, 1)
         g = grad_dst(w_ptr, (Cin, Cout, 3, 3), dev, strides=want)   # the slice is taken only if it has the weight's own memory order
         if g.stride() != want:
@@ -1586,12 +1742,13 @@ class IGateResFn(torch.autograd.Function):
     def forward(ctx, x, res, gama, enhance, threshold):
         _need_gpu(x)
         B, L, C = x.shape
-        x, r = x.contiguous(), res.reshape(B, C).contiguous()
+        per_token = int(res.numel() == x.numel())   # the reference's own call form hands over the gate already expanded over the tokens
+        x, r = x.contiguous(), (res.reshape(B, L, C) if per_token else res.reshape(B, C)).contiguous()
         y = torch.empty_like(x)
-        lib.call("adnm_igate_res_fwd", x.data_ptr(), r.data_ptr(), gama.data_ptr(), enhance.data_ptr(), threshold.data_ptr(), y.data_ptr(), B, L, C,
-                 _stream())
+        lib.call("adnm_igate_res_fwd", x.data_ptr(), r.data_ptr(), per_token, gama.data_ptr(), enhance.data_ptr(), threshold.data_ptr(), y.data_ptr(),
+                 B, L, C, _stream())
         ctx.save_for_backward(x, r, gama, enhance, threshold)
-        ctx.rshape = res.shape
+        ctx.rshape, ctx.per_token = res.shape, per_token
         return y
 
     @staticmethod
@@ -1605,7 +1762,7 @@ class IGateResFn(torch.autograd.Function):
         nb = lib.query("adnm_igate_res_bwd_ws_bytes", B, L, C)
         ws = _ws(nb, dev)
         with FOLDS.defer(dev, ws):   # d res is complete when the launch ends; only the three scalar gradients go through the fold
-            lib.call("adnm_igate_res_bwd", dy.data_ptr(), x.data_ptr(), r.data_ptr(), gama.data_ptr(), enhance.data_ptr(), threshold.data_ptr(),
+            lib.call("adnm_igate_res_bwd", dy.data_ptr(), x.data_ptr(), r.data_ptr(), ctx.per_token, gama.data_ptr(), enhance.data_ptr(), threshold.data_ptr(),
                      dx.data_ptr(), dres.data_ptr(), dg.data_ptr(), de.data_ptr(), dt.data_ptr(), ws.data_ptr(), nb, B, L, C, _stream())
         return dx, dres.view(ctx.rshape), dg, de, dt
 
@@ -1613,8 +1770,8 @@ class IGateResFn(torch.autograd.Function):
 def igate_res(x, res, gama, enhance, threshold):
     _need_gpu(x)
     B, L, C = x.shape
-    if x.dtype != torch.float32 or C % 4 or res.numel() != B * C or any(p.numel() != 1 for p in (gama, enhance, threshold)):
-        _unsupported("igate_res", f"needs fp32 (B, L, C) tokens with 4 | C, a (B, 1, C) gate and 1-element scalars, got {x.dtype} {tuple(x.shape)}, "
+    if x.dtype != torch.float32 or C % 4 or res.numel() not in (B * C, B * L * C) or any(p.numel() != 1 for p in (gama, enhance, threshold)):
+        _unsupported("igate_res", f"needs fp32 (B, L, C) tokens with 4 | C, a (B, 1, C) or (B, L, C) gate and 1-element scalars, got {x.dtype} {tuple(x.shape)}, "
                                   f"gate {tuple(res.shape)}")
     return IGateResFn.apply(x, res, gama, enhance, threshold)
 

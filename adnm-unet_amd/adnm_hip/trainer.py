@@ -248,8 +248,30 @@ class FlatTrainer:
 
     def _prepare(self, x, tgt):
         self.model.zero_grad(set_to_none=True)
-        self._fwd_bwd(x, tgt)
-        self._flatten()
+        # fp8 (BASELINE config 5): the dry run and the calibration step run on bf16 operands; the calibration step — after the
+        # parameters have moved into the flat buffer, so that the call-site keys are the final addresses — collects every GEMM
+        # operand's amax, from which adnm_quant_update makes the first scales.  From then on the steps run on fp8 operands and
+        # re-calibrate themselves every ops.QUANT.period steps (delayed per-tensor scaling, all on the device: graph-replayable).
+        self.fp8 = ops.mfma_precision() == "fp8" and x.is_cuda
+        if self.fp8:
+            ops.set_mfma_precision("bf16")
+        try:
+            self._fwd_bwd(x, tgt)
+            self._flatten()
+            if self.fp8:
+                ops.QUANT.reset(x.device)
+                ops.QUANT.calibrating = True
+                for p in self.used:
+                    p.grad = None
+                self._run_eager(x, tgt)
+                ops.QUANT.calibrating = False
+                ops.QUANT.update(x.device)
+                for p in self.used:
+                    p.grad = None
+        finally:
+            ops.QUANT.calibrating = False
+            if self.fp8:
+                ops.set_mfma_precision("fp8")
         if not self.use_graph:
             return
         self.sx, self.st = x.clone(), tgt.clone()
@@ -353,6 +375,8 @@ class FlatTrainer:
                 p.grad = None
         self._reduce_end(pending)
         self._optimizer_step()
+        if getattr(self, "fp8", False):
+            ops.QUANT.update(self.flat_g.device)   # one launch: amax -> scales on calibration steps, the next step's record flags
         self._steps += 1
         return loss
 

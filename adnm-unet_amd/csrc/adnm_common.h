@@ -36,7 +36,7 @@ void adnm_launch_fold(const char* prof_name, const float* part, int rows, int n,
 // counters from the per-device ring, NULL on failure.
 int64_t adnm_lgemm_ws_bytes(int64_t I, int64_t J, int64_t R, int nbs);
 int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, void* ws,
-                      int64_t ws_bytes, int64_t I, int64_t J, int64_t R, int nbs, int prec, hipStream_t st);
+                      int64_t ws_bytes, int64_t I, int64_t J, int64_t R, int nbs, int prec, float* q, hipStream_t st);
 int* adnm_take_tickets(int n, hipStream_t st);
 
 #define ADNM_REQUIRE(cond, ...)            \
@@ -120,25 +120,135 @@ struct Io<uint16_t> {  // bf16 storage
   static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
-// ---- MFMA precision of the GEMM-shaped kernels (tsgemm, skgemm, conv3): ADNM_MFMA_F32 = v_mfma_f32_16x16x4_f32 (exact fp32, an fmaf
-// chain); ADNM_MFMA_BF16 = operands rounded to bf16 (RNE) on the way into v_mfma_f32_16x16x16_bf16, fp32 accumulation — the arithmetic
-// of BASELINE's bf16 configs at 8x the matrix rate.  Lane (i, kq) of a 16x16x16 bf16 operand holds k = 4*kq .. 4*kq+3: exactly the
-// four consecutive reduction steps one float4 fragment load provides, so both precisions share every loader.
+// ---- MFMA precision ladder of the GEMM-shaped kernels (tsgemm, skgemm / lgemm, conv3) — all on gfx950's own instructions:
+//   ADNM_MFMA_F32  = v_mfma_f32_16x16x4_f32   (exact fp32: an fmaf chain; the bit-level parity path);
+//   ADNM_MFMA_BF16 = v_mfma_f32_16x16x32_bf16 (operands rounded to bf16, RNE, on the way in; fp32 accumulation) — BASELINE's bf16 configs;
+//   ADNM_MFMA_FP8  = v_mfma_f32_16x16x32_{fp8,bf8}_fp8 (config 5): per-tensor scaled OCP e4m3 for activations and weights, e5m2 ("bf8")
+//                    for gradients, saturating, fp32 accumulation; the accumulator is multiplied by 1 / (scale_a * scale_b) on the way out.
+// One MFMA step = 32 reduction steps = 8 per lane.  Every kernel feeds BOTH operands of a step through the same lane -> k map (a dot
+// product does not care which k a lane holds as long as the two operands agree), so a lane's 8 values are simply "two float4 fragment
+// loads" in all three precisions and the loaders are shared.
 using adnm_f32x4 = __attribute__((ext_vector_type(4))) float;
-using adnm_bf16x4 = __attribute__((ext_vector_type(4))) short;
-__device__ __forceinline__ adnm_bf16x4 adnm_pack_bf16(float a, float b, float c, float d) {
-  using bf4 = __attribute__((ext_vector_type(4))) __bf16;
-  const adnm_f32x4 v = {a, b, c, d};
-  const bf4 h = __builtin_convertvector(v, bf4);   // two v_cvt_pk_bf16_f32
-  return __builtin_bit_cast(adnm_bf16x4, h);
+using adnm_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+// Quantisation record of one GEMM call site (device memory, 8 floats = 32 B; layout documented in include/adnm_hip.h):
+// scale_a multiplies the first ("activation-like") operand, scale_b the weight; amax_* collect max |value| of what the launch read
+// (atomic max on the bit pattern: non-negative floats order like unsigned ints) when record != 0.
+struct AdnmQuant {
+  float scale_a, scale_b, amax_a, amax_b, fmax_a, fmax_b, record, pad;
+};
+
+__device__ __forceinline__ adnm_bf16x8 adnm_pack_bf16x8(const float (&v)[8]) {
+  using f8 = __attribute__((ext_vector_type(8))) float;
+  const f8 t = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+  return __builtin_convertvector(t, adnm_bf16x8);   // four v_cvt_pk_bf16_f32
 }
-// acc += A(16 x 16 k-steps) . B for one 16x16 block: a[e], b[e] = the operands of reduction step 4*kq + e of this lane
-template <bool BF16>
-__device__ __forceinline__ adnm_f32x4 adnm_mfma16(const float (&a)[4], const float (&b)[4], adnm_f32x4 acc) {
-  if (BF16) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(adnm_pack_bf16(a[0], a[1], a[2], a[3]), adnm_pack_bf16(b[0], b[1], b[2], b[3]), acc, 0, 0, 0);
+// 8 values -> 8 OCP fp8 (BF8 = false: e4m3, |x| <= 448; true: e5m2, |x| <= 57344), RNE, saturating (v_med3 first: the conversion
+// itself would turn an overflow into NaN).  The values are already multiplied by the tensor's scale.
+template <bool BF8>
+__device__ __forceinline__ long adnm_pack_f8x8(const float (&v)[8]) {
+  constexpr float kMax = BF8 ? 57344.f : 448.f;
+  float c[8];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
-  return acc;
+  for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_fmed3f(v[i], kMax, -kMax);
+  int lo = 0, hi = 0;
+  if (BF8) {
+    lo = __builtin_amdgcn_cvt_pk_bf8_f32(c[0], c[1], lo, false), lo = __builtin_amdgcn_cvt_pk_bf8_f32(c[2], c[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_bf8_f32(c[4], c[5], hi, false), hi = __builtin_amdgcn_cvt_pk_bf8_f32(c[6], c[7], hi, true);
+  } else {
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], lo, false), lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], hi, false), hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+  }
+  return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
+}
+// acc += P(32 reduction steps) . Q for one 16 x 16 block: p[e], q[e] = the operands of this lane's e-th reduction step of the group.
+// P_BF8 / Q_BF8: that operand is a gradient (e5m2) in the fp8 mode.  In the fp8 mode p / q are already scaled.
+template <int PREC, bool P_BF8 = false, bool Q_BF8 = false>
+__device__ __forceinline__ adnm_f32x4 adnm_mfma32(const float (&p)[8], const float (&q)[8], adnm_f32x4 acc) {
+  if constexpr (PREC == ADNM_MFMA_BF16) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(adnm_pack_bf16x8(p), adnm_pack_bf16x8(q), acc, 0, 0, 0);
+  } else if constexpr (PREC == ADNM_MFMA_FP8) {
+    const long a = adnm_pack_f8x8<P_BF8>(p), b = adnm_pack_f8x8<Q_BF8>(q);
+    if constexpr (P_BF8 && Q_BF8) return __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(a, b, acc, 0, 0, 0);
+    else if constexpr (P_BF8) return __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(a, b, acc, 0, 0, 0);
+    else if constexpr (Q_BF8) return __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(a, b, acc, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p[e], q[e], acc, 0, 0, 0);
+    return acc;
+  }
+}
+// the same for ONE group of 16 reduction steps (4 per lane): the odd group at the end of a reduction.  The narrow modes run the 32-step
+// instruction on a zero upper half (products with zero operands add nothing).
+template <int PREC, bool P_BF8 = false, bool Q_BF8 = false>
+__device__ __forceinline__ adnm_f32x4 adnm_mfma16(const float (&p)[4], const float (&q)[4], adnm_f32x4 acc) {
+  if constexpr (PREC == ADNM_MFMA_F32) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p[e], q[e], acc, 0, 0, 0);
+    return acc;
+  } else {
+    const float p8[8] = {p[0], p[1], p[2], p[3], 0.f, 0.f, 0.f, 0.f}, q8[8] = {q[0], q[1], q[2], q[3], 0.f, 0.f, 0.f, 0.f};
+    return adnm_mfma32<PREC, P_BF8, Q_BF8>(p8, q8, acc);
+  }
+}
+// A lane's packed operand of one 32-step group: built ONCE per loaded fragment (scale, saturate, convert), used by every MFMA that reads it
+template <int PREC>
+struct AdnmFrag {
+  float v[8];
+};
+template <>
+struct AdnmFrag<ADNM_MFMA_BF16> {
+  adnm_bf16x8 v;
+};
+template <>
+struct AdnmFrag<ADNM_MFMA_FP8> {
+  long v;
+};
+// lo = the lane's 4 reduction steps of the group's first half, hi = of its second half (hi == nullptr: an odd last half, zeros)
+template <int PREC, bool BF8>
+__device__ __forceinline__ AdnmFrag<PREC> adnm_make_frag(const float (&lo)[4], const float* hi, float scale) {
+  AdnmFrag<PREC> f;
+  float t[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) t[e] = lo[e], t[4 + e] = hi ? hi[e] : 0.f;
+  if constexpr (PREC == ADNM_MFMA_BF16) {
+    f.v = adnm_pack_bf16x8(t);
+  } else if constexpr (PREC == ADNM_MFMA_FP8) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] *= scale;
+    f.v = adnm_pack_f8x8<BF8>(t);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f.v[e] = t[e];
+  }
+  return f;
+}
+// HALF: only the first 16 steps of the group are real (fp32: skip the zero half's four MFMAs; the narrow modes multiply zeros)
+template <int PREC, bool P_BF8, bool Q_BF8, bool HALF = false>
+__device__ __forceinline__ adnm_f32x4 adnm_mma(const AdnmFrag<PREC>& p, const AdnmFrag<PREC>& q, adnm_f32x4 acc) {
+  if constexpr (PREC == ADNM_MFMA_BF16) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(p.v, q.v, acc, 0, 0, 0);
+  } else if constexpr (PREC == ADNM_MFMA_FP8) {
+    if constexpr (P_BF8 && Q_BF8) return __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(p.v, q.v, acc, 0, 0, 0);
+    else if constexpr (P_BF8) return __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(p.v, q.v, acc, 0, 0, 0);
+    else if constexpr (Q_BF8) return __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(p.v, q.v, acc, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(p.v, q.v, acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int e = 0; e < (HALF ? 4 : 8); ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p.v[e], q.v[e], acc, 0, 0, 0);
+    return acc;
+  }
+}
+
+__device__ __forceinline__ float adnm_amax4(float m, float a, float b, float c, float d) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(a), fabsf(b))), fmaxf(fabsf(c), fabsf(d)));
+}
+// wave-wide max of a non-negative value, then ONE atomic max per wave on the record's slot (order-independent: deterministic)
+__device__ __forceinline__ void adnm_amax_commit(float* slot, float m) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(m));
 }
 
 // ---- math ----------------------------------------------------------------------------------

@@ -55,6 +55,7 @@ struct ConvArgs {
   int B, H, W, K, N, nsplit, chunks_per_split;
   int TW, RB, TH, VR, tiles_x;
   int vec_in, vec_w, vec_out;         // 16-byte access is legal for the input rows / the weight's reduction axis / the output rows
+  AdnmQuant* q;                       // quantisation record (fp8 scales, amax collection) or NULL
 };
 
 // pixel row of tall-image position (v, x), or -1 outside the images
@@ -65,9 +66,11 @@ __device__ __forceinline__ int64_t pixel_of(int v, int x, int B, int H, int W, i
 }
 
 // ---- stage the (TH+2) x (TW+2) tile of channels [c0, c0+16) of (in [* act'(in2)]) into LDS, zeros outside
+// (scale: the fp8 mode stages value * scale; amax: running max |value| of what this thread staged, before scaling)
 template <int ACT>
 __device__ __forceinline__ void stage_tile(const float* __restrict__ in, int64_t ldin, const float* __restrict__ in2, int64_t ldin2, bool vec,
-                                           int K, int B, int H, int W, int VR, int TW, int TH, float* sIn, int v0, int x0, int c0) {
+                                           int K, int B, int H, int W, int VR, int TW, int TH, float* sIn, int v0, int x0, int c0,
+                                           float scale = 1.f, float* amax = nullptr) {
   const int TWp = TW + 2, PT = (TH + 2) * TWp;
   for (int it = threadIdx.x; it < PT * 4; it += kBlock) {
     const int pix = it >> 2, q = it & 3, r = pix / TWp, c = pix - r * TWp, ch = c0 + 4 * q;
@@ -90,15 +93,27 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ in, int64_t
           }
       }
     }
-    *reinterpret_cast<float4*>(sIn + pix * CKP + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+    if (amax) *amax = adnm_amax4(*amax, v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(sIn + pix * CKP + 4 * q) = make_float4(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale);
   }
 }
 
 // ================================================================================================ forward / dgrad
 // LDS: [input tile (TH+2)(TW+2) x CKP] [weights of the chunk: 9 taps x NB*16 channels x CKP]
-template <int NB, int ACT_IN, int ACT_OUT, bool BF16>
+// PREC = ADNM_MFMA_*; A_BF8: in the fp8 mode the pixel rows are a gradient (e5m2) — the dgrad use.
+template <int NB, int ACT_IN, int ACT_OUT, int PREC, bool A_BF8>
 __global__ __launch_bounds__(kBlock) void conv3_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // fp8: the tile and the weights are staged already multiplied by their per-tensor scales (the accumulators are un-scaled in the
+  // epilogue); rec_a / rec_b (workgroup-uniform): collect max |value| of the pixels / weights staged — the first channel group /
+  // first pixel tile only, so every element is seen once (halo pixels twice, harmless for a max)
+  float q_sa = 1.f, q_sb = 1.f, amax_a = 0.f, amax_b = 0.f;
+  bool rec_a = false, rec_b = false;
+  if (a.q) {
+    if (PREC == ADNM_MFMA_FP8) q_sa = a.q->scale_a, q_sb = a.q->scale_b;
+    const bool rec = a.q->record != 0.f;
+    rec_a = rec && blockIdx.y == 0, rec_b = rec && blockIdx.x == 0;
+  }
   const int TWp = a.TW + 2;
   float* sIn = smem;
   float* sW = smem + (a.TH + 2) * TWp * CKP;
@@ -119,7 +134,8 @@ __global__ __launch_bounds__(kBlock) void conv3_kernel(ConvArgs a) {
   const int cend = cbeg + a.chunks_per_split < nchunks ? cbeg + a.chunks_per_split : nchunks;
   for (int c = cbeg; c < cend; ++c) {
     __syncthreads();
-    stage_tile<ACT_IN>(a.in, a.ldin, a.in2, a.ldin2, a.vec_in != 0, a.K, a.B, a.H, a.W, a.VR, a.TW, a.TH, sIn, v0, x0, c * CK);
+    stage_tile<ACT_IN>(a.in, a.ldin, a.in2, a.ldin2, a.vec_in != 0, a.K, a.B, a.H, a.W, a.VR, a.TW, a.TH, sIn, v0, x0, c * CK, q_sa,
+                       rec_a ? &amax_a : nullptr);
     // weights of this chunk: sW[(tap*NB*16 + nl)*CKP + kq*4 .. +3] = W(n0 + nl, tap, c*16 + 4 kq ..)
     for (int it = threadIdx.x; it < 9 * NB * 16 * 4; it += kBlock) {
       const int kq = it & 3, nl = (it >> 2) % (NB * 16), tap = it / (NB * 64);
@@ -136,28 +152,52 @@ __global__ __launch_bounds__(kBlock) void conv3_kernel(ConvArgs a) {
             if (k0 + e < a.K) v[e] = wp[(int64_t)e * a.sk];
         }
       }
-      *reinterpret_cast<float4*>(sW + (tap * NB * 16 + nl) * CKP + 4 * kq) = make_float4(v[0], v[1], v[2], v[3]);
+      if (rec_b) amax_b = adnm_amax4(amax_b, v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(sW + (tap * NB * 16 + nl) * CKP + 4 * kq) = make_float4(v[0] * q_sb, v[1] * q_sb, v[2] * q_sb, v[3] * q_sb);
     }
     __syncthreads();
+    // one MFMA step = 32 reduction steps = the chunk's 16 channels of TWO taps (tap 8 runs on a zero upper half)
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int toff = ((tap / 3) * TWp + (tap % 3)) * CKP;
-      float wa[NB][4], xb[MB][4];
+    for (int tp = 0; tp < 9; tp += 2) {
+      float wa[NB][2][4], xb[MB][2][4];
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const float4 t = *reinterpret_cast<const float4*>(sW + (tap * NB * 16 + nb * 16 + j) * CKP + 4 * kk);
-        wa[nb][0] = t.x; wa[nb][1] = t.y; wa[nb][2] = t.z; wa[nb][3] = t.w;
+      for (int h = 0; h < 2; ++h) {
+        const int tap = tp + h < 9 ? tp + h : 8;
+        const int toff = ((tap / 3) * TWp + (tap % 3)) * CKP;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float4 t = *reinterpret_cast<const float4*>(sW + (tap * NB * 16 + nb * 16 + j) * CKP + 4 * kk);
+          wa[nb][h][0] = t.x; wa[nb][h][1] = t.y; wa[nb][h][2] = t.z; wa[nb][h][3] = t.w;
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const float4 t = *reinterpret_cast<const float4*>(sIn + base[mb] + toff);
+          xb[mb][h][0] = t.x; xb[mb][h][1] = t.y; xb[mb][h][2] = t.z; xb[mb][h][3] = t.w;
+        }
       }
+      const bool pair = tp + 1 < 9;
+      AdnmFrag<PREC> fw[NB], fx[MB];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const float4 t = *reinterpret_cast<const float4*>(sIn + base[mb] + toff);
-        xb[mb][0] = t.x; xb[mb][1] = t.y; xb[mb][2] = t.z; xb[mb][3] = t.w;
-      }
+      for (int nb = 0; nb < NB; ++nb) fw[nb] = adnm_make_frag<PREC, false>(wa[nb][0], pair ? wa[nb][1] : nullptr, 1.f);   // (already scaled)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) fx[mb] = adnm_make_frag<PREC, A_BF8>(xb[mb][0], pair ? xb[mb][1] : nullptr, 1.f);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = adnm_mfma16<BF16>(wa[nb], xb[mb], acc[nb][mb]);
+        for (int mb = 0; mb < MB; ++mb) {
+          if (tp + 1 < 9) acc[nb][mb] = adnm_mma<PREC, false, A_BF8, false>(fw[nb], fx[mb], acc[nb][mb]);
+          else acc[nb][mb] = adnm_mma<PREC, false, A_BF8, true>(fw[nb], fx[mb], acc[nb][mb]);
+        }
     }
+  }
+  if (rec_a) adnm_amax_commit(&a.q->amax_a, amax_a);
+  if (rec_b) adnm_amax_commit(&a.q->amax_b, amax_b);
+  if (PREC == ADNM_MFMA_FP8) {   // back to the operands' own scale (before partials are written, bias is added)
+    const float inv = 1.0f / (q_sa * q_sb);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = acc[nb][mb] * inv;
   }
   // epilogue.  D layout: row = channel (kk*4 + reg) of the block, column = pixel j
   const int64_t M = (int64_t)a.B * a.H * a.W;
@@ -223,7 +263,7 @@ struct WgArgs {
   int vec_in, vec_do;
 };
 
-template <int NB, int ACT, bool BF16>
+template <int NB, int ACT, int PREC>   // PREC: fp32 or bf16 (the fp8 configuration keeps bf16 operands for the weight gradient)
 __global__ __launch_bounds__(kBlock) void conv3_wgrad_kernel(WgArgs a) {
   constexpr int DP = NB * 16 + 16;   // pitch of a dpre pixel row: (DP mod 32) == 16 -> conflict-free A-operand reads
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -268,26 +308,33 @@ __global__ __launch_bounds__(kBlock) void conv3_wgrad_kernel(WgArgs a) {
       *reinterpret_cast<float4*>(sD + pxl * DP + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
     }
     __syncthreads();
+    // reduction = the pixels of the wave's MB = 2 pixel blocks: lane (., kk) takes pixels 4 kk .. 4 kk + 3 of each (step e) — 8 per lane =
+    // one 32-step MFMA group
+    static_assert(MB == 2, "the weight-gradient step pairs the wave's two pixel blocks");
+    float av[NB][2][4];
+    const float* bp[2][4];
 #pragma unroll
     for (int pbw = 0; pbw < MB; ++pbw) {
       const int pb = wave * MB + pbw;
-      // reduction = the 16 pixels of the block: lane (., kk) takes pixels 4 kk .. 4 kk + 3 (step e)
-      float av[NB][4];
-      const float* bp[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int jj = 4 * kk + e, pxl = pb * 16 + jj, dy_ = jj / a.TW, dx_ = jj - dy_ * a.TW;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) av[nb][e] = sD[pxl * DP + nb * 16 + j];   // A[i = channel][k = pixel]
-        bp[e] = sIn + ((pb * a.RB + dy_) * TWp + dx_) * CKP + j;                   // B[k = pixel][j = input channel], tap (0,0)
+        for (int nb = 0; nb < NB; ++nb) av[nb][pbw][e] = sD[pxl * DP + nb * 16 + j];   // A[i = channel][k = pixel]
+        bp[pbw][e] = sIn + ((pb * a.RB + dy_) * TWp + dx_) * CKP + j;                   // B[k = pixel][j = input channel], tap (0,0)
       }
+    }
+    AdnmFrag<PREC> fa[NB];
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int toff = ((tap / 3) * TWp + (tap % 3)) * CKP;
-        const float bv[4] = {bp[0][toff], bp[1][toff], bp[2][toff], bp[3][toff]};
+    for (int nb = 0; nb < NB; ++nb) fa[nb] = adnm_make_frag<PREC, false>(av[nb][0], av[nb][1], 1.f);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[tap][nb] = adnm_mfma16<BF16>(av[nb], bv, acc[tap][nb]);
-      }
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = ((tap / 3) * TWp + (tap % 3)) * CKP;
+      const float b0[4] = {bp[0][0][toff], bp[0][1][toff], bp[0][2][toff], bp[0][3][toff]};
+      const float b1[4] = {bp[1][0][toff], bp[1][1][toff], bp[1][2][toff], bp[1][3][toff]};
+      const AdnmFrag<PREC> fb = adnm_make_frag<PREC, false>(b0, b1, 1.f);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[tap][nb] = adnm_mma<PREC, false, false>(fa[nb], fb, acc[tap][nb]);
     }
     if (a.want_bias && blockIdx.y == 0 && lane < NB * 16) {
 #pragma unroll 8
@@ -355,15 +402,17 @@ int launch_conv(const ConvArgs& a, const Geo& g, const Split& s, int prec, hipSt
   const size_t smem = sizeof(float) * ((size_t)(g.TH + 2) * (g.TW + 2) * CKP + (size_t)9 * s.nb * 16 * CKP);
   const dim3 grid((unsigned)(g.tiles_x * g.tiles_y), (unsigned)s.ngroups, (unsigned)s.nsplit);
   ADNM_PROF(prof, st, bytes);
-  if (prec == ADNM_MFMA_BF16) {
-    if (s.nb == 4) conv3_kernel<4, ACT_IN, ACT_OUT, true><<<grid, kBlock, smem, st>>>(a);
-    else if (s.nb == 2) conv3_kernel<2, ACT_IN, ACT_OUT, true><<<grid, kBlock, smem, st>>>(a);
-    else conv3_kernel<1, ACT_IN, ACT_OUT, true><<<grid, kBlock, smem, st>>>(a);
-  } else {
-    if (s.nb == 4) conv3_kernel<4, ACT_IN, ACT_OUT, false><<<grid, kBlock, smem, st>>>(a);
-    else if (s.nb == 2) conv3_kernel<2, ACT_IN, ACT_OUT, false><<<grid, kBlock, smem, st>>>(a);
-    else conv3_kernel<1, ACT_IN, ACT_OUT, false><<<grid, kBlock, smem, st>>>(a);
-  }
+#define CV(PRECV, BF8V)                                                                                  \
+  do {                                                                                                   \
+    if (s.nb == 4) conv3_kernel<4, ACT_IN, ACT_OUT, PRECV, BF8V><<<grid, kBlock, smem, st>>>(a);         \
+    else if (s.nb == 2) conv3_kernel<2, ACT_IN, ACT_OUT, PRECV, BF8V><<<grid, kBlock, smem, st>>>(a);    \
+    else conv3_kernel<1, ACT_IN, ACT_OUT, PRECV, BF8V><<<grid, kBlock, smem, st>>>(a);                   \
+  } while (0)
+  if (prec == ADNM_MFMA_BF16) CV(ADNM_MFMA_BF16, false);
+  else if (prec == ADNM_MFMA_FP8) CV(ADNM_MFMA_FP8, false);
+  else if (prec == ADNM_MFMA_FP8_GRAD) CV(ADNM_MFMA_FP8, true);
+  else CV(ADNM_MFMA_F32, false);
+#undef CV
   return ADNM_OK;
 }
 
@@ -383,9 +432,11 @@ extern "C" int64_t adnm_conv3_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t 
 // and the channels-last one (Cout,3,3,Cin) (ws_n=9K, ws_tap=K, ws_k=1) are read in place.
 extern "C" int adnm_conv3_fwd(const float* in, int64_t ldin, const float* w, int64_t ws_n, int64_t ws_tap, int64_t ws_k, const float* bias,
                               float* out, int64_t ldo, float* pre, int64_t ldpre, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W,
-                              int64_t K, int64_t N, int act, int prec, adnm_stream_t stream) {
+                              int64_t K, int64_t N, int act, int prec, float* q, adnm_stream_t stream) {
   if (int rc = check_shape("conv3_fwd", B, H, W, K, N)) return rc;
   ADNM_REQUIRE(in && w && out, "conv3_fwd: null pointer");
+  ADNM_REQUIRE(prec >= ADNM_MFMA_F32 && prec <= ADNM_MFMA_FP8, "conv3_fwd: bad prec %d", prec);
+  ADNM_REQUIRE(prec != ADNM_MFMA_FP8 || q, "conv3_fwd: the fp8 mode needs a quantisation record");
   ADNM_REQUIRE(ldin >= K && ldo >= N && (!pre || ldpre >= N), "conv3_fwd: row strides smaller than the rows");
   ADNM_REQUIRE(act == ADNM_ACT_NONE || act == ADNM_ACT_GELU, "conv3_fwd: activation %d not in {none, gelu}", act);
   const Geo g = make_geo(B, H, W);
@@ -403,6 +454,7 @@ extern "C" int adnm_conv3_fwd(const float* in, int64_t ldin, const float* w, int
   a.vec_in = al16(in) && ldin % 4 == 0 && K % 4 == 0;
   a.vec_w = ws_k == 1 && al16(w) && ws_n % 4 == 0 && ws_tap % 4 == 0 && K % 4 == 0;
   a.vec_out = al16(out) && ldo % 4 == 0 && N % 4 == 0 && (!pre || (al16(pre) && ldpre % 4 == 0));
+  a.q = reinterpret_cast<AdnmQuant*>(q);
   hipStream_t st = (hipStream_t)stream;
   const double bytes = 4.0 * ((double)B * H * W * (K + N * (pre ? 2 : 1)) + 9.0 * K * N);
   if (act == ADNM_ACT_GELU && s.nsplit == 1) launch_conv<ADNM_ACT_NONE, ADNM_ACT_GELU>(a, g, s, prec, st, "conv3_fwd", bytes);
@@ -423,9 +475,12 @@ extern "C" int adnm_conv3_fwd(const float* in, int64_t ldin, const float* w, int
 // din = conv3x3^T(dout * act'(pre), w): the input gradient of adnm_conv3_fwd (K = Cin, N = Cout of the forward conv, same w strides).
 extern "C" int adnm_conv3_dgrad(const float* dout, int64_t lddo, const float* pre, int64_t ldpre, int act, const float* w, int64_t ws_n,
                                 int64_t ws_tap, int64_t ws_k, float* din, int64_t lddin, void* ws, int64_t ws_bytes, int64_t B, int64_t H,
-                                int64_t W, int64_t K, int64_t N, int prec, adnm_stream_t stream) {
+                                int64_t W, int64_t K, int64_t N, int prec, float* q, adnm_stream_t stream) {
   if (int rc = check_shape("conv3_dgrad", B, H, W, K, N)) return rc;
   ADNM_REQUIRE(dout && w && din, "conv3_dgrad: null pointer");
+  ADNM_REQUIRE(prec >= ADNM_MFMA_F32 && prec <= ADNM_MFMA_FP8_GRAD, "conv3_dgrad: bad prec %d", prec);
+  ADNM_REQUIRE((prec != ADNM_MFMA_FP8 && prec != ADNM_MFMA_FP8_GRAD) || q, "conv3_dgrad: the fp8 modes need a quantisation record");
+  if (prec == ADNM_MFMA_FP8) prec = ADNM_MFMA_FP8_GRAD;   // the pixel rows of this op are always a gradient
   ADNM_REQUIRE(act == ADNM_ACT_NONE || (act == ADNM_ACT_GELU && pre), "conv3_dgrad: activation %d needs the saved pre-activation", act);
   ADNM_REQUIRE(lddo >= N && lddin >= K && (!pre || ldpre >= N), "conv3_dgrad: row strides smaller than the rows");
   const Geo g = make_geo(B, H, W);
@@ -443,6 +498,7 @@ extern "C" int adnm_conv3_dgrad(const float* dout, int64_t lddo, const float* pr
   a.vec_in = al16(dout) && lddo % 4 == 0 && N % 4 == 0 && (!pre || (al16(pre) && ldpre % 4 == 0));
   a.vec_w = a.sk == 1 && al16(w) && a.sn % 4 == 0 && a.st % 4 == 0 && N % 4 == 0;
   a.vec_out = al16(din) && lddin % 4 == 0 && K % 4 == 0;
+  a.q = reinterpret_cast<AdnmQuant*>(q);
   hipStream_t st = (hipStream_t)stream;
   const double bytes = 4.0 * ((double)B * H * W * (K + N * (act != ADNM_ACT_NONE ? 2 : 1)) + 9.0 * K * N);
   if (act == ADNM_ACT_GELU) launch_conv<ADNM_ACT_GELU, ADNM_ACT_NONE>(a, g, s, prec, st, "conv3_dgrad", bytes);
@@ -489,6 +545,7 @@ extern "C" int64_t adnm_conv3_wgrad_ws_bytes(int64_t B, int64_t H, int64_t W, in
 extern "C" int adnm_conv3_wgrad(const float* dout, int64_t lddo, const float* pre, int64_t ldpre, int act, const float* in, int64_t ldin,
                                 float* dw, float* dbias, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W, int64_t K, int64_t N,
                                 int prec, adnm_stream_t stream) {
+  if (prec == ADNM_MFMA_FP8 || prec == ADNM_MFMA_FP8_GRAD) prec = ADNM_MFMA_BF16;   // the weight gradient keeps bf16 operands in the fp8 configuration
   if (int rc = check_shape("conv3_wgrad", B, H, W, K, N)) return rc;
   ADNM_REQUIRE(dout && in && dw, "conv3_wgrad: null pointer");
   ADNM_REQUIRE(act == ADNM_ACT_NONE || (act == ADNM_ACT_GELU && pre), "conv3_wgrad: activation %d needs the saved pre-activation", act);
@@ -521,8 +578,8 @@ extern "C" int adnm_conv3_wgrad(const float* dout, int64_t lddo, const float* pr
   } while (0)
 #define WG(NBV)                                                                               \
   do {                                                                                        \
-    if (act == ADNM_ACT_GELU) { if (prec == ADNM_MFMA_BF16) WG1(NBV, ADNM_ACT_GELU, true); else WG1(NBV, ADNM_ACT_GELU, false); } \
-    else { if (prec == ADNM_MFMA_BF16) WG1(NBV, ADNM_ACT_NONE, true); else WG1(NBV, ADNM_ACT_NONE, false); }                     \
+    if (act == ADNM_ACT_GELU) { if (prec == ADNM_MFMA_BF16) WG1(NBV, ADNM_ACT_GELU, ADNM_MFMA_BF16); else WG1(NBV, ADNM_ACT_GELU, ADNM_MFMA_F32); } \
+    else { if (prec == ADNM_MFMA_BF16) WG1(NBV, ADNM_ACT_NONE, ADNM_MFMA_BF16); else WG1(NBV, ADNM_ACT_NONE, ADNM_MFMA_F32); }                     \
   } while (0)
     if (p.nb == 2) WG(2);
     else WG(1);

@@ -17,7 +17,7 @@ void adnm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* adnm_last_error(void) { return g_err; }
-extern "C" int adnm_abi_version(void) { return 6; }   // 6: tap_ld of adnm_adnprep_*; 5: `prec` of adnm_tsgemm_nt; 4: workspace of adnm_colsum
+extern "C" int adnm_abi_version(void) { return 7; }   // 7: precision ladder (`q` of the GEMM-shaped entry points, adnm_quant_update, fp8); 6: tap_ld of adnm_adnprep_*; 5: `prec` of adnm_tsgemm_nt; 4: workspace of adnm_colsum
 
 // ---- profiler: OFF by default (one relaxed atomic load per launch).  When bench.py enables it, every kernel
 // launch of the library is bracketed by hipEventRecord on the stream it is launched on; adnm_prof_collect()
@@ -334,5 +334,38 @@ extern "C" int adnm_colsum(const float* x, float* out, int64_t rows, int64_t n, 
   ADNM_CHECK_LAUNCH("colsum_partial");
   adnm_launch_fold("colsum", (const float*)ws, bands, (int)n, {out, (int)n}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
   ADNM_CHECK_LAUNCH("colsum");
+  return ADNM_OK;
+}
+
+
+// ---- delayed per-tensor scaling of the fp8 configuration (include/adnm_hip.h: adnm_quant_update).  One workgroup: a model has a
+// few hundred GEMM call sites, and a single workgroup can advance the step counter behind its own barrier.
+namespace {
+__global__ __launch_bounds__(256) void quant_update_kernel(AdnmQuant* __restrict__ tab, int n, float* __restrict__ state, float headroom) {
+  const float c = state[0], period = state[1] < 1.f ? 1.f : state[1];
+  const bool was_recording = fmodf(c, period) == 0.f;        // the step that just ended collected amax
+  const bool will_record = fmodf(c + 1.f, period) == 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    AdnmQuant r = tab[i];
+    if (was_recording) {
+      if (r.amax_a > 0.f && r.fmax_a > 0.f) r.scale_a = r.fmax_a / (r.amax_a * headroom);
+      if (r.amax_b > 0.f && r.fmax_b > 0.f) r.scale_b = r.fmax_b / (r.amax_b * headroom);
+      r.amax_a = r.amax_b = 0.f;
+    }
+    r.record = will_record ? 1.f : 0.f;
+    tab[i] = r;
+  }
+  __syncthreads();   // every thread has read the counter
+  if (threadIdx.x == 0) state[0] = c + 1.f;
+}
+}  // namespace
+
+extern "C" int adnm_quant_update(float* table, int64_t n, float* state, float headroom, adnm_stream_t stream) {
+  ADNM_REQUIRE(table && state && n >= 0 && n < (1 << 20), "quant_update: bad arguments");
+  ADNM_REQUIRE(headroom >= 1.f, "quant_update: headroom %f must be >= 1", headroom);
+  hipStream_t st = (hipStream_t)stream;
+  ADNM_PROF("quant_update", st, 64.0 * (double)n);
+  quant_update_kernel<<<1, 256, 0, st>>>(reinterpret_cast<AdnmQuant*>(table), (int)n, state, headroom);
+  ADNM_CHECK_LAUNCH("quant_update");
   return ADNM_OK;
 }

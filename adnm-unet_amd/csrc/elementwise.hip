@@ -344,12 +344,12 @@ extern "C" int adnm_igate_bwd(const void* dy, const void* x, const float* enhanc
 namespace {
 __global__ __launch_bounds__(kBlock) void igate_res_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gama,
                                                                const float* __restrict__ enh, const float* __restrict__ thr, float* __restrict__ y,
-                                                               int B, int L, int C4) {
+                                                               int B, int L, int C4, int per_token) {
   const float a = *enh, t = *thr, gm = *gama;
   const int64_t n4 = (int64_t)B * L * C4;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
     const int c = (int)(i % C4), b = (int)(i / ((int64_t)L * C4));
-    const float4 v = Io<float>::ld4(x + i * 4), r = Io<float>::ld4(res + ((int64_t)b * C4 + c) * 4);
+    const float4 v = Io<float>::ld4(x + i * 4), r = Io<float>::ld4(res + (per_token ? i : (int64_t)b * C4 + c) * 4);
     Io<float>::st4(y + i * 4, make_float4(siluf_(a * (fmaf(gm, r.x, v.x) - t)), siluf_(a * (fmaf(gm, r.y, v.y) - t)),
                                           siluf_(a * (fmaf(gm, r.z, v.z) - t)), siluf_(a * (fmaf(gm, r.w, v.w) - t))));
   }
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void igate_res_fwd_kernel(const float* __re
 __global__ __launch_bounds__(kBlock) void igate_res_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ res,
                                                                const float* __restrict__ gama, const float* __restrict__ enh,
                                                                const float* __restrict__ thr, float* __restrict__ dx, float* __restrict__ dres,
-                                                               float* __restrict__ spart, int B, int L, int C4) {
+                                                               float* __restrict__ spart, int B, int L, int C4, int per_token) {
   __shared__ float4 sm[16][16];
   __shared__ float ss[3][kBlock / 64];
   const float a = *enh, t = *thr, gm = *gama;
@@ -370,12 +370,13 @@ __global__ __launch_bounds__(kBlock) void igate_res_bwd_kernel(const float* __re
   const int cq = (blockIdx.x % chunks) * 16 + cl;
   const bool valid = cq < C4;
   const int c = valid ? cq : 0;
-  const float4 r4 = Io<float>::ld4(res + ((int64_t)b * C4 + c) * 4);
-  const float rv[4] = {r4.x, r4.y, r4.z, r4.w};
+  float4 r4 = Io<float>::ld4(res + (per_token ? 0 : ((int64_t)b * C4 + c) * 4));
   float dr[4] = {0.f, 0.f, 0.f, 0.f}, s_g = 0.f, s_e = 0.f, s_t = 0.f;
   for (int l = valid ? sl : L; l < L; l += 16) {
     const int64_t off = (((int64_t)b * L + l) * C4 + c) * 4;
     const float4 v = Io<float>::ld4(x + off), g = Io<float>::ld4(dy + off);
+    if (per_token) r4 = Io<float>::ld4(res + off);
+    const float rv[4] = {r4.x, r4.y, r4.z, r4.w};
     const float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g.x, g.y, g.z, g.w};
     float o[4];
 #pragma unroll
@@ -388,12 +389,13 @@ __global__ __launch_bounds__(kBlock) void igate_res_bwd_kernel(const float* __re
       s_t += gp;
     }
     Io<float>::st4(dx + off, make_float4(o[0], o[1], o[2], o[3]));
+    if (per_token) Io<float>::st4(dres + off, make_float4(gm * o[0], gm * o[1], gm * o[2], gm * o[3]));
   }
   sm[sl][cl] = make_float4(dr[0], dr[1], dr[2], dr[3]);
   s_g = wave_sum(s_g), s_e = wave_sum(s_e), s_t = wave_sum(s_t);
   if ((threadIdx.x & 63) == 0) ss[0][threadIdx.x >> 6] = s_g, ss[1][threadIdx.x >> 6] = s_e, ss[2][threadIdx.x >> 6] = s_t;
   __syncthreads();
-  if (sl == 0 && valid) {
+  if (sl == 0 && valid && !per_token) {
     float4 acc = sm[0][cl];
 #pragma unroll
     for (int k = 1; k < 16; ++k) acc.x += sm[k][cl].x, acc.y += sm[k][cl].y, acc.z += sm[k][cl].z, acc.w += sm[k][cl].w;
@@ -415,20 +417,20 @@ extern "C" int64_t adnm_igate_res_bwd_ws_bytes(int64_t B, int64_t L, int64_t C) 
   return igate_res_blocks(B, C) * 4 * (int64_t)sizeof(float);
 }
 
-extern "C" int adnm_igate_res_fwd(const float* x, const float* res, const float* gama, const float* enhance, const float* threshold, float* y,
-                                  int64_t B, int64_t L, int64_t C, adnm_stream_t stream) {
+extern "C" int adnm_igate_res_fwd(const float* x, const float* res, int per_token, const float* gama, const float* enhance, const float* threshold,
+                                  float* y, int64_t B, int64_t L, int64_t C, adnm_stream_t stream) {
   ADNM_REQUIRE(x && res && gama && enhance && threshold && y, "igate_res_fwd: null pointer");
   ADNM_REQUIRE(B > 0 && L > 0 && C > 0 && C % 4 == 0 && B * L * C < (1ll << 31), "igate_res_fwd: bad shape B=%lld L=%lld C=%lld (4 | C)", (long long)B,
                (long long)L, (long long)C);
   hipStream_t st = (hipStream_t)stream;
   ADNM_PROF("igate_fwd", st, 4.0 * (2.0 * B * L * C + B * C));
-  igate_res_fwd_kernel<<<grid_for(B * L * C / 4), kBlock, 0, st>>>(x, res, gama, enhance, threshold, y, (int)B, (int)L, (int)(C / 4));
+  igate_res_fwd_kernel<<<grid_for(B * L * C / 4), kBlock, 0, st>>>(x, res, gama, enhance, threshold, y, (int)B, (int)L, (int)(C / 4), per_token);
   ADNM_CHECK_LAUNCH("igate_res_fwd");
   return ADNM_OK;
 }
 
-extern "C" int adnm_igate_res_bwd(const float* dy, const float* x, const float* res, const float* gama, const float* enhance, const float* threshold,
-                                  float* dx, float* dres, float* dgama, float* denhance, float* dthreshold, void* ws, int64_t ws_bytes, int64_t B,
+extern "C" int adnm_igate_res_bwd(const float* dy, const float* x, const float* res, int per_token, const float* gama, const float* enhance,
+                                  const float* threshold, float* dx, float* dres, float* dgama, float* denhance, float* dthreshold, void* ws, int64_t ws_bytes, int64_t B,
                                   int64_t L, int64_t C, adnm_stream_t stream) {
   ADNM_REQUIRE(dy && x && res && gama && enhance && threshold && dx && dres && dgama && denhance && dthreshold, "igate_res_bwd: null pointer");
   ADNM_REQUIRE(B > 0 && L > 0 && C > 0 && C % 4 == 0 && B * L * C < (1ll << 31), "igate_res_bwd: bad shape B=%lld L=%lld C=%lld (4 | C)", (long long)B,
@@ -442,7 +444,8 @@ extern "C" int adnm_igate_res_bwd(const float* dy, const float* x, const float* 
   float* spart = (float*)ws;
   {
     ADNM_PROF("igate_bwd", st, 4.0 * (3.0 * B * L * C + 2.0 * B * C));
-    igate_res_bwd_kernel<<<(unsigned)blocks, kBlock, 0, st>>>(dy, x, res, gama, enhance, threshold, dx, dres, spart, (int)B, (int)L, (int)(C / 4));
+    igate_res_bwd_kernel<<<(unsigned)blocks, kBlock, 0, st>>>(dy, x, res, gama, enhance, threshold, dx, dres, spart, (int)B, (int)L, (int)(C / 4),
+                                                               per_token);
   }
   ADNM_CHECK_LAUNCH("igate_res_bwd");
   adnm_launch_fold("igate_bwd_fold", spart, (int)blocks, 4, {dgama, 1}, {denhance, 1}, {dthreshold, 1}, {nullptr, 0}, st);   // deferrable

@@ -27,6 +27,9 @@ namespace {
 using f32x4 = adnm_f32x4;
 constexpr int kThreads = 256, kTile = 64, kStep = 32;
 
+// BF16: the LDS images hold bf16 pairs (rounded once, when a tile is staged).  fp32 AND fp8 keep fp32 images: the fp8 operands are
+// scaled / saturated / converted when a lane forms its fragment (the same code as the register-streaming kernel; an fp8 image would
+// quarter the LDS traffic of a kernel that is bound by the L2 -> CU fill, not by LDS).
 template <bool BF16>
 struct Geo {
   static constexpr int rc_stride = BF16 ? 24 : 40;   // words per RC row (32 reduction steps + pad)
@@ -48,6 +51,7 @@ struct LgArgs {
   int* tickets;
   int I, J, R;
   int tiles_j, nbs, kt_per_slice, nkt;
+  AdnmQuant* q;         // quantisation record (fp8 scales, amax collection) or NULL
 };
 
 // by value on purpose: `ok ? a : b` on two float4 OBJECTS selects an address and pushes both into scratch
@@ -59,8 +63,9 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));
 }
 
-template <bool B_OC, bool BF16, int D>
+template <bool B_OC, int PREC, bool A_BF8, int D>
 __global__ __launch_bounds__(kThreads) void lgemm_kernel(LgArgs p) {
+  constexpr bool BF16 = PREC == ADNM_MFMA_BF16;
   using G = Geo<BF16>;
   constexpr int kAW = G::rc_words, kBW = B_OC ? G::oc_words : G::rc_words;
   __shared__ __attribute__((aligned(16))) uint32_t lds[2 * (kAW + kBW)];
@@ -120,10 +125,33 @@ __global__ __launch_bounds__(kThreads) void lgemm_kernel(LgArgs p) {
       bv[u] = *reinterpret_cast<const float4*>(b_row[u] + (b_ok(kt, u) ? (B_OC ? r0 * (int)p.ldb : r0) : b_dead[u]));
     }
   };
+  // fp8: per-tensor scales from the call site's quantisation record (the accumulators are un-scaled in the epilogue); rec_a / rec_b
+  // (workgroup-uniform): collect max |value| of the A rows / B columns this workgroup stages — the first tile column / tile row only
+  float q_sa = 1.f, q_sb = 1.f, amax_a = 0.f, amax_b = 0.f;
+  bool rec_a = false, rec_b = false;
+  if (p.q) {
+    if (PREC == ADNM_MFMA_FP8) q_sa = p.q->scale_a, q_sb = p.q->scale_b;
+    const bool rec = p.q->record != 0.f;
+    rec_a = rec && (tile % p.tiles_j) == 0, rec_b = rec && (tile / p.tiles_j) == 0;
+  }
   auto stage = [&](int kt, int buf, const float4 (&av)[2], const float4 (&bv)[2]) {
     uint32_t* const sa = ldsA + buf * kAW;
     uint32_t* const sb = ldsB + buf * kBW;
     const bool oka = a_ok(kt);
+    if (rec_a) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float4 v = keep_if(oka, av[u]);
+        amax_a = adnm_amax4(amax_a, v.x, v.y, v.z, v.w);
+      }
+    }
+    if (rec_b) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float4 v = keep_if(b_ok(kt, u), bv[u]);
+        amax_b = adnm_amax4(amax_b, v.x, v.y, v.z, v.w);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const float4 v = keep_if(oka, av[u]);
@@ -159,8 +187,8 @@ __global__ __launch_bounds__(kThreads) void lgemm_kernel(LgArgs p) {
   auto compute = [&](int buf) {
     const uint32_t* const sa = ldsA + buf * kAW;
     const uint32_t* const sb = ldsB + buf * kBW;
-    if (BF16) {
-      uint4 fa[2], fb[2];   // 8 bf16 = reduction steps 8 kq .. 8 kq + 7 of the tile
+    if constexpr (BF16) {
+      uint4 fa[2], fb[2];   // 8 bf16 = reduction steps 8 kq .. 8 kq + 7 of the tile: ONE v_mfma_f32_16x16x32_bf16 per block pair
 #pragma unroll
       for (int a = 0; a < 2; ++a) fa[a] = *reinterpret_cast<const uint4*>(sa + (32 * wi + 16 * a + l15) * G::rc_stride + 4 * kq);
 #pragma unroll
@@ -174,39 +202,39 @@ __global__ __launch_bounds__(kThreads) void lgemm_kernel(LgArgs p) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(adnm_bf16x4, make_uint2(fb[b].x, fb[b].y)),
-                                                                __builtin_bit_cast(adnm_bf16x4, make_uint2(fa[a].x, fa[a].y)), acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(adnm_bf16x4, make_uint2(fb[b].z, fb[b].w)),
-                                                                __builtin_bit_cast(adnm_bf16x4, make_uint2(fa[a].z, fa[a].w)), acc[a][b], 0, 0, 0);
-        }
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(adnm_bf16x8, fb[b]), __builtin_bit_cast(adnm_bf16x8, fa[a]), acc[a][b], 0, 0, 0);
     } else {
+      // fp32 images: lane (l15, kq) takes reduction steps 16 g + 4 kq + e of the tile's 32 (g = 0, 1): 8 per lane = one 32-step MFMA group
+      float fa[2][2][4], fb[2][2][4];
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {   // reduction steps 16 g + 4 kq + e
-        float fa[2][4], fb[2][4];
+      for (int g = 0; g < 2; ++g) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
           const float4 v = *reinterpret_cast<const float4*>(sa + (32 * wi + 16 * a + l15) * G::rc_stride + 16 * g + 4 * kq);
-          fa[a][0] = v.x, fa[a][1] = v.y, fa[a][2] = v.z, fa[a][3] = v.w;
+          fa[a][g][0] = v.x, fa[a][g][1] = v.y, fa[a][g][2] = v.z, fa[a][g][3] = v.w;
         }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           if (!B_OC) {
             const float4 v = *reinterpret_cast<const float4*>(sb + (32 * wj + 16 * b + l15) * G::rc_stride + 16 * g + 4 * kq);
-            fb[b][0] = v.x, fb[b][1] = v.y, fb[b][2] = v.z, fb[b][3] = v.w;
+            fb[b][g][0] = v.x, fb[b][g][1] = v.y, fb[b][g][2] = v.z, fb[b][g][3] = v.w;
           } else {
             const float* s = reinterpret_cast<const float*>(sb) + (16 * g + 4 * kq) * G::oc_stride + 32 * wj + 16 * b + l15;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) fb[b][e] = s[e * G::oc_stride];
+            for (int e = 0; e < 4; ++e) fb[b][g][e] = s[e * G::oc_stride];
           }
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[b][e], fa[a][e], acc[a][b], 0, 0, 0);
       }
+      AdnmFrag<PREC> pa[2], pb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) pa[a] = adnm_make_frag<PREC, A_BF8>(fa[a][0], fa[a][1], q_sa);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) pb[b] = adnm_make_frag<PREC, false>(fb[b][0], fb[b][1], q_sb);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = adnm_mma<PREC, false, A_BF8>(pb[b], pa[a], acc[a][b]);
     }
   };
 
@@ -228,6 +256,15 @@ __global__ __launch_bounds__(kThreads) void lgemm_kernel(LgArgs p) {
     }
   }
 
+  if (rec_a) adnm_amax_commit(&p.q->amax_a, amax_a);
+  if (rec_b) adnm_amax_commit(&p.q->amax_b, amax_b);
+  if (PREC == ADNM_MFMA_FP8) {   // back to the operands' own scale, before bias / slabs
+    const float inv = 1.0f / (q_sa * q_sb);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = acc[a][b] * inv;
+  }
   // ---- epilogue
   const bool split = p.nbs > 1;
   float* const slab = split ? p.slab + ((int64_t)tile * p.nbs + slice) * (kTile * kTile) : nullptr;
@@ -338,13 +375,14 @@ int64_t adnm_lgemm_ws_bytes(int64_t I, int64_t J, int64_t R, int nbs) {
 }
 
 int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, void* ws,
-                      int64_t ws_bytes, int64_t I, int64_t J, int64_t R, int nbs, int prec, hipStream_t st) {
+                      int64_t ws_bytes, int64_t I, int64_t J, int64_t R, int nbs, int prec, float* q, hipStream_t st) {
   const LgPlan pl = make_plan(I, J, R, nbs);
   LgArgs p;
   p.A = a, p.lda = lda, p.B = b, p.ldb = ldb, p.bias = bias, p.C = c, p.ldc = ldc;
   p.I = (int)I, p.J = (int)J, p.R = (int)R;
   p.tiles_j = pl.tiles_j, p.nbs = pl.nbs, p.kt_per_slice = pl.kt_per_slice, p.nkt = pl.nkt;
   p.slab = nullptr, p.tickets = nullptr;
+  p.q = reinterpret_cast<AdnmQuant*>(q);
   if (pl.nbs > 1) {
     if (!ws || ws_bytes < adnm_lgemm_ws_bytes(I, J, R, nbs)) {
       adnm_set_error("skgemm: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_lgemm_ws_bytes(I, J, R, nbs));
@@ -355,13 +393,15 @@ int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, in
     ADNM_REQUIRE(p.tickets, "skgemm: no arrival counters (first split launch of a device under stream capture, or hipMalloc failed)");
   }
   const unsigned grid = (unsigned)(pl.ntiles * pl.nbs);
-  const bool bf = prec == ADNM_MFMA_BF16;
-  if (!b_oc) {
-    if (bf) lgemm_kernel<false, true, kRingDepth><<<grid, kThreads, 0, st>>>(p);
-    else lgemm_kernel<false, false, kRingDepth><<<grid, kThreads, 0, st>>>(p);
-  } else {
-    if (bf) lgemm_kernel<true, true, kRingDepth><<<grid, kThreads, 0, st>>>(p);
-    else lgemm_kernel<true, false, kRingDepth><<<grid, kThreads, 0, st>>>(p);
-  }
+#define LG(OC)                                                                                                                    \
+  do {                                                                                                                            \
+    if (prec == ADNM_MFMA_BF16) lgemm_kernel<OC, ADNM_MFMA_BF16, false, kRingDepth><<<grid, kThreads, 0, st>>>(p);                \
+    else if (prec == ADNM_MFMA_FP8) lgemm_kernel<OC, ADNM_MFMA_FP8, false, kRingDepth><<<grid, kThreads, 0, st>>>(p);             \
+    else if (prec == ADNM_MFMA_FP8_GRAD) lgemm_kernel<OC, ADNM_MFMA_FP8, true, kRingDepth><<<grid, kThreads, 0, st>>>(p);         \
+    else lgemm_kernel<OC, ADNM_MFMA_F32, false, kRingDepth><<<grid, kThreads, 0, st>>>(p);                                        \
+  } while (0)
+  if (!b_oc) LG(false);
+  else LG(true);
+#undef LG
   return ADNM_OK;
 }

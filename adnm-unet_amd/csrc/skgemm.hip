@@ -51,10 +51,12 @@ struct SkArgs {
   int* tickets;         // NT / NN with nbs > 1: one arrival counter per output tile (zero when idle); the result goes to `out`
   float* out;
   int64_t ldo;
+  AdnmQuant* q;         // quantisation record (fp8 scales, amax collection) or NULL
 };
 
 // A_RC / B_RC: operand contiguous along the reduction axis.  TM x TN blocks of 16 x 16 per wave, KC 16-step groups per chunk.
-template <bool A_RC, bool B_RC, bool BF16, int TM, int TN, int KC>
+// PREC: ADNM_MFMA_* (the matrix-core precision); A_BF8: in the fp8 mode the A operand is a gradient (e5m2).
+template <bool A_RC, bool B_RC, int PREC, bool A_BF8, int TM, int TN, int KC>
 __global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
   static_assert((A_RC || TM == 4) && (B_RC || TN == 4), "an operand contiguous along the output axis is 4 interleaved blocks wide");
   constexpr int kAcc = TM * TN * 256;        // one wave's accumulators ...
@@ -133,6 +135,16 @@ __global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  // fp8: per-tensor scales from the call site's quantisation record; the accumulators are un-scaled in the epilogue.  rec_a / rec_b
+  // (wave-uniform): this wave collects max |value| of the A rows / B columns it reads — only the first tile column / tile row do, so every
+  // element is seen once per reduction slice and the atomics stay a handful per launch.
+  float q_sa = 1.f, q_sb = 1.f, amax_a = 0.f, amax_b = 0.f;
+  bool rec_a = false, rec_b = false;
+  if (p.q) {
+    if (PREC == ADNM_MFMA_FP8) q_sa = p.q->scale_a, q_sb = p.q->scale_b;
+    const bool rec = p.q->record != 0.f && active;
+    rec_a = rec && (tile % p.tiles_j) == 0, rec_b = rec && (tile / p.tiles_j) == 0;
+  }
   auto compute = [&](int c, float (&av)[TM][KC][4], const float (&bv)[TN][KC][4]) {
 #pragma unroll
     for (int s = 0; s < KC; ++s) {
@@ -149,15 +161,33 @@ __global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
 #pragma unroll
         for (int t = 0; t < TM; ++t) bs[t] += (av[t][s][0] + av[t][s][1]) + (av[t][s][2] + av[t][s][3]);
       }
+      if (rec_a) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) amax_a = adnm_amax4(amax_a, av[t][s][0], av[t][s][1], av[t][s][2], av[t][s][3]);
+      }
+      if (rec_b && r0 + 16 <= p.R) {   // (B's tail steps are not zeroed: skip the group that holds them; the weight's amax comes from the rest)
+#pragma unroll
+        for (int t = 0; t < TN; ++t) amax_b = adnm_amax4(amax_b, bv[t][s][0], bv[t][s][1], bv[t][s][2], bv[t][s][3]);
+      }
+    }
+    // one MFMA step = 32 reduction steps = two 16-step groups (an odd last group runs on a zero upper half); every fragment is scaled /
+    // rounded / packed once, then used by the TN (TM) MFMAs that read it
+#pragma unroll
+    for (int s = 0; s < KC; s += 2) {
+      constexpr bool kHalf = (KC & 1) != 0;   // KC == 1: the chunk is one group
+      AdnmFrag<PREC> fa[TM], fb[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) fa[a] = adnm_make_frag<PREC, A_BF8>(av[a][s], kHalf ? nullptr : av[a][(s + 1) % KC], q_sa);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) fb[b] = adnm_make_frag<PREC, false>(bv[b][s], kHalf ? nullptr : bv[b][(s + 1) % KC], q_sb);
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
           // B_RC (the NT op): operands swapped, so the accumulator block is C^T and a lane ends up with four CONSECUTIVE output
           // columns of one row (float4 stores); otherwise the 4 interleaved column blocks already give that.
-          // av[.][s][e] / bv[.][s][e] = one reduction step: one bf16 MFMA (ADNM_MFMA_BF16) or four fp32 ones per group
-          if (B_RC) acc[a][b] = adnm_mfma16<BF16>(bv[b][s], av[a][s], acc[a][b]);
-          else acc[a][b] = adnm_mfma16<BF16>(av[a][s], bv[b][s], acc[a][b]);
+          if (B_RC) acc[a][b] = adnm_mma<PREC, false, A_BF8, kHalf>(fb[b], fa[a], acc[a][b]);
+          else acc[a][b] = adnm_mma<PREC, A_BF8, false, kHalf>(fa[a], fb[b], acc[a][b]);
         }
     }
   };
@@ -185,6 +215,15 @@ __global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
     __builtin_amdgcn_sched_barrier(0);
   }
 
+  if (rec_a) adnm_amax_commit(&p.q->amax_a, amax_a);
+  if (rec_b) adnm_amax_commit(&p.q->amax_b, amax_b);
+  if (PREC == ADNM_MFMA_FP8) {   // back to the operands' own scale (before slices are summed, bias is added or slabs are written)
+    const float inv = 1.0f / (q_sa * q_sb);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = acc[a][b] * inv;
+  }
   // sum the wpt slices of the tile: upper half of the group writes, lower half adds (log2(wpt) rounds, fixed order)
   for (int half = p.wpt >> 1; half >= 1; half >>= 1) {
     if (gw >= half && gw < 2 * half) {
@@ -502,9 +541,11 @@ void dims(int op, int64_t M, int64_t N, int64_t K, int64_t* I, int64_t* J, int64
 }
 
 template <bool A_RC, bool B_RC, int TM, int TN, int KC>
-void launch(bool bf16, unsigned grid, hipStream_t st, const SkArgs& p) {
-  if (bf16) skgemm_kernel<A_RC, B_RC, true, TM, TN, KC><<<grid, kBlock, 0, st>>>(p);
-  else skgemm_kernel<A_RC, B_RC, false, TM, TN, KC><<<grid, kBlock, 0, st>>>(p);
+void launch(int prec, unsigned grid, hipStream_t st, const SkArgs& p) {
+  if (prec == ADNM_MFMA_BF16) skgemm_kernel<A_RC, B_RC, ADNM_MFMA_BF16, false, TM, TN, KC><<<grid, kBlock, 0, st>>>(p);
+  else if (prec == ADNM_MFMA_FP8) skgemm_kernel<A_RC, B_RC, ADNM_MFMA_FP8, false, TM, TN, KC><<<grid, kBlock, 0, st>>>(p);
+  else if (prec == ADNM_MFMA_FP8_GRAD) skgemm_kernel<A_RC, B_RC, ADNM_MFMA_FP8, true, TM, TN, KC><<<grid, kBlock, 0, st>>>(p);
+  else skgemm_kernel<A_RC, B_RC, ADNM_MFMA_F32, false, TM, TN, KC><<<grid, kBlock, 0, st>>>(p);
 }
 }  // namespace
 
@@ -528,8 +569,13 @@ extern "C" int64_t adnm_skgemm_ws_bytes(int op, int64_t M, int64_t N, int64_t K)
 }
 
 extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, float* dbias,
-                           void* ws, int64_t ws_bytes, int64_t M, int64_t N, int64_t K, int prec, adnm_stream_t stream) {
-  ADNM_REQUIRE(prec == ADNM_MFMA_F32 || prec == ADNM_MFMA_BF16, "skgemm: bad prec %d", prec);
+                           void* ws, int64_t ws_bytes, int64_t M, int64_t N, int64_t K, int prec, float* q, adnm_stream_t stream) {
+  ADNM_REQUIRE(prec >= ADNM_MFMA_F32 && prec <= ADNM_MFMA_FP8_GRAD, "skgemm: bad prec %d", prec);
+  const bool fp8 = prec == ADNM_MFMA_FP8 || prec == ADNM_MFMA_FP8_GRAD;
+  ADNM_REQUIRE(!fp8 || q, "skgemm: the fp8 modes need a quantisation record");
+  // the weight-gradient op keeps bf16 operands in the fp8 configuration (its two operands are the forward's activation and the output
+  // gradient; the record of the forward call site does not describe that pair)
+  if (fp8 && op == ADNM_SKGEMM_TN) prec = ADNM_MFMA_BF16, q = nullptr;
   ADNM_REQUIRE(a && b && c, "skgemm: null pointer");
   ADNM_REQUIRE(shape_ok(op, M, N, K), "skgemm: unsupported op/shape op=%d M=%lld N=%lld K=%lld", op, (long long)M, (long long)N, (long long)K);
   int64_t I, J, R;
@@ -539,7 +585,7 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   ADNM_REQUIRE(!(bias && op != ADNM_SKGEMM_NT) && !(dbias && op != ADNM_SKGEMM_TN), "skgemm: bias only with NT, dbias only with TN");
   ADNM_REQUIRE(((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) % 16 == 0, "skgemm: operands must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const bool bf = prec == ADNM_MFMA_BF16;
+  const bool bf = prec != ADNM_MFMA_F32;   // the narrow modes share the tile plan measured for bf16
   Plan pl = make_plan(op, I, J, R, false, bf);
   // the deferred fold writes whole contiguous rows: a strided output (column slice of a wider buffer) takes no partials there
   if (op == ADNM_SKGEMM_TN && ldc != J) pl = make_plan(op, I, J, R, true, bf);
@@ -548,7 +594,7 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   const double algo_bytes = 4.0 * ((double)M * (K + N) + (double)N * K);
   if (pl.kernel == KERNEL_LDS) {
     ADNM_PROF(scope, st, algo_bytes);
-    const int rc = adnm_lgemm_launch(op == ADNM_SKGEMM_NN, a, lda, b, ldb, bias, c, ldc, ws, ws_bytes, I, J, R, pl.nbs, prec, st);
+    const int rc = adnm_lgemm_launch(op == ADNM_SKGEMM_NN, a, lda, b, ldb, bias, c, ldc, ws, ws_bytes, I, J, R, pl.nbs, prec, q, st);
     if (rc != ADNM_OK) return rc;
     ADNM_CHECK_LAUNCH("skgemm");
     return ADNM_OK;
@@ -573,6 +619,7 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   p.bsum = dbias ? (split ? part + I * J : dbias) : nullptr;
   p.bsum_stride = split ? rowlen : 0;
   p.tickets = nullptr, p.out = c, p.ldo = ldc;
+  p.q = reinterpret_cast<AdnmQuant*>(q);
   if (pl.combine) {
     p.tickets = adnm_take_tickets(pl.ntiles, st);
     ADNM_REQUIRE(p.tickets, "skgemm: no arrival counters (first split launch of a device under stream capture, or hipMalloc failed)");
@@ -581,15 +628,15 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   {
     ADNM_PROF(scope, st, algo_bytes);
     if (op == ADNM_SKGEMM_NT) {
-      if (pl.tm == 1) launch<true, true, 1, 1, 4>(bf, grid, st, p);
-      else if (pl.tm == 2) launch<true, true, 2, 2, 2>(bf, grid, st, p);
-      else launch<true, true, 4, 4, 1>(bf, grid, st, p);
+      if (pl.tm == 1) launch<true, true, 1, 1, 4>(prec, grid, st, p);
+      else if (pl.tm == 2) launch<true, true, 2, 2, 2>(prec, grid, st, p);
+      else launch<true, true, 4, 4, 1>(prec, grid, st, p);
     } else if (op == ADNM_SKGEMM_NN) {
-      if (pl.tm == 1) launch<true, false, 1, 4, 2>(bf, grid, st, p);
-      else if (pl.tm == 2) launch<true, false, 2, 4, 2>(bf, grid, st, p);
-      else launch<true, false, 4, 4, 1>(bf, grid, st, p);
+      if (pl.tm == 1) launch<true, false, 1, 4, 2>(prec, grid, st, p);
+      else if (pl.tm == 2) launch<true, false, 2, 4, 2>(prec, grid, st, p);
+      else launch<true, false, 4, 4, 1>(prec, grid, st, p);
     } else {
-      launch<false, false, 4, 4, 1>(bf, grid, st, p);
+      launch<false, false, 4, 4, 1>(prec, grid, st, p);
     }
   }
   ADNM_CHECK_LAUNCH("skgemm");

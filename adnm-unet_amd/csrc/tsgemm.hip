@@ -24,21 +24,37 @@ constexpr int kWaves = 8;
 
 // ---------------------------------------------------------------------------------------------- nt: Y = X . Wp^T
 // Wp[n][k] is read at w[n * ws_n + k * ws_k]  (forward: ws_n=K, ws_k=1; input gradient: ws_n=1, ws_k=K_of_weight)
-template <int KQ, int NB, bool BF16>
+// PREC = ADNM_MFMA_*; A_BF8: in the fp8 mode the rows of X are a gradient (e5m2).
+template <int PREC>
+struct WImg {   // bytes of one (column block, reduction group, lane) entry of the LDS weight image, reduction steps per entry
+  static constexpr int kEntry = PREC == ADNM_MFMA_F32 ? 4 : (PREC == ADNM_MFMA_BF16 ? 16 : 8);
+  static constexpr int kSteps = PREC == ADNM_MFMA_F32 ? 1 : 8;   // per lane
+};
+template <int KQ, int NB, int PREC, bool A_BF8>
 __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
                                                            int64_t ws_n, int64_t ws_k, const float* __restrict__ bias,
-                                                           float* __restrict__ y, int64_t ldy, int64_t M, int N, int K) {
-  // fp32: [NB][K/4][64] floats, one per (column block, k step, lane).  bf16 (ADNM_MFMA_BF16): [NB][K/16][64] entries of 4 bf16 = the
-  // lane's four reduction steps of one v_mfma_f32_16x16x16_bf16 — a quarter of the MFMAs and LDS reads per row block
+                                                           float* __restrict__ y, int64_t ldy, int64_t M, int N, int K, AdnmQuant* q) {
+  // fp32: [NB][K/4][64] floats, one per (column block, k step, lane).  bf16 / fp8: [NB][KP][64] entries of 8 bf16 / 8 fp8 = the lane's
+  // eight reduction steps of ONE v_mfma_f32_16x16x32 (KP = ceil(KQ / 2) groups of 32 steps; an odd last half is zeros)
   extern __shared__ __attribute__((aligned(16))) float wl[];
   uint16_t* const wh = reinterpret_cast<uint16_t*>(wl);
+  uint8_t* const wb = reinterpret_cast<uint8_t*>(wl);
+  constexpr int KP = (KQ + 1) / 2;
   const int ksteps = K >> 2;
   constexpr int kTStride = 68;   // floats per row of a wave's 16 x 64 output staging tile (64 + pad: conflict-free float4 writes)
-  float* const tbuf = wl + ((NB * (K >> 2) * 64 * (BF16 ? 2 : 4) + 15) / 16) * 4;   // behind the weight image
+  const int wbytes = PREC == ADNM_MFMA_F32 ? NB * (K >> 2) * 64 * 4 : NB * KP * 64 * WImg<PREC>::kEntry;
+  float* const tbuf = wl + ((wbytes + 15) / 16) * 4;   // behind the weight image
+  float q_sa = 1.f, q_sb = 1.f, amax_a = 0.f, amax_b = 0.f;
+  bool rec = false;
+  if (q) {
+    if (PREC == ADNM_MFMA_FP8) q_sa = q->scale_a, q_sb = q->scale_b;
+    rec = q->record != 0.f;
+  }
   // stage the weight in fragment order: entry (cb, s, lane=(j,kk)) = Wp[cb*16+j][16*(s/4) + 4*kk + (s%4)].
   // Global reads run along the weight's contiguous axis (k for the forward layout, n for the transposed one).
   {
-    const int total = NB * 16 * K;
+    const int Kp = PREC == ADNM_MFMA_F32 ? K : KP * 32;   // the narrow images cover whole 32-step groups: steps >= K are zeros
+    const int total = NB * 16 * Kp;
     constexpr int kU = 8;   // loads issued back to back before the first LDS write: one HBM round trip per 4096 elements
     for (int base = 0; base < total; base += kBlock * kU) {
       float v[kU];
@@ -46,20 +62,24 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
       for (int u = 0; u < kU; ++u) {
         const int idx = base + u * kBlock + threadIdx.x;
         int n, k;
-        if (ws_k == 1) { n = idx / K; k = idx - n * K; }
+        if (ws_k == 1) { n = idx / Kp; k = idx - n * Kp; }
         else { k = idx / (NB * 16); n = idx - k * (NB * 16); }
-        v[u] = (idx < total && n < N) ? w[(int64_t)n * ws_n + (int64_t)k * ws_k] : 0.f;
+        v[u] = (idx < total && n < N && k < K) ? w[(int64_t)n * ws_n + (int64_t)k * ws_k] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         const int idx = base + u * kBlock + threadIdx.x;
         if (idx >= total) continue;
         int n, k;
-        if (ws_k == 1) { n = idx / K; k = idx - n * K; }
+        if (ws_k == 1) { n = idx / Kp; k = idx - n * Kp; }
         else { k = idx / (NB * 16); n = idx - k * (NB * 16); }
-        const int cb = n >> 4, j = n & 15, q = k >> 4, kk = (k >> 2) & 3, e = k & 3;
-        if (BF16) wh[((cb * KQ + q) * 64 + kk * 16 + j) * 4 + e] = (uint16_t)(adnm_pack_bf16(v[u], 0.f, 0.f, 0.f)[0]);
-        else wl[(cb * ksteps + (q * 4 + e)) * 64 + kk * 16 + j] = v[u];
+        const int cb = n >> 4, j = n & 15, qq = k >> 4, kk = (k >> 2) & 3, e = k & 3;
+        amax_b = fmaxf(amax_b, fabsf(v[u]));
+        if (PREC == ADNM_MFMA_BF16) wh[((cb * KP + (qq >> 1)) * 64 + kk * 16 + j) * 8 + (qq & 1) * 4 + e] = f32_to_bf16(v[u]);
+        else if (PREC == ADNM_MFMA_FP8)
+          wb[((cb * KP + (qq >> 1)) * 64 + kk * 16 + j) * 8 + (qq & 1) * 4 + e] =
+              (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v[u] * q_sb, 448.f, -448.f), 0.f, 0, false) & 0xff);
+        else wl[(cb * ksteps + (qq * 4 + e)) * 64 + kk * 16 + j] = v[u];
       }
     }
   }
@@ -75,10 +95,11 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
     const int64_t row = b * 16 + i;
     const bool rv = b < nrb && row < M;
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) dst[q] = rv ? *reinterpret_cast<const float4*>(x + row * ldx + 16 * q + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int qq = 0; qq < KQ; ++qq) dst[qq] = rv ? *reinterpret_cast<const float4*>(x + row * ldx + 16 * qq + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   const bool vec_ok = (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
   constexpr bool kPrefetch = KQ < 16 && NB < 16;   // the widest variants have no registers to spare for a second row block
+  const float inv = 1.0f / (q_sa * q_sb);
   fetch(rb, xa);
   __syncthreads();
   for (; rb < nrb; rb += stride) {
@@ -86,25 +107,42 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
     f32x4 acc[NB];
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (rec) {
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) {
-      if (BF16) {
-        const adnm_bf16x4 xb = adnm_pack_bf16(xa[q].x, xa[q].y, xa[q].z, xa[q].w);
+      for (int qq = 0; qq < KQ; ++qq) amax_a = adnm_amax4(amax_a, xa[qq].x, xa[qq].y, xa[qq].z, xa[qq].w);
+    }
+    if constexpr (PREC != ADNM_MFMA_F32) {
+#pragma unroll
+      for (int qp = 0; qp < KP; ++qp) {
+        const float lo[4] = {xa[2 * qp].x, xa[2 * qp].y, xa[2 * qp].z, xa[2 * qp].w};
+        float hi[4] = {0.f, 0.f, 0.f, 0.f};
+        if (2 * qp + 1 < KQ) hi[0] = xa[(2 * qp + 1) % KQ].x, hi[1] = xa[(2 * qp + 1) % KQ].y, hi[2] = xa[(2 * qp + 1) % KQ].z, hi[3] = xa[(2 * qp + 1) % KQ].w;
+        const AdnmFrag<PREC> xf = adnm_make_frag<PREC, A_BF8>(lo, hi, q_sa);
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
-          const uint2 wv = *reinterpret_cast<const uint2*>(wh + ((cb * KQ + q) * 64 + lane) * 4);
-          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(adnm_bf16x4, wv), xb, acc[cb], 0, 0, 0);
+          AdnmFrag<PREC> wf;
+          if constexpr (PREC == ADNM_MFMA_BF16) wf.v = __builtin_bit_cast(adnm_bf16x8, *reinterpret_cast<const uint4*>(wh + ((cb * KP + qp) * 64 + lane) * 8));
+          else wf.v = *reinterpret_cast<const long*>(wb + ((cb * KP + qp) * 64 + lane) * 8);
+          // operands swapped (W fragment first): the accumulator tile is Y^T, a lane ends up with FOUR CONSECUTIVE output columns of one row
+          acc[cb] = adnm_mma<PREC, false, A_BF8>(wf, xf, acc[cb]);
         }
-        continue;
       }
-      const float ae[4] = {xa[q].x, xa[q].y, xa[q].z, xa[q].w};
+      if (PREC == ADNM_MFMA_FP8) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int s = q * 4 + e;
+        for (int cb = 0; cb < NB; ++cb) acc[cb] = acc[cb] * inv;
+      }
+    } else {
 #pragma unroll
-        // operands swapped (W fragment as A, X fragment as B): the accumulator tile is Y^T, i.e. a lane ends up with FOUR
-        // CONSECUTIVE output columns of one row -> float4 stores (8 per row block instead of 32 scalar ones)
-        for (int cb = 0; cb < NB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(cb * ksteps + s) * 64 + lane], ae[e], acc[cb], 0, 0, 0);
+      for (int qq = 0; qq < KQ; ++qq) {
+        const float ae[4] = {xa[qq].x, xa[qq].y, xa[qq].z, xa[qq].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int s = qq * 4 + e;
+#pragma unroll
+          // operands swapped (W fragment as A, X fragment as B): the accumulator tile is Y^T, i.e. a lane ends up with FOUR
+          // CONSECUTIVE output columns of one row -> float4 stores (8 per row block instead of 32 scalar ones)
+          for (int cb = 0; cb < NB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(cb * ksteps + s) * 64 + lane], ae[e], acc[cb], 0, 0, 0);
+        }
       }
     }
     // C^T layout: column (lane & 15) -> row of Y, row (lane >> 4) * 4 + reg -> column of Y: a lane holds four consecutive output columns
@@ -147,9 +185,24 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
     }
     if (kPrefetch) {
 #pragma unroll
-      for (int q = 0; q < KQ; ++q) xa[q] = xn[q];
+      for (int qq = 0; qq < KQ; ++qq) xa[qq] = xn[qq];
     } else {
       fetch(rb + stride, xa);
+    }
+  }
+  if (rec) {   // amax of the rows this workgroup streamed (8 waves -> one atomic through LDS) and, from workgroup 0, of the weight
+    __syncthreads();
+    float* const red = wl;   // the weight image is idle by now
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) amax_a = fmaxf(amax_a, __shfl_xor(amax_a, o, 64)), amax_b = fmaxf(amax_b, __shfl_xor(amax_b, o, 64));
+    if (lane == 0) red[wave] = amax_a, red[kWaves + wave] = amax_b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float ma = 0.f, mb = 0.f;
+#pragma unroll
+      for (int k = 0; k < kWaves; ++k) ma = fmaxf(ma, red[k]), mb = fmaxf(mb, red[kWaves + k]);
+      if (ma > 0.f) atomicMax(reinterpret_cast<unsigned int*>(&q->amax_a), __float_as_uint(ma));
+      if (mb > 0.f && blockIdx.x == 0) atomicMax(reinterpret_cast<unsigned int*>(&q->amax_b), __float_as_uint(mb));
     }
   }
 }
@@ -278,17 +331,22 @@ int tn_blocks(int64_t M) {
 
 template <int KQ, int NB>
 int launch_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, float* y, int64_t ldy, int64_t M,
-               int N, int K, bool bf16, hipStream_t st) {
-  const size_t wbytes = ((size_t)NB * (K / 4) * 64 * (bf16 ? sizeof(uint16_t) : sizeof(float)) + 15) / 16 * 16;
+               int N, int K, int prec, AdnmQuant* q, hipStream_t st) {
+  const bool narrow = prec != ADNM_MFMA_F32;
+  const size_t entries = narrow ? (size_t)NB * ((KQ + 1) / 2) * 64 : (size_t)NB * (K / 4) * 64;
+  const size_t wbytes = (entries * (prec == ADNM_MFMA_F32 ? 4 : (prec == ADNM_MFMA_BF16 ? 16 : 8)) + 15) / 16 * 16;
   const size_t smem = wbytes + (size_t)kWaves * 16 * 68 * sizeof(float);   // weight image + one 16 x 64 output staging tile per wave
   ADNM_PROF("tsgemm_nt", st, 4.0 * ((double)M * (K + N) + (double)N * K));
-  if (bf16) {
-    ADNM_ALLOW_LDS((tsgemm_nt_kernel<KQ, NB, true>), smem, "tsgemm_nt");   // > 64 KB of dynamic LDS for the widest weights: per-device opt-in
-    tsgemm_nt_kernel<KQ, NB, true><<<nt_blocks(M, true), kBlock, smem, st>>>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, N, K);
-  } else {
-    ADNM_ALLOW_LDS((tsgemm_nt_kernel<KQ, NB, false>), smem, "tsgemm_nt");
-    tsgemm_nt_kernel<KQ, NB, false><<<nt_blocks(M, false), kBlock, smem, st>>>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, N, K);
-  }
+#define TS_GO(PRECV, BF8V)                                                                                                               \
+  do {                                                                                                                                   \
+    ADNM_ALLOW_LDS((tsgemm_nt_kernel<KQ, NB, PRECV, BF8V>), smem, "tsgemm_nt"); /* > 64 KB of dynamic LDS for the widest weights */      \
+    tsgemm_nt_kernel<KQ, NB, PRECV, BF8V><<<nt_blocks(M, narrow), kBlock, smem, st>>>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, N, K, q);   \
+  } while (0)
+  if (prec == ADNM_MFMA_BF16) TS_GO(ADNM_MFMA_BF16, false);
+  else if (prec == ADNM_MFMA_FP8) TS_GO(ADNM_MFMA_FP8, false);
+  else if (prec == ADNM_MFMA_FP8_GRAD) TS_GO(ADNM_MFMA_FP8, true);
+  else TS_GO(ADNM_MFMA_F32, false);
+#undef TS_GO
   return ADNM_OK;
 }
 
@@ -332,9 +390,10 @@ extern "C" int adnm_tsgemm_supported(int64_t M, int64_t N, int64_t K) {
 
 // Y[M,N] = X[M,K] . Wp^T (+bias), Wp[n][k] = w[n*ws_n + k*ws_k].  K % 16 == 0, K <= 256, N <= 256.
 extern "C" int adnm_tsgemm_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, float* y,
-                              int64_t ldy, int64_t M, int64_t N, int64_t K, int prec, adnm_stream_t stream) {
+                              int64_t ldy, int64_t M, int64_t N, int64_t K, int prec, float* q, adnm_stream_t stream) {
   ADNM_REQUIRE(x && w && y, "tsgemm_nt: null pointer");
-  ADNM_REQUIRE(prec == ADNM_MFMA_F32 || prec == ADNM_MFMA_BF16, "tsgemm_nt: bad prec %d", prec);
+  ADNM_REQUIRE(prec >= ADNM_MFMA_F32 && prec <= ADNM_MFMA_FP8_GRAD, "tsgemm_nt: bad prec %d", prec);
+  ADNM_REQUIRE((prec != ADNM_MFMA_FP8 && prec != ADNM_MFMA_FP8_GRAD) || q, "tsgemm_nt: the fp8 modes need a quantisation record");
   ADNM_REQUIRE(adnm_tsgemm_supported(M, N, K), "tsgemm_nt: unsupported shape M=%lld N=%lld K=%lld (need K%%16==0, K<=256, N<=256)", (long long)M,
                (long long)N, (long long)K);
   ADNM_REQUIRE(ldx >= K && ldx % 4 == 0 && ldy >= N, "tsgemm_nt: bad row strides");
@@ -344,7 +403,7 @@ extern "C" int adnm_tsgemm_nt(const float* x, int64_t ldx, const float* w, int64
   // only the variants adnm_tsgemm_supported admits (N*K <= 8192, i.e. KQ*NB <= 32 blocks: <= 64 accumulator + 64 operand VGPRs,
   // no scratch) are instantiated
   int rc = ADNM_EINVAL;
-#define NT(KQ, NB) if (kq == KQ && nb == NB) rc = launch_nt<KQ, NB>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, (int)N, (int)K, prec == ADNM_MFMA_BF16, st)
+#define NT(KQ, NB) if (kq == KQ && nb == NB) rc = launch_nt<KQ, NB>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, (int)N, (int)K, prec, reinterpret_cast<AdnmQuant*>(q), st)
   NT(1, 1); NT(1, 2); NT(1, 4); NT(1, 8); NT(1, 13); NT(1, 16);
   NT(2, 1); NT(2, 2); NT(2, 4); NT(2, 8); NT(2, 13); NT(2, 16);
   NT(4, 1); NT(4, 2); NT(4, 4); NT(4, 8);

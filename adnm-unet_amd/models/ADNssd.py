@@ -160,4 +160,5 @@ class Mamba2(nn.Module):
              self.conv_31_bc2.weight, self.conv_13_x1.weight, self.conv_13_bc1.weight, self.conv_13_x2.weight, self.conv_13_bc2.weight,
              self.conv2d_z.weight, self.norm.weight, self.norm.bias, self.out_proj.weight, self.alpha1])
         return ops.adn_mixer(u, w_in, taps, None, self.dt_bias, self.A_log, self.D, ln_w, ln_b, w_out, H, W,
-                             self.headdim, self.ngroups * self.d_state // 2, scan_chunk, self.ngroups)
+                             self.headdim, self.ngroups * self.d_state // 2, scan_chunk, self.ngroups,
+                             qkeys=(self.in_proj.weight.data_ptr(), self.out_proj.weight.data_ptr()))

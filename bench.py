@@ -80,11 +80,14 @@ def parse():
     ap.add_argument("--reduce-dtype", default="f32", choices=["f32", "bf16"], help="wire dtype of the gradient all-reduce (N>1)")
     ap.add_argument("--dump-prof", default="", help="write the per-(kernel, shape) HIP-event table of the instrumented steps to this file")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): replay fwd+bwd as captured hipGraphs; 0: eager launches")
-    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16", "fp8"],
                     help="matrix-core precision of the GEMM-shaped kernels.  bf16 (default) = BASELINE config 2's precision: bf16 MFMA operands, "
                          "fp32 accumulation, fp32 master parameters and activations (parity: rel-L2 <= 6e-2 vs the fp32 reference fixtures, <= 3e-2 "
                          "vs the fp32 HIP path, tests/test_model_gpu.py::test_visionmamba_bf16_mfma_vs_reference); f32 = exact fp32 MFMA (the "
-                         "bit-level parity path, tolerance 1e-4 / 1e-3)")
+                         "bit-level parity path, tolerance 1e-4 / 1e-3); fp8 = BASELINE config 5: per-tensor scaled OCP e4m3 / e5m2 operands into the "
+                         "fp8 MFMA for the forward and input-gradient GEMMs / dense convs (delayed scaling, re-calibrated every 16 steps on the "
+                         "device), bf16 operands for the weight gradients (parity: rel-L2 <= 1.5e-1, 50-step loss curve within 5 %, "
+                         "tests/test_model_gpu.py::test_visionmamba_fp8_vs_reference)")
     return ap.parse_args()
 
 
@@ -429,10 +432,15 @@ def main():
             "metric": f"sequences/sec training ADNM-UNet {args.in_frames}->{args.out_frames}x{args.size}x{args.size}", "value": round(world * args.batch * args.steps / dt, 3),
             "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "f32" else "bf16",
-            "dtype_detail": ("exact fp32 MFMA everywhere" if args.dtype == "f32" else
-                             "bf16 x bf16 -> fp32 MFMA in the short GEMMs (K6b) and dense convs (K5/K9); fp32 accumulation, master parameters, "
-                             "activations and every other kernel; --dtype f32 is the exact-fp32 parity path"),
+            "dtype": args.dtype,
+            "dtype_detail": {"f32": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32) everywhere: the bit-level parity path",
+                             "bf16": "bf16 x bf16 -> fp32 on v_mfma_f32_16x16x32_bf16 in every GEMM-shaped kernel (K6 tall-skinny forward / input "
+                                     "gradient, K6b short GEMMs, K5/K9 dense convs); fp32 accumulation, master parameters, activation storage and "
+                                     "every other kernel",
+                             "fp8": "BASELINE config 5: per-tensor scaled OCP fp8 operands (e4m3 activations and weights, e5m2 output gradients) on "
+                                    "v_mfma_f32_16x16x32_{fp8,bf8}_fp8 in the forward and input-gradient GEMMs / dense convs, delayed scaling "
+                                    f"re-calibrated on the device every {os.environ.get('ADNM_FP8_PERIOD', '16')} steps; bf16 operands for the weight "
+                                    "gradients; fp32 accumulation, master parameters, activation storage and every other kernel"}[args.dtype],
             "data": "synthetic",
             "config": {"workload": f"ADNM-UNet create_ADNMUNet({args.in_frames},{args.out_frames},6) {args.size}x{args.size} full training step "
                                    "(fwd + enRainfallLoss + bwd + clip_grad_norm_ + AdamW), recipe parameters, synthetic radar frames in HBM",

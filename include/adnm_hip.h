@@ -38,9 +38,25 @@ typedef void* adnm_stream_t; /* hipStream_t */
 enum { ADNM_F32 = 0, ADNM_BF16 = 1 };
 enum { ADNM_ACT_NONE = 0, ADNM_ACT_SILU = 1, ADNM_ACT_GELU = 2 };
 enum { ADNM_OK = 0, ADNM_EINVAL = -1, ADNM_ELAUNCH = -2, ADNM_EWORKSPACE = -3 };
-/* `prec` of the GEMM-shaped entry points (tsgemm, skgemm, conv3): exact fp32 MFMA, or operands rounded to bf16 on the way into the
- * bf16 MFMA with fp32 accumulation (BASELINE's bf16 configurations: 8x the matrix rate; storage stays fp32). */
-enum { ADNM_MFMA_F32 = 0, ADNM_MFMA_BF16 = 1 };
+/* `prec` of the GEMM-shaped entry points (tsgemm, skgemm, conv3) — the precision ladder, storage stays fp32:
+ *   ADNM_MFMA_F32   exact fp32 MFMA (v_mfma_f32_16x16x4_f32: the parity path);
+ *   ADNM_MFMA_BF16  operands rounded to bf16 on the way into v_mfma_f32_16x16x32_bf16, fp32 accumulation (BASELINE configs 2-4);
+ *   ADNM_MFMA_FP8   BASELINE config 5: per-tensor scaled OCP fp8 operands into v_mfma_f32_16x16x32_fp8_fp8, fp32 accumulation:
+ *                   first operand (the activation rows) e4m3, second (the weight) e4m3;
+ *   ADNM_MFMA_FP8_GRAD  the same with the first operand in e5m2 (a gradient: output gradients into the input-gradient GEMMs).
+ * The fp8 modes need a quantisation record `q` (device memory, 8 floats): {scale_a, scale_b, amax_a, amax_b, fmax_a, fmax_b, record, -}.
+ * An operand value v enters the MFMA as fp8(clamp(v * scale)), the accumulator is multiplied by 1 / (scale_a * scale_b) before bias /
+ * activation.  With q != NULL and record != 0 (any prec) the launch also collects amax_a / amax_b = max |v| of the operands it read
+ * (atomic max, order-independent); adnm_quant_update turns them into the next scales (delayed per-tensor scaling: a tensor's scale
+ * comes from an earlier step's amax, so quantisation costs no extra pass over the activations).  q == NULL: scales 1, nothing recorded. */
+enum { ADNM_MFMA_F32 = 0, ADNM_MFMA_BF16 = 1, ADNM_MFMA_FP8 = 2, ADNM_MFMA_FP8_GRAD = 3 };
+
+/* One pass over a table of `n` quantisation records (n * 8 floats), once per training step:
+ *   state = {step counter, period}: the counter advances; records collect amax (record = 1) during the steps where counter % period == 0;
+ *   after such a step: scale_x = fmax_x / (amax_x * headroom) for every operand with amax_x > 0 (else unchanged), amax_x = 0.
+ * fmax_a / fmax_b are set by the caller when a record is created (448 for e4m3 operands, 57344 for e5m2).  headroom >= 1 leaves room
+ * for the tensor to grow between calibrations (2 = one binade). */
+int adnm_quant_update(float* table, int64_t n, float* state, float headroom, adnm_stream_t stream);
 
 const char* adnm_last_error(void);
 int adnm_abi_version(void);
@@ -217,13 +233,14 @@ int adnm_igate_bwd(const void* dy, const void* x, const float* enhance, const fl
 /* EncoderToDecoder's entry, fused (model_untils.py:761-763: x = self.act(x + self.gama * res), act = IntensityGate):
  *   y[b,l,c] = silu(enhance * (x[b,l,c] + gama * res[b,c] - threshold)),   x, y:(B,L,C) fp32 contiguous, res:(B,C) — the
  * channel-attention gate of Channel_Att_Bridge, one value per (sample, channel), which the reference expands over the tokens
- * (model_untils.py:604-613).  gama / enhance / threshold: 1-element fp32.  C % 4 == 0.
- * Backward: dx:(B,L,C), dres:(B,C) (complete when the launch ends), dgama/denhance/dthreshold:(1) through per-workgroup partials
+ * (model_untils.py:604-613); per_token != 0: res is the expanded (B,L,C) tensor itself (the reference's own call form).
+ * gama / enhance / threshold: 1-element fp32.  C % 4 == 0.
+ * Backward: dx:(B,L,C), dres: the shape of res (complete when the launch ends), dgama/denhance/dthreshold:(1) through per-workgroup partials
  * + one fold (deferrable: parameter gradients).  All OVERWRITTEN. */
-int adnm_igate_res_fwd(const float* x, const float* res, const float* gama, const float* enhance, const float* threshold, float* y,
-                       int64_t B, int64_t L, int64_t C, adnm_stream_t stream);
+int adnm_igate_res_fwd(const float* x, const float* res, int per_token, const float* gama, const float* enhance,
+                       const float* threshold, float* y, int64_t B, int64_t L, int64_t C, adnm_stream_t stream);
 int64_t adnm_igate_res_bwd_ws_bytes(int64_t B, int64_t L, int64_t C);
-int adnm_igate_res_bwd(const float* dy, const float* x, const float* res, const float* gama, const float* enhance,
+int adnm_igate_res_bwd(const float* dy, const float* x, const float* res, int per_token, const float* gama, const float* enhance,
                        const float* threshold, float* dx, float* dres, float* dgama, float* denhance, float* dthreshold, void* ws,
                        int64_t ws_bytes, int64_t B, int64_t L, int64_t C, adnm_stream_t stream);
 
@@ -285,14 +302,16 @@ int adnm_colsum(const float* x, float* out, int64_t rows, int64_t n, void* ws, i
  *   ADNM_SKGEMM_NT: c[M,N] = a[M,K] . b[N,K]^T (+ bias[N])           forward          K % 4 == 0
  *   ADNM_SKGEMM_NN: c[M,K] = a[M,N] . b[N,K]                         input gradient   N % 4 == 0, K % 4 == 0
  *   ADNM_SKGEMM_TN: c[N,K] = a[M,N]^T . b[M,K]; dbias[N] = sum_m a   weight gradient  N % 4 == 0, K % 4 == 0
- * lda / ldb / ldc: row strides in elements (multiples of 4); bias only with NT, dbias only with TN; c / dbias OVERWRITTEN. */
+ * lda / ldb / ldc: row strides in elements (multiples of 4); bias only with NT, dbias only with TN; c / dbias OVERWRITTEN.
+ * prec / q: the precision ladder and the call site's quantisation record (see ADNM_MFMA_*); a = the "first operand", b = the weight.
+ * TN (the weight gradient) runs on bf16 operands in the fp8 modes. */
 #define ADNM_SKGEMM_NT 0
 #define ADNM_SKGEMM_NN 1
 #define ADNM_SKGEMM_TN 2
 int adnm_skgemm_supported(int op, int64_t M, int64_t N, int64_t K);
 int64_t adnm_skgemm_ws_bytes(int op, int64_t M, int64_t N, int64_t K);
 int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, float* dbias,
-                void* ws, int64_t ws_bytes, int64_t M, int64_t N, int64_t K, int prec, adnm_stream_t stream);
+                void* ws, int64_t ws_bytes, int64_t M, int64_t N, int64_t K, int prec, float* q, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- enRainfallLoss (K14)
  * models/loss.py:30-57 of the reference (train_untils.py:43 builds it with omega_t 0.57, alpha 0.25, gamma 0):
@@ -353,10 +372,10 @@ int adnm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, flo
 int64_t adnm_conv3_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t K, int64_t N);
 int adnm_conv3_fwd(const float* in, int64_t ldin, const float* w, int64_t ws_n, int64_t ws_tap, int64_t ws_k, const float* bias,
                    float* out, int64_t ldo, float* pre, int64_t ldpre, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W,
-                   int64_t K, int64_t N, int act, int prec, adnm_stream_t stream);
+                   int64_t K, int64_t N, int act, int prec, float* q, adnm_stream_t stream);
 int adnm_conv3_dgrad(const float* dout, int64_t lddo, const float* pre, int64_t ldpre, int act, const float* w, int64_t ws_n,
                      int64_t ws_tap, int64_t ws_k, float* din, int64_t lddin, void* ws, int64_t ws_bytes, int64_t B, int64_t H,
-                     int64_t W, int64_t K, int64_t N, int prec, adnm_stream_t stream);
+                     int64_t W, int64_t K, int64_t N, int prec, float* q, adnm_stream_t stream);
 int64_t adnm_conv3_wgrad_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t K, int64_t N);
 int adnm_conv3_wgrad(const float* dout, int64_t lddo, const float* pre, int64_t ldpre, int act, const float* in, int64_t ldin,
                      float* dw, float* dbias, void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t W, int64_t K, int64_t N,
@@ -413,7 +432,7 @@ int adnm_cast_bf16_f32(const void* src, void* dst, int64_t n, float scale, adnm_
  * *_supported() return 1 when the shape fits the kernels (callers use the library GEMM otherwise). */
 int adnm_tsgemm_supported(int64_t M, int64_t N, int64_t K);
 int adnm_tsgemm_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, float* y,
-                   int64_t ldy, int64_t M, int64_t N, int64_t K, int prec, adnm_stream_t stream);
+                   int64_t ldy, int64_t M, int64_t N, int64_t K, int prec, float* q, adnm_stream_t stream);
 int adnm_tsgemm_tn_supported(int64_t M, int64_t N, int64_t K);
 int64_t adnm_tsgemm_tn_ws_bytes(int64_t M, int64_t N, int64_t K);
 int adnm_tsgemm_tn(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* dbias, void* ws,

@@ -409,12 +409,12 @@ def test_igate():
     assert_close(tg.grad, to.grad, GRAD_TOL, "dthreshold", atol=1e-5)
 
 
-@pytest.mark.parametrize("B,L,C", [(4, 16, 1024), (2, 64, 512), (3, 256, 256), (2, 77, 36), (1, 4096, 32)])
-def test_igate_res(B, L, C):
+@pytest.mark.parametrize("B,L,C,per_token", [(4, 16, 1024, 0), (2, 64, 512, 0), (3, 256, 256, 0), (2, 77, 36, 0), (1, 4096, 32, 0), (2, 64, 16, 1)])
+def test_igate_res(B, L, C, per_token):
     """EncoderToDecoder's entry IntensityGate(x + gama * res) with the (B, 1, C) bridge gate broadcast over the tokens
     (model_untils.py:761-763) vs the same maths in fp64 torch ops."""
     tag = f"igr{B}{L}{C}"
-    x, r, cot = T(tag + "x", (B, L, C), 2.0), T(tag + "r", (B, 1, C)), T(tag + "c", (B, L, C))
+    x, r, cot = T(tag + "x", (B, L, C), 2.0), T(tag + "r", (B, L if per_token else 1, C)), T(tag + "c", (B, L, C))
     g, e, t = torch.tensor(0.8), torch.tensor(1.2), torch.tensor(0.15)
     lo = [leaf(v.double()) for v in (x, r, g, e, t)]
     yo = O.silu(lo[3] * (lo[0] + lo[2] * lo[1] - lo[4]))
@@ -807,3 +807,94 @@ def test_conv3_bf16_mfma(bf16_mfma):
     assert_close(xg.grad, xo.grad, 2e-6, "dx")
     assert_close(wg.grad, wo.grad, 2e-6, "dw")
     assert_close(bg.grad, cot.double().sum((0, 1)), 1e-5, "db (fp32 sums of the unrounded gradient)")
+
+
+# ------------------------------------------------------------------------------------------- fp8 MFMA precision (BASELINE config 5)
+F8MAX = {False: 448.0, True: 57344.0}
+
+
+def _fp8_round(t, scale, grad=False):
+    """what the kernels feed the MFMA: fp8(clamp(t * scale)) — OCP e4m3 (activations, weights) or e5m2 (gradients), RNE — as fp64"""
+    q = (t.float() * scale).clamp(-F8MAX[grad], F8MAX[grad]).to(torch.float8_e5m2 if grad else torch.float8_e4m3fn)
+    return q.float().double()
+
+
+def _scale_for(t, grad=False):
+    return F8MAX[grad] / (2.0 * float(t.abs().max()))   # one binade of headroom, as the delayed scaling leaves
+
+
+@pytest.fixture
+def fp8_mfma():
+    ops.QUANT.reset()
+    ops.set_mfma_precision("fp8")
+    rows, ops.QUANT.max_rows = ops.QUANT.max_rows, 1 << 30   # kernel tests: every shape on fp8 (the model keeps bf16 above 8192 token rows)
+    yield
+    ops.QUANT.max_rows = rows
+    ops.set_mfma_precision("f32")
+    ops.QUANT.reset()
+
+
+@pytest.mark.parametrize("M,K,N", [(64, 1024, 512), (1024, 256, 1216), (300, 20, 64), (64, 4096, 1024), (256, 1024, 2048), (65536, 32, 128),
+                                   (65536, 128, 32), (40000, 208, 32)])
+def test_linear_fp8_mfma(M, K, N, fp8_mfma):
+    """prec = ADNM_MFMA_FP8: the forward GEMM is EXACTLY (up to fp32 summation order) the product of the e4m3-rounded scaled operands
+    divided by the two scales; the input gradient the product of the e5m2-rounded output gradient and the e4m3 weight; the weight
+    gradient stays on bf16 operands (tall-skinny shapes: exact fp32).  Covers the streaming, the LDS-tiled and the tall-skinny kernel.
+    Tolerance 2e-5, not the bf16 test's 2e-6: the fp8 MFMA sums its 32 products per step in the hardware's own internal format
+    (measured 6e-6 at K = 1024 against the fp64 sum of the same rounded operands); a wrong scale, format or lane map would be >= 1e-2."""
+    x, w, cot = T(f"f8.x{M}{K}", (M, K)), T(f"f8.w{N}{K}", (N, K), 0.05), T(f"f8.c{M}{N}", (M, N))
+    xg, wg = leaf(x, DEV), leaf(w, DEV)
+    sx, sw, sc = _scale_for(x), _scale_for(w), _scale_for(cot, True)
+    ops.QUANT.set(xg.device, wg.data_ptr(), "linear_fwd", sx, sw)
+    ops.QUANT.set(xg.device, wg.data_ptr(), "linear_dgrad", sc, sw)
+    yg = ops.linear(xg, wg, None)
+    (yg * cot.to(DEV)).sum().backward()
+    xq, wq, cq = _fp8_round(x, sx), _fp8_round(w, sw), _fp8_round(cot, sc, True)
+    assert_close(yg, (xq @ wq.t()) / (sx * sw), 2e-5, "y vs the GEMM of the fp8-rounded operands")
+    assert_close(yg, x.double() @ w.double().t(), 8e-2, "y vs the unrounded GEMM")
+    assert_close(xg.grad, (cq @ wq) / (sc * sw), 2e-5, "dx vs the GEMM of the e5m2 gradient and the e4m3 weight")
+    big = M >= 32768
+    cr, xr = (cot.double(), x.double()) if big else (_bf16_round(cot).double(), _bf16_round(x).double())
+    assert_close(wg.grad, cr.t() @ xr, 1e-5 if big else 2e-6, "dw (bf16 operands / exact fp32 for the tall-skinny shapes)")
+
+
+def test_conv3_fp8_mfma(fp8_mfma):
+    B, H, W, K, N = 2, 16, 16, 32, 64
+    x, w, b, cot = T("f8c.x", (B, H * W, K)), T("f8c.w", (N, K, 3, 3), 0.2), T("f8c.b", (N,)), T("f8c.c", (B, H * W, N))
+    xg, wg, bg = leaf(x, DEV), leaf(w, DEV), leaf(b, DEV)
+    sx, sw, sc = _scale_for(x), _scale_for(w), _scale_for(cot, True)
+    ops.QUANT.set(xg.device, wg.data_ptr(), "conv3_fwd", sx, sw)
+    ops.QUANT.set(xg.device, wg.data_ptr(), "conv3_dgrad", sc, sw)
+    yg = ops.conv3(xg, wg, bg, H, W, lib.ACT_NONE)
+    (yg * cot.to(DEV)).sum().backward()
+    xq, wq, cq = _fp8_round(x, sx), _fp8_round(w, sw), _fp8_round(cot, sc, True)
+    conv = lambda a, ww: F.conv2d(a.view(B, H, W, -1).permute(0, 3, 1, 2), ww, None, padding=1).permute(0, 2, 3, 1).reshape(B, H * W, -1)
+    assert_close(yg, conv(xq, wq) / (sx * sw) + b.double(), 2e-5, "y vs the conv of the fp8-rounded operands")
+    dx_ref = F.conv_transpose2d(cq.view(B, H, W, N).permute(0, 3, 1, 2), wq, None, padding=1).permute(0, 2, 3, 1).reshape(B, H * W, K) / (sc * sw)
+    assert_close(xg.grad, dx_ref, 2e-5, "dx vs the transposed conv of the e5m2 gradient and the e4m3 weight")
+    xo, wo = leaf(_bf16_round(x).double()), leaf(_bf16_round(w).double())
+    (conv(xo, wo) * _bf16_round(cot).double()).sum().backward()
+    assert_close(wg.grad, wo.grad, 2e-6, "dw (bf16 operands)")
+
+
+def test_fp8_amax_collection_and_update(fp8_mfma):
+    """a calibration pass (bf16 operands, record flag set) collects exactly max |operand| on every kernel path; adnm_quant_update turns it
+    into fmax / (amax * headroom), clears the amax and schedules the next calibration by the period"""
+    ops.set_mfma_precision("f32")
+    for M, K, N in [(64, 1024, 512), (256, 1024, 2048), (65536, 32, 128)]:
+        x, w, cot = T(f"am.x{M}", (M, K), 3.0), T(f"am.w{N}", (N, K), 0.05), T(f"am.c{M}", (M, N), 0.01)
+        xg, wg = leaf(x, DEV), leaf(w, DEV)
+        y = ops.fp8_calibrate(xg.device, lambda: ops.linear(xg, wg, None).mul(cot.to(DEV)).sum().backward())
+        tab = ops.QUANT.dump(xg.device)
+        f, g = tab[(wg.data_ptr(), "fnt")], tab[(wg.data_ptr(), "gnn")]
+        h = ops.QUANT.headroom
+        assert abs(f[0] - 448.0 / (float(x.abs().max()) * h)) <= 1e-5 * f[0], (M, K, N, f)
+        assert abs(f[1] - 448.0 / (float(w.abs().max()) * h)) <= 1e-5 * f[1], (M, K, N, f)
+        assert abs(g[0] - 57344.0 / (float(cot.abs().max()) * h)) <= 1e-5 * g[0], (M, K, N, g)
+        assert f[2] == 0.0 and f[3] == 0.0 and f[6] == 0.0   # amax cleared, not recording until the period comes round
+        for _ in range(ops.QUANT.period - 2):
+            ops.QUANT.update(xg.device)
+        assert ops.QUANT.dump(xg.device)[(wg.data_ptr(), "fnt")][6] == 0.0
+        ops.QUANT.update(xg.device)
+        assert ops.QUANT.dump(xg.device)[(wg.data_ptr(), "fnt")][6] == 1.0   # step `period`: collect again
+        ops.set_mfma_precision("f32")
