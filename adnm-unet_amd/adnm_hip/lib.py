@@ -16,7 +16,7 @@ _CT = {
     "const void*": ctypes.c_void_p, "void*": ctypes.c_void_p, "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p,
     "int64_t": ctypes.c_int64, "int": ctypes.c_int, "float": ctypes.c_float, "adnm_stream_t": ctypes.c_void_p,
     "const char*": ctypes.c_char_p, "char*": ctypes.c_char_p, "void": None,
-    "float* const*": ctypes.c_void_p, "const float* const*": ctypes.c_void_p,
+    "float* const*": ctypes.c_void_p, "const float* const*": ctypes.c_void_p, "const int64_t*": ctypes.c_void_p,
 }
 
 
@@ -95,6 +95,11 @@ def ptr_table(tensors):
     for i, t in enumerate(tensors):
         arr[i] = None if t is None else t.data_ptr()
     return arr
+
+
+def i64_table(values):
+    """Host array of int64 for the `const int64_t*` parameters."""
+    return (ctypes.c_int64 * len(values))(*[int(v) for v in values])
 
 
 def query(name, *args):

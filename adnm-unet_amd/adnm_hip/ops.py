@@ -256,6 +256,20 @@ class GradRegistry:
         with self._lock:
             return set(self._claimed.get(owner, ())) - self._multi.get(owner, set())
 
+    def take_accumulating(self, ptr, shape, device):
+        """-> (tensor, accumulate).  Like take(), for a kernel whose gradient goes through a DEFERRED fold: a second claim of a registered
+        slice inside one backward pass gets the slice again with accumulate = True — the caller marks its queued fold as accumulating
+        (adnm_foldq_accumulate_next) and hands autograd None for that input, so no separate add (and no flush) is needed.  Outside a
+        deferring trainer this is take()."""
+        with self._lock:
+            self._drain()
+            ent = self._dst.get(ptr)
+            if ent is not None:
+                owner, g = ent
+                if ptr in self._claimed[owner] and ptr not in self._multi[owner] and tuple(g.shape) == tuple(shape) and FOLDS.deferring(device):
+                    return g.detach(), True
+        return self.take(ptr, shape, device), False
+
     def take(self, ptr, shape, device, dtype=torch.float32, strides=None):
         """strides: the memory layout the caller is going to WRITE (element strides of `shape`); a registered slice laid out
         differently is refused WITHOUT being recorded as claimed, so the trainer's gather still copies that gradient."""
@@ -307,6 +321,10 @@ class FoldRegistry:
         """with FOLDS.active(dev): ... — deferral is on for the kernels launched inside (from any thread: autograd runs backward on
         its own), the queue is flushed on the way out.  Scoped in time, so plain autograd users of the device are never deferred."""
         return _Active(self, device, on)
+
+    def deferring(self, device):
+        ent = self._q.get(device.index)
+        return ent is not None and ent["on"] and not ent.get("hold", False)
 
     def hold(self, device):
         """The next defer() on this device (the call that asked for the gradient slice just refused) runs undeferred."""
@@ -608,9 +626,12 @@ def k_dwconv_fwd(x, wt, bias, B, H, W, C, K, act, y=None, addend=None, chan_majo
     return y
 
 
-def k_dwconv_bwd(dy, x, wt, bias, B, H, W, C, K, act, dx=None, want_bias=False, want_w=True, chan_major=False):
+def k_dwconv_bwd(dy, x, wt, bias, B, H, W, C, K, act, dx=None, want_bias=False, want_w=True, chan_major=False, want_dx=True):
+    """want_dx=False (the input needs no gradient; only without activation, where the tap gradient reads dy itself): tap / bias gradients only."""
     dev = x.device
-    if dx is None:
+    if not want_dx:
+        assert act == lib.ACT_NONE and want_w
+    if dx is None and want_dx:
         dx = torch.empty((B * H * W, C), dtype=x.dtype, device=dev)
     dwt = torch.empty((C, K * K) if chan_major else (K * K, C), dtype=torch.float32, device=dev) if want_w else None
     db = torch.empty(C, dtype=torch.float32, device=dev) if want_bias else None
@@ -619,14 +640,15 @@ def k_dwconv_bwd(dy, x, wt, bias, B, H, W, C, K, act, dx=None, want_bias=False, 
     ws = _ws(nb, dev)
     pdy, lddy = _rows(dy)
     px, ldx = _rows(x)
-    pdx, lddx = _rows(dx)
+    pdx, lddx = _rows(dx) if dx is not None else (None, 0)
     if not want_w:
         lib.call("adnm_dwconv_bwd", pdy, lddy, px, ldx, _p(wt), _p(bias), _p(dpre), pdx, lddx, None, None, ws.data_ptr(),
                  nb, B, H, W, C, K, K, act, int(chan_major), _dt(x), _stream())
         return dx, dwt, db
     # input gradient (and the pre-activation gradient it needs) on the current stream, the tap / bias gradients as a leaf beside it
-    lib.call("adnm_dwconv_bwd", pdy, lddy, px, ldx, _p(wt), _p(bias), _p(dpre), pdx, lddx, None, None, ws.data_ptr(),
-             nb, B, H, W, C, K, K, act, int(chan_major), _dt(x), _stream())
+    if want_dx:
+        lib.call("adnm_dwconv_bwd", pdy, lddy, px, ldx, _p(wt), _p(bias), _p(dpre), pdx, lddx, None, None, ws.data_ptr(),
+                 nb, B, H, W, C, K, K, act, int(chan_major), _dt(x), _stream())
     g, ldg = (dpre.data_ptr(), C) if dpre is not None else (pdy, lddy)
     pdw, pdb, dt_ = _p(dwt), _p(db), _dt(x)
     # taps / bias gradients: parameters, or prep intermediates flushed at the prep node
@@ -645,12 +667,15 @@ def k_haar_dwt(x, B, H, W, C, cx=1):
     return y
 
 
-def k_haar_idwt(s, ll_add, B, H, W, C):
-    """s: (B*h2*w2, 4C) contiguous (+ ll_add (B*h2*w2, C)) -> (B*H*W, C)."""
+def k_haar_idwt(s, ll_add, B, H, W, C, y_add=()):
+    """s: (B*h2*w2, 4C) contiguous (+ ll_add (B*h2*w2, C)) -> (B*H*W, C) [+ up to two contiguous (B*H*W, C) addends]."""
     _need_gpu(s)
     assert s.is_contiguous() and (ll_add is None or ll_add.is_contiguous())
+    adds = [a if a.is_contiguous() else a.contiguous() for a in y_add if a is not None]
+    assert len(adds) <= 2
+    adds += [None] * (2 - len(adds))
     y = torch.empty((B * H * W, C), dtype=s.dtype, device=s.device)
-    lib.call("adnm_haar_idwt", s.data_ptr(), _p(ll_add), y.data_ptr(), B, H, W, C, _dt(s), _stream())
+    lib.call("adnm_haar_idwt", s.data_ptr(), _p(ll_add), _p(adds[0]), _p(adds[1]), y.data_ptr(), B, H, W, C, _dt(s), _stream())
     return y
 
 
@@ -945,7 +970,10 @@ class WTConvFn(torch.autograd.Function):
     """WTConv2d.forward (WTConv2d.py:100-153) on (B, H*W, C) tokens: Haar pyramid, depthwise KxK on every
     level's 4C sub-bands (per-channel wavelet_scale folded into the taps by the caller), inverse pyramid,
     plus the base depthwise conv (base_scale folded) — all by HIP kernels, manual backward.
-    Arguments: x, base taps (K*K,C), base bias (C)|None, *level taps (K*K,4C)."""
+    Arguments: x, base taps (K*K,C), base bias (C)|None, *level taps (K*K,4C).
+    Returns (y, x): the second value is an autograd alias of the input for its OTHER consumer (the residual mixes of PatchEmbed /
+    WTLayer / OutProj read x again: model_untils.py:306,310,418,881 of the reference) — its gradient is added inside the last synthesis
+    kernel of the backward pass instead of by a separate autograd add."""
 
     @staticmethod
     def forward(ctx, x, H, W, K, base_wt, base_bias, *level_wt):
@@ -969,17 +997,21 @@ class WTConvFn(torch.autograd.Function):
         y = k_dwconv_fwd(x2, base_wt, base_bias, B, H, W, C, K, lib.ACT_NONE, addend=nxt)
         ctx.save_for_backward(x2, base_wt, base_bias, *level_wt, *subs)
         ctx.dims = (B, H, W, C, K, levels, shapes)
-        return y.view(B, L, C)
+        ctx.set_materialize_grads(False)
+        return y.view(B, L, C), x
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dalias):
         B, H, W, C, K, levels, shapes = ctx.dims
         saved = ctx.saved_tensors
         x2, base_wt, base_bias = saved[0], saved[1], saved[2]
         level_wt, subs = saved[3:3 + levels], saved[3 + levels:]
+        need_dx = ctx.needs_input_grad[0]
+        if dy is None:   # only the alias was used
+            return (dalias if need_dx else None, None, None, None, None, None, *([None] * levels))
         dy2 = dy.reshape(B * H * W, C)
         dy2 = dy2 if dy2.stride(-1) == 1 else dy2.contiguous()
-        dxb, dbase, dbb = k_dwconv_bwd(dy2, x2, base_wt, base_bias, B, H, W, C, K, lib.ACT_NONE, want_bias=base_bias is not None)
+        dxb, dbase, dbb = k_dwconv_bwd(dy2, x2, base_wt, base_bias, B, H, W, C, K, lib.ACT_NONE, want_bias=base_bias is not None, want_dx=need_dx)
         # the reconstruction's backward walks down: d(merged_i) = DWT(d r_{i-1}); its LL band is d r_i
         dtags = []
         cur, cx = dy2, 1
@@ -988,20 +1020,30 @@ class WTConvFn(torch.autograd.Function):
             dm = k_haar_dwt(cur, B, hh, ww, C, cx)
             dtags.append(dm)
             cur, cx = dm, 4
-        # the analysis side's backward walks up: d(ll_{i-1}) = IDWT(d sub_i + [d ll_i on the LL band])
+        # the analysis side's backward walks up: d(ll_{i-1}) = IDWT(d sub_i + [d ll_i on the LL band]); the last step adds the base conv's
+        # input gradient and the alias's gradient in the same pass.  An input that needs no gradient (PatchEmbed.conv1: the radar frames)
+        # skips every input-gradient kernel.
         dll = None
         dlw = [None] * levels
         for i in range(levels - 1, -1, -1):
             hh, ww = shapes[i]
             h2, w2 = (hh + 1) // 2, (ww + 1) // 2
-            dsub, dlw[i], _ = k_dwconv_bwd(dtags[i], subs[i], level_wt[i], None, B, h2, w2, 4 * C, K, lib.ACT_NONE)
-            dll = k_haar_idwt(dsub, dll, B, hh, ww, C)
-        dx = dxb + dll
-        return (dx.view(B, H * W, C), None, None, None, dbase, dbb, *dlw)
+            dsub, dlw[i], _ = k_dwconv_bwd(dtags[i], subs[i], level_wt[i], None, B, h2, w2, 4 * C, K, lib.ACT_NONE, want_dx=need_dx)
+            if need_dx:
+                dll = k_haar_idwt(dsub, dll, B, hh, ww, C, y_add=(dxb, dalias.reshape(B * H * W, C) if dalias is not None else None) if i == 0 else ())
+        if not need_dx:
+            dx = None
+        elif levels == 0:
+            dx = dxb if dalias is None else dxb + dalias.reshape(B * H * W, C)
+        else:
+            dx = dll
+        return (dx.view(B, H * W, C) if dx is not None else None, None, None, None, dbase, dbb, *dlw)
 
 
-def wtconv(x, H, W, K, base_wt, base_bias, level_wts):
-    return WTConvFn.apply(x, H, W, K, base_wt, base_bias, *level_wts)
+def wtconv(x, H, W, K, base_wt, base_bias, level_wts, tap=False):
+    """tap=True: -> (y, alias of x) — hand the alias to x's other consumer (see WTConvFn)."""
+    y, xa = WTConvFn.apply(x, H, W, K, base_wt, base_bias, *level_wts)
+    return (y, xa) if tap else y
 
 
 class ADNMixerFn(torch.autograd.Function):
@@ -1139,8 +1181,16 @@ class LinCombFn(torch.autograd.Function):
         g = g if g.stride(-1) == 1 else g.contiguous()
         need_x = ctx.needs_input_grad[1:1 + n]
         dxs = [torch.empty((M, C), dtype=x2[0].dtype, device=dev) if need_x[i] else None for i in range(n)]
-        # Block's beta1 / beta2 feed two mixes: the second claim of their slice flushes the queue before autograd adds (GRADS.take)
-        dss = [grad_dst(ss[i].data_ptr(), ss[i].shape, dev) if ss[i] is not None else None for i in range(n)]
+        # Block's beta1 / beta2 feed two mixes: the second claim of their slice lets the deferred fold ADD to it (fold segments: 0 = gamma,
+        # 1 + i = scalar i) and hands autograd None — no flush, no separate add (GRADS.take_accumulating)
+        dss, accmask = [], 0
+        for i in range(n):
+            if ss[i] is None:
+                dss.append(None)
+                continue
+            t, acc = GRADS.take_accumulating(ss[i].data_ptr(), ss[i].shape, dev)
+            dss.append(t)
+            accmask |= (1 << (1 + i)) if acc else 0
         dgamma = grad_dst(gamma.data_ptr(), gamma.shape, dev) if gamma is not None else None
         nb = lib.query("adnm_lincomb_bwd_ws_bytes", M, C)
         ws = _ws(nb, dev)
@@ -1149,11 +1199,15 @@ class LinCombFn(torch.autograd.Function):
         sp = [_p(s) for s in ss] + [None] * (3 - n)
         dsp = [_p(s) for s in dss] + [None] * (3 - n)
         pg, ldg = _rows(g)
-        with FOLDS.defer(dev, ws):
+        with FOLDS.defer(dev, ws) as deferred:
+            if accmask:
+                assert deferred, "an accumulating gradient claim needs the deferred fold queue"
+                lib.load().adnm_foldq_accumulate_next(accmask)
             lib.call("adnm_lincomb_bwd", pg, ldg, xp[0][0], xp[0][1], xp[1][0], xp[1][1], xp[2][0], xp[2][1], sp[0], sp[1], sp[2], _p(gamma),
                      dxp[0][0], dxp[0][1], dxp[1][0], dxp[1][1], dxp[2][0], dxp[2][1], dsp[0], dsp[1], dsp[2], _p(dgamma), ws.data_ptr(), nb,
                      M, C, _dt(g), _stream())
-        return (dgamma, *[d.view(shp) if d is not None else None for d in dxs], *dss)
+        return (dgamma, *[d.view(shp) if d is not None else None for d in dxs],
+                *[None if (accmask >> (1 + i)) & 1 else d for i, d in enumerate(dss)])
 
 
 def lincomb(xs, scalars, gamma=None):
@@ -1249,6 +1303,143 @@ class WtPrepFn(torch.autograd.Function):
 def wt_prep(C, Cp, K, levels, bias, weights, scales):
     out = WtPrepFn.apply(C, Cp, K, levels, bias, *weights, *scales)
     return out[0], out[1], list(out[2:])
+
+
+class AdnPrepMultiFn(torch.autograd.Function):
+    """AdnPrepFn for every mixer of a model stage in ONE launch each way (include/adnm_hip.h: adnm_adnprep_*_multi).
+    args: dims = [(dm, di, gn, P), ...], then 15 parameters per mixer; returns 5 tensors per mixer (w_in, taps, ln_w, ln_b, w_out)."""
+
+    @staticmethod
+    def forward(ctx, dims, *params):
+        params = [p.contiguous() for p in params]
+        n = len(dims)
+        dev = params[0].device
+        _need_gpu(params[0])
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        outs, table, dflat = [], [], []
+        for dm, di, gn, P in dims:
+            nh, cx = di // P, di + 2 * gn
+            w_in, taps, ln_w, ln_b, w_out = f(2 * di + 2 * gn + nh, dm), f(9, di + cx), f(di), f(di), f(dm, 2 * di)
+            outs += [w_in, taps, ln_w, ln_b, w_out]
+            table += [w_in, taps[:, di:], taps[:, :di], ln_w, ln_b, w_out]
+            dflat += [dm, di, gn, P, di + cx]
+        lib.call("adnm_adnprep_fwd_multi", n, lib.ptr_table(params), lib.ptr_table(table), lib.i64_table(dflat), _stream())
+        ctx.save_for_backward(*params)
+        ctx.dims = dims
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g):
+        params = ctx.saved_tensors
+        dims = ctx.dims
+        n = len(dims)
+        dev = params[0].device
+        FOLDS.flush(dev)   # the incoming gradients are (deferred) fold results of the mixers' backward
+        g = [t.contiguous() for t in g]
+        gtab, dflat = [], []
+        for i, (dm, di, gn, P) in enumerate(dims):
+            g_w_in, g_taps, g_ln_w, g_ln_b, g_w_out = g[5 * i:5 * i + 5]
+            gtab += [g_w_in, g_taps[:, di:], g_taps[:, :di], g_ln_w, g_ln_b, g_w_out]
+            dflat += [dm, di, gn, P, 2 * di + 2 * gn]
+        dparams = [grad_dst(p.data_ptr(), p.shape, dev, p.dtype) for p in params]
+        nb = lib.query("adnm_adnprep_bwd_multi_ws_bytes", n)
+        ws = _ws(nb, dev)
+        with FOLDS.defer(dev, ws, *g):
+            lib.call("adnm_adnprep_bwd_multi", n, lib.ptr_table(params), lib.ptr_table(gtab), lib.ptr_table(dparams), lib.i64_table(dflat),
+                     ws.data_ptr(), nb, _stream())
+        return (None, *dparams)
+
+
+class WtPrepMultiFn(torch.autograd.Function):
+    """WtPrepFn for every WTConv2d of a model stage in ONE launch each way.  args: dims = [(C, Cp, K, levels, has_bias), ...], then per
+    module: bias (if has_bias), (1 + levels) conv weights, (1 + levels) scales.  Returns per module: bias_t (if has_bias), (1 + levels) taps."""
+
+    @staticmethod
+    def forward(ctx, dims, *ts):
+        dev = ts[0].device
+        _need_gpu(ts[0])
+        w, s, bias, taps, bias_t, dflat, outs = [], [], [], [], [], [], []
+        it = iter(ts)
+        saved = []
+        for C, Cp, K, levels, has_bias in dims:
+            n1 = 1 + levels
+            b = next(it).contiguous() if has_bias else None
+            ws_ = [next(it).contiguous() for _ in range(n1)]
+            ss = [next(it).contiguous() for _ in range(n1)]
+            tp = [torch.empty((K * K, Cp if k == 0 else 4 * Cp), dtype=torch.float32, device=dev) for k in range(n1)]
+            bt = torch.empty(Cp, dtype=torch.float32, device=dev) if has_bias else None
+            pad = [None] * (5 - n1)
+            w += ws_ + pad; s += ss + pad; taps += tp + pad
+            bias.append(b); bias_t.append(bt)
+            dflat += [C, Cp, K, levels]
+            outs += ([bt] if has_bias else []) + tp
+            saved += ([b] if has_bias else []) + ws_ + ss
+        lib.call("adnm_wtprep_fwd_multi", len(dims), lib.ptr_table(w), lib.ptr_table(s), lib.ptr_table(bias), lib.ptr_table(taps), lib.ptr_table(bias_t),
+                 lib.i64_table(dflat), _stream())
+        ctx.save_for_backward(*saved)
+        ctx.dims = dims
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g):
+        dims = ctx.dims
+        saved = ctx.saved_tensors
+        dev = saved[0].device
+        FOLDS.flush(dev)   # the incoming tap gradients are (deferred) fold results of the depthwise weight-gradient kernels
+        w, s, bias, gtaps, gbias_t, dw, ds, dbias, dflat, grads = [], [], [], [], [], [], [], [], [], []
+        si, gi = iter(saved), iter(g)
+        for C, Cp, K, levels, has_bias in dims:
+            n1 = 1 + levels
+            b = next(si) if has_bias else None
+            ws_ = [next(si) for _ in range(n1)]
+            ss = [next(si) for _ in range(n1)]
+            gb = next(gi).contiguous() if has_bias else None
+            gt = [next(gi).contiguous() for _ in range(n1)]
+            dws, dss = [torch.empty_like(t) for t in ws_], [torch.empty_like(t) for t in ss]
+            db = torch.empty_like(b) if has_bias else None
+            pad = [None] * (5 - n1)
+            w += list(ws_) + pad; s += list(ss) + pad; gtaps += gt + pad; dw += dws + pad; ds += dss + pad
+            bias.append(b); gbias_t.append(gb); dbias.append(db)
+            dflat += [C, Cp, K, levels]
+            grads += ([db] if has_bias else []) + dws + dss
+        lib.call("adnm_wtprep_bwd_multi", len(dims), lib.ptr_table(w), lib.ptr_table(s), lib.ptr_table(bias), lib.ptr_table(gtaps), lib.ptr_table(gbias_t),
+                 lib.ptr_table(dw), lib.ptr_table(ds), lib.ptr_table(dbias), lib.i64_table(dflat), _stream())
+        return (None, *grads)
+
+
+def prep_group(*roots):
+    """Prepare the kernel-layout parameters of EVERY ADN-SSD mixer and WTConv2d under `roots` in one launch per kind (instead of one per
+    module): each module finds its tensors in `_adnm_prepped` at its next forward and uses them once.  The modules define
+    adnm_prep_kind ("adn" / "wt") and adnm_prep_args().  Called by VisionMamba.forward_stage1 / forward_stage2 (one group per model
+    stage, so a staged backward still finds all of a group's gradients inside one stage)."""
+    adn, wt = [], []
+    for r in roots:
+        for m in r.modules():
+            kind = getattr(m, "adnm_prep_kind", None)
+            if kind == "adn" and m.adnm_prep_ready():
+                adn.append(m)
+            elif kind == "wt":
+                wt.append(m)
+    if adn and adn[0].in_proj.weight.is_cuda:
+        dims, params = [], []
+        for m in adn:
+            d, p = m.adnm_prep_args()
+            dims.append(d)
+            params += p
+        out = AdnPrepMultiFn.apply(dims, *params)
+        for i, m in enumerate(adn):
+            m.__dict__["_adnm_prepped"] = out[5 * i:5 * i + 5]
+    if wt and wt[0].base_conv.weight.is_cuda:
+        dims, ts = [], []
+        for m in wt:
+            d, t = m.adnm_prep_args()
+            dims.append(d)
+            ts += t
+        out = list(WtPrepMultiFn.apply(dims, *ts))
+        for m, (C, Cp, K, levels, has_bias) in zip(wt, dims):
+            bias_t = out.pop(0) if has_bias else None
+            taps = [out.pop(0) for _ in range(1 + levels)]
+            m.__dict__["_adnm_prepped"] = (Cp, taps[0], bias_t, taps[1:])
 
 
 class MaxPoolFn(torch.autograd.Function):
@@ -1734,6 +1925,36 @@ def igate(x, enhance, threshold):
     return IGateFn.apply(x, enhance, threshold)
 
 
+class ChanPadFn(torch.autograd.Function):
+    """(…, Cin) tokens -> (…, Cout): zero-padded (Cout > Cin) or cropped channels in one HIP pass; backward is the same kernel the other way."""
+
+    @staticmethod
+    def forward(ctx, x, Cout):
+        _need_gpu(x)
+        Cin = x.shape[-1]
+        x2 = x.reshape(-1, Cin)
+        x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
+        y = torch.empty((x2.shape[0], Cout), dtype=torch.float32, device=x.device)
+        lib.call("adnm_chancopy", x2.data_ptr(), x2.stride(0), Cin, y.data_ptr(), Cout, x2.shape[0], _stream())
+        ctx.meta = (x.shape, Cin, Cout)
+        return y.view(*x.shape[:-1], Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        shp, Cin, Cout = ctx.meta
+        d2 = dy.reshape(-1, Cout)
+        d2 = d2 if d2.stride(-1) == 1 else d2.contiguous()
+        dx = torch.empty((d2.shape[0], Cin), dtype=torch.float32, device=dy.device)
+        lib.call("adnm_chancopy", d2.data_ptr(), d2.stride(0), Cout, dx.data_ptr(), Cin, d2.shape[0], _stream())
+        return dx.view(shp), None
+
+
+def chanpad(x, Cout):
+    if x.dtype != torch.float32:
+        _unsupported("chanpad", f"needs fp32 tokens, got {x.dtype}")
+    return ChanPadFn.apply(x, Cout)
+
+
 class IGateResFn(torch.autograd.Function):
     """EncoderToDecoder's entry (model_untils.py:761-763): IntensityGate(x + gama * res), res the (B, 1, C) bridge gate broadcast over
     the tokens — one pass each way (csrc/elementwise.hip)."""
@@ -1893,6 +2114,65 @@ def tokmean_tap(x):
     if x.dtype != torch.float32 or x.dim() != 3 or x.shape[-1] % 4:
         _unsupported("tokmean_tap", f"needs fp32 (B, L, C) tokens with 4 | C, got {x.dtype} {tuple(x.shape)}")
     return TokMeanTapFn.apply(x)
+
+
+class BridgeHeadsFn(torch.autograd.Function):
+    """The live heads of Channel_Att_Bridge in one launch each way + one fold (csrc/bridge.hip): for every head i,
+    gate_i = IntensityGate(att . W_i^T + b_i).  args: att (B, 1, S), enhance, threshold, then W_0, b_0, W_1, b_1, ...; returns the gates
+    (B, 1, C_i)."""
+
+    @staticmethod
+    def forward(ctx, att, enhance, threshold, *wb):
+        _need_gpu(att)
+        B, _, S = att.shape
+        a2 = att.reshape(B, S).contiguous()
+        Ws, bs = [w.contiguous() for w in wb[0::2]], list(wb[1::2])
+        Cs = [w.shape[0] for w in Ws]
+        dev = att.device
+        zs = [torch.empty((B, c), dtype=torch.float32, device=dev) for c in Cs]
+        ys = [torch.empty((B, 1, c), dtype=torch.float32, device=dev) for c in Cs]
+        lib.call("adnm_bridge_heads_fwd", a2.data_ptr(), lib.ptr_table(Ws), lib.ptr_table(bs), lib.i64_table(Cs), len(Ws), enhance.data_ptr(),
+                 threshold.data_ptr(), lib.ptr_table(zs), lib.ptr_table(ys), B, S, _stream())
+        ctx.save_for_backward(a2, enhance, threshold, *Ws, *zs)
+        ctx.meta = (B, S, Cs, [b is not None for b in bs], [b.data_ptr() if b is not None else 0 for b in bs], att.shape)
+        ctx.set_materialize_grads(False)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        B, S, Cs, has_b, b_ptrs, ashape = ctx.meta
+        n = len(Cs)
+        saved = ctx.saved_tensors
+        a2, enhance, threshold, Ws, zs = saved[0], saved[1], saved[2], saved[3:3 + n], saved[3 + n:]
+        dev = a2.device
+        dys = [(d.reshape(B, c).contiguous() if d is not None else torch.zeros((B, c), dtype=torch.float32, device=dev)) for d, c in zip(dys, Cs)]
+        datt = torch.empty((B, S), dtype=torch.float32, device=dev)
+        dWs = [grad_dst(w.data_ptr(), w.shape, dev) for w in Ws]
+        dbs = [grad_dst(p, (c,), dev) if h else None for p, c, h in zip(b_ptrs, Cs, has_b)]
+        de, dt = grad_dst(enhance.data_ptr(), enhance.shape, dev), grad_dst(threshold.data_ptr(), threshold.shape, dev)
+        nb = lib.query("adnm_bridge_heads_bwd_ws_bytes", sum(Cs), B, S)
+        ws = _ws(nb, dev)
+        lib.call("adnm_bridge_heads_bwd", a2.data_ptr(), lib.ptr_table(Ws), lib.i64_table(Cs), n, enhance.data_ptr(), threshold.data_ptr(),
+                 lib.ptr_table(zs), lib.ptr_table(dys), datt.data_ptr(), lib.ptr_table(dWs), lib.ptr_table(dbs), de.data_ptr(), dt.data_ptr(),
+                 ws.data_ptr(), nb, B, S, _stream())
+        out = [datt.view(ashape), de, dt]
+        for dw, db in zip(dWs, dbs):
+            out += [dw, db]
+        return tuple(out)
+
+
+def bridge_heads(att, enhance, threshold, weights, biases):
+    """att (B, 1, S) -> [IntensityGate(att . W_i^T + b_i) for i]: every live head of Channel_Att_Bridge in one launch."""
+    _need_gpu(att)
+    B, one, S = att.shape
+    if att.dtype != torch.float32 or one != 1 or S % 4 or S > 3072 or not 1 <= B <= 8 or not 1 <= len(weights) <= 8 or \
+            any(w.dim() != 2 or w.shape[1] != S for w in weights) or enhance.numel() != 1 or threshold.numel() != 1:
+        _unsupported("bridge_heads", f"needs fp32 (B <= 8, 1, S) pooled channels with 4 | S <= 3072 and 1..8 (C_i, S) weights, got {tuple(att.shape)}, "
+                                     f"{[tuple(w.shape) for w in weights]}")
+    wb = []
+    for w, b in zip(weights, biases):
+        wb += [w, b]
+    return list(BridgeHeadsFn.apply(att, enhance, threshold, *wb))
 
 
 class Conv1d3Fn(torch.autograd.Function):

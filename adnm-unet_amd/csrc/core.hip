@@ -108,6 +108,7 @@ struct FoldDesc {
   const float* part;
   int rows, n;
   int lc;   // log2(columns per workgroup): 2 .. 10
+  int acc;  // bit q: segment q ADDS the folded value to its destination instead of overwriting it (adnm_foldq_accumulate_next)
   FoldSegs segs;
 };
 struct MultiFold {
@@ -168,7 +169,10 @@ __global__ __launch_bounds__(kFoldThreads) void fold_rows_kernel(MultiFold mf_by
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (c < fd.segs.end[q]) {
-        if (fd.segs.ptr[q]) fd.segs.ptr[q][c - begin] = t;
+        if (fd.segs.ptr[q]) {
+          if (fd.acc & (1 << q)) fd.segs.ptr[q][c - begin] += t;
+          else fd.segs.ptr[q][c - begin] = t;
+        }
         break;
       }
       begin = fd.segs.end[q];
@@ -181,6 +185,7 @@ struct FoldQueue {
   std::vector<const char*> names;
 };
 thread_local FoldQueue* tls_foldq = nullptr;
+thread_local int tls_fold_acc_next = 0;   // accumulate mask of the next fold queued on this thread (cleared when used)
 
 // measurement aid: ADNM_FOLD_BATCH=1 launches every queued fold on its own (and under its own profiler name)
 int fold_batch_limit() {
@@ -230,6 +235,8 @@ void adnm_launch_fold(const char* prof_name, const float* part, int rows, int n,
                       AdnmFoldSeg s3, hipStream_t st) {
   FoldDesc fd;
   fd.part = part, fd.rows = rows, fd.n = n, fd.lc = fold_lc(rows, n);
+  fd.acc = tls_foldq ? tls_fold_acc_next : 0;   // accumulation exists for queued folds only: the flush orders it behind the overwriting ones
+  tls_fold_acc_next = 0;
   const AdnmFoldSeg in[4] = {s0, s1, s2, s3};
   int end = 0;
   for (int k = 0; k < 4; ++k) {
@@ -262,11 +269,38 @@ extern "C" int adnm_foldq_clear(void* q) {   // forget what is queued without la
   ((FoldQueue*)q)->names.clear();
   return ADNM_OK;
 }
+extern "C" int adnm_foldq_accumulate_next(int mask) {
+  tls_fold_acc_next = mask & 15;
+  return ADNM_OK;
+}
 extern "C" int adnm_foldq_flush(void* q, adnm_stream_t stream) {
   ADNM_REQUIRE(q, "foldq_flush: null queue");
   FoldQueue* fq = (FoldQueue*)q;
   if (fq->pending.empty()) return ADNM_OK;
-  launch_folds(fq->pending.data(), fq->names.data(), (int)fq->pending.size(), (hipStream_t)stream);
+  // the overwriting folds first, then — in later launches, i.e. ordered behind them on the stream — the accumulating ones; two
+  // accumulating folds that share a destination never share a launch (the workgroups of one launch run concurrently)
+  std::vector<FoldDesc> plain, accs;
+  std::vector<const char*> pn, an;
+  for (size_t i = 0; i < fq->pending.size(); ++i) {
+    if (fq->pending[i].acc) accs.push_back(fq->pending[i]), an.push_back(fq->names[i]);
+    else plain.push_back(fq->pending[i]), pn.push_back(fq->names[i]);
+  }
+  if (!plain.empty()) launch_folds(plain.data(), pn.data(), (int)plain.size(), (hipStream_t)stream);
+  while (!accs.empty()) {
+    std::vector<FoldDesc> round, rest;
+    std::vector<const char*> rn, restn;
+    for (size_t i = 0; i < accs.size(); ++i) {
+      bool clash = false;
+      for (const FoldDesc& r : round)
+        for (int a = 0; a < 4 && !clash; ++a)
+          for (int b = 0; b < 4 && !clash; ++b)
+            clash = r.segs.ptr[a] && r.segs.ptr[a] == accs[i].segs.ptr[b] && ((r.acc >> a) & 1) && ((accs[i].acc >> b) & 1);
+      if (clash) rest.push_back(accs[i]), restn.push_back(an[i]);
+      else round.push_back(accs[i]), rn.push_back(an[i]);
+    }
+    launch_folds(round.data(), rn.data(), (int)round.size(), (hipStream_t)stream);
+    accs.swap(rest), an.swap(restn);
+  }
   fq->pending.clear();
   fq->names.clear();
   ADNM_CHECK_LAUNCH("foldq_flush");

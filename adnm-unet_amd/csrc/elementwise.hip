@@ -453,6 +453,28 @@ extern "C" int adnm_igate_res_bwd(const float* dy, const float* x, const float* 
   return ADNM_OK;
 }
 
+// Channel pad / crop of a token matrix: y[m, c] = x[m, c] for c < min(Cin, Cout), 0 for Cin <= c < Cout.  The 5-frame input stage is run on
+// 8 channels (every stencil kernel moves 16-byte channel quads): pad on the way in, crop on the way out, and each is the other's backward.
+namespace {
+__global__ __launch_bounds__(kBlock) void chancopy_kernel(const float* __restrict__ x, int64_t ldx, int Cin, float* __restrict__ y, int Cout, int64_t M) {
+  const int64_t total = M * Cout;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t m = i / Cout;
+    const int c = (int)(i - m * Cout);
+    y[i] = c < Cin ? x[m * ldx + c] : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int adnm_chancopy(const float* x, int64_t ldx, int64_t Cin, float* y, int64_t Cout, int64_t M, adnm_stream_t stream) {
+  ADNM_REQUIRE(x && y && M > 0 && Cin > 0 && Cout > 0 && ldx >= Cin && M * Cout < (1ll << 40), "chancopy: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  ADNM_PROF("chancopy", st, 4.0 * M * ((Cin < Cout ? Cin : Cout) + Cout));
+  chancopy_kernel<<<grid_for(M * Cout), kBlock, 0, st>>>(x, ldx, (int)Cin, y, (int)Cout, M);
+  ADNM_CHECK_LAUNCH("chancopy");
+  return ADNM_OK;
+}
+
 namespace {
 unsigned catmix_blocks(int64_t M, int64_t d) {
   const int64_t g = adnm_cdiv(M * (d / 4), kBlock);

@@ -25,7 +25,8 @@ struct AdnDims {
 };
 
 // kernel-order xBC channel -> reference xBC channel, and back
-__device__ __forceinline__ int adn_fwd_map(int ch, const AdnDims& d) {
+template <typename D>
+__device__ __forceinline__ int adn_fwd_map(int ch, const D& d) {
   const int half = d.gn >> 1;
   if (ch < d.di) {
     const int h = ch / d.P, p = ch - h * d.P;
@@ -36,7 +37,8 @@ __device__ __forceinline__ int adn_fwd_map(int ch, const AdnDims& d) {
   const int e = q / half, n = q - e * half;
   return base + 2 * n + e;
 }
-__device__ __forceinline__ int adn_inv_map(int co, const AdnDims& d) {
+template <typename D>
+__device__ __forceinline__ int adn_inv_map(int co, const D& d) {
   const int half = d.gn >> 1;
   if (co < d.di) {
     const int e = co & 1, m = co >> 1, j = m / d.P, p = m - j * d.P;
@@ -55,7 +57,8 @@ struct AdnPrepped {     // kernel-layout tensors (or their gradients)
 };
 
 // chain of reference xBC channel `co` (odd): which (c31,c13) pair and which row
-__device__ __forceinline__ void adn_chain_of(int co, const AdnDims& d, int& chain, int& row) {
+template <typename D>
+__device__ __forceinline__ void adn_chain_of(int co, const D& d, int& chain, int& row) {
   const int o = (co - 1) >> 1;          // index in the odd part O
   const int i = o >> 1;                 // index in Oe / Oo
   const int nx = d.di >> 2;
@@ -66,11 +69,14 @@ __device__ __forceinline__ void adn_chain_of(int co, const AdnDims& d, int& chai
 
 // The two big matrices (in_proj.weight: a ROW permutation; out_proj.weight: a column permutation of its first half, scaled by alpha1 —
 // 19 + 17 MB at the deepest mixer) move as float4s, one quad per work item; the small tap / norm tensors one element per work item.
-__global__ __launch_bounds__(kBlock) void adn_prep_fwd_kernel(AdnParams p, AdnPrepped o, AdnDims d) {
+// (bid, nblk): this workgroup's index and the workgroup count of ITS mixer — the whole grid for the single-mixer launch, a block range
+// of the grouped launch (adnm_adnprep_*_multi: every mixer of a model stage in one launch)
+template <typename P, typename O, typename D>
+__device__ __forceinline__ void adn_prep_fwd_body(const P& p, const O& o, const D& d, int bid, int nblk) {
   const int cx = d.di + 2 * d.gn, dinp = 2 * d.di + 2 * d.gn + d.nh, dm4 = d.dm >> 2, oq = d.di >> 1;   // oq: quads per out_proj row (2 di / 4)
   const int64_t n0 = (int64_t)dinp * dm4, n1 = n0 + 9 * cx, n2 = n1 + 9 * d.di, n3 = n2 + 2 * d.di, n4 = n3 + (int64_t)d.dm * oq;
   const float a1 = *p.alpha1;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+  for (int64_t i = (int64_t)bid * kBlock + threadIdx.x; i < n4; i += (int64_t)nblk * kBlock) {
     if (i < n0) {
       const int r = (int)(i / dm4), c = (int)(i - (int64_t)r * dm4) * 4;
       int src = r;
@@ -105,10 +111,12 @@ __global__ __launch_bounds__(kBlock) void adn_prep_fwd_kernel(AdnParams p, AdnPr
     }
   }
 }
+__global__ __launch_bounds__(kBlock) void adn_prep_fwd_kernel(AdnParams p, AdnPrepped o, AdnDims d) { adn_prep_fwd_body(p, o, d, blockIdx.x, gridDim.x); }
 
 // thread per reference-parameter element: gathers its gradient from the prepped gradients.  part[blockIdx.x] =
 // this block's share of d alpha1 = sum g_w_out * out_proj.weight(permuted).
-__global__ __launch_bounds__(kBlock) void adn_prep_bwd_kernel(AdnParams p, AdnPrepped g, AdnParams dp, AdnDims d, float* __restrict__ part) {
+template <typename P, typename G, typename D>
+__device__ __forceinline__ void adn_prep_bwd_body(const P& p, const G& g, const P& dp, const D& d, float* __restrict__ part, int bid, int nblk) {
   __shared__ float sm[kBlock / 64];
   const int cx = d.di + 2 * d.gn, dinp = 2 * d.di + 2 * d.gn + d.nh, ce = cx >> 1, nx = d.di >> 2, nbc = d.gn >> 1;
   const int nchain = 2 * (nx + nbc) * 3;  // per kind (c31 / c13): x1,bc1,x2,bc2 rows x 3 taps
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void adn_prep_bwd_kernel(AdnParams p, AdnPr
                 n5 = n4 + (int64_t)d.dm * oq;
   const float a1 = *p.alpha1;
   float acc = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n5; i += (int64_t)gridDim.x * kBlock) {
+  for (int64_t i = (int64_t)bid * kBlock + threadIdx.x; i < n5; i += (int64_t)nblk * kBlock) {
     if (i < n0) {
       const int r = (int)(i / dm4), c = (int)(i - (int64_t)r * dm4) * 4;
       int src = r;
@@ -172,7 +180,45 @@ __global__ __launch_bounds__(kBlock) void adn_prep_bwd_kernel(AdnParams p, AdnPr
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  if (threadIdx.x == 0) part[bid] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+__global__ __launch_bounds__(kBlock) void adn_prep_bwd_kernel(AdnParams p, AdnPrepped g, AdnParams dp, AdnDims d, float* __restrict__ part) {
+  adn_prep_bwd_body(p, g, dp, d, part, blockIdx.x, gridDim.x);
+}
+
+// Grouped launches: up to kMaxMulti mixers per launch, descriptors by value in the kernel argument segment (read through the constant
+// address space: the descriptor index is a run-time, workgroup-uniform value).
+constexpr int kMaxMulti = 8;
+struct MultiAdnFwd {
+  int count, blk_end[kMaxMulti];
+  AdnParams p[kMaxMulti];
+  AdnPrepped o[kMaxMulti];
+  AdnDims d[kMaxMulti];
+};
+struct MultiAdnBwd {
+  int count, blk_end[kMaxMulti];
+  AdnParams p[kMaxMulti];
+  AdnPrepped g[kMaxMulti];
+  AdnParams dp[kMaxMulti];
+  AdnDims d[kMaxMulti];
+  float* part[kMaxMulti];
+};
+#define ADNM_KERNARG(T) (*(const __attribute__((address_space(4))) T*)__builtin_amdgcn_kernarg_segment_ptr())
+__global__ __launch_bounds__(kBlock) void adn_prep_fwd_multi_kernel(MultiAdnFwd by_value) {
+  (void)by_value;
+  const auto& m = ADNM_KERNARG(MultiAdnFwd);
+  int k = 0;
+  while (k + 1 < m.count && (int)blockIdx.x >= m.blk_end[k]) ++k;
+  const int b0 = k ? m.blk_end[k - 1] : 0;
+  adn_prep_fwd_body(m.p[k], m.o[k], m.d[k], (int)blockIdx.x - b0, m.blk_end[k] - b0);
+}
+__global__ __launch_bounds__(kBlock) void adn_prep_bwd_multi_kernel(MultiAdnBwd by_value) {
+  (void)by_value;
+  const auto& m = ADNM_KERNARG(MultiAdnBwd);
+  int k = 0;
+  while (k + 1 < m.count && (int)blockIdx.x >= m.blk_end[k]) ++k;
+  const int b0 = k ? m.blk_end[k - 1] : 0;
+  adn_prep_bwd_body(m.p[k], m.g[k], m.dp[k], m.d[k], m.part[k], (int)blockIdx.x - b0, m.blk_end[k] - b0);
 }
 
 // ------------------------------------------------------------------------------------------------ WTConv2d
@@ -183,12 +229,12 @@ struct WtPtrs {
   float *bias, *bias_t;
 };
 
-template <int KK>
-__global__ __launch_bounds__(kBlock) void wt_prep_fwd_kernel(WtPtrs p, int C, int Cp, int levels) {
+template <int KK, typename P>
+__device__ __forceinline__ void wt_prep_fwd_body(const P& p, int C, int Cp, int levels, int bid, int nblk) {
   // one thread per (group, padded channel): writes its K*K taps
   const int per0 = Cp, perl = 4 * Cp;
   const int total = per0 + levels * perl;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+  for (int i = bid * kBlock + threadIdx.x; i < total; i += nblk * kBlock) {
     int g = 0, c = i;
     if (i >= per0) { g = 1 + (i - per0) / perl; c = (i - per0) % perl; }
     const int cg = g == 0 ? C : 4 * C, cgp = g == 0 ? Cp : 4 * Cp;
@@ -203,14 +249,17 @@ __global__ __launch_bounds__(kBlock) void wt_prep_fwd_kernel(WtPtrs p, int C, in
   }
 }
 
+template <int KK>
+__global__ __launch_bounds__(kBlock) void wt_prep_fwd_kernel(WtPtrs p, int C, int Cp, int levels) { wt_prep_fwd_body<KK>(p, C, Cp, levels, blockIdx.x, gridDim.x); }
+
 // g: gradients of the tap-major tensors (same struct, fields t / bias_t); d: gradients of the parameters (w, s, bias)
 // KK is a template parameter so that the tap loop unrolls: all K*K gradient / weight loads of a channel are in flight together
 // (as a runtime loop of dependent load -> store pairs this took 15 us for ~400 channels)
-template <int KK>
-__global__ __launch_bounds__(kBlock) void wt_prep_bwd_kernel(WtPtrs p, WtPtrs g, WtPtrs d, int C, int Cp, int levels) {
+template <int KK, typename P>
+__device__ __forceinline__ void wt_prep_bwd_body(const P& p, const P& g, const P& d, int C, int Cp, int levels, int bid, int nblk) {
   const int per0 = C, perl = 4 * C;
   const int total = per0 + levels * perl;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+  for (int i = bid * kBlock + threadIdx.x; i < total; i += nblk * kBlock) {
     int gi = 0, c = i;
     if (i >= per0) { gi = 1 + (i - per0) / perl; c = (i - per0) % perl; }
     const int cgp = gi == 0 ? Cp : 4 * Cp;
@@ -234,6 +283,44 @@ __global__ __launch_bounds__(kBlock) void wt_prep_bwd_kernel(WtPtrs p, WtPtrs g,
     }
     d.s[gi][c] = ds;
   }
+}
+
+template <int KK>
+__global__ __launch_bounds__(kBlock) void wt_prep_bwd_kernel(WtPtrs p, WtPtrs g, WtPtrs d, int C, int Cp, int levels) {
+  wt_prep_bwd_body<KK>(p, g, d, C, Cp, levels, blockIdx.x, gridDim.x);
+}
+
+// grouped launches of the WTConv2d preparation (every WTConv2d of a model stage in one launch); K is per descriptor (3 or 5)
+struct WtDims {
+  int C, Cp, K, levels;
+};
+struct MultiWtFwd {
+  int count, blk_end[kMaxMulti];
+  WtPtrs p[kMaxMulti];
+  WtDims d[kMaxMulti];
+};
+struct MultiWtBwd {
+  int count, blk_end[kMaxMulti];
+  WtPtrs p[kMaxMulti], g[kMaxMulti], dp[kMaxMulti];
+  WtDims d[kMaxMulti];
+};
+__global__ __launch_bounds__(kBlock) void wt_prep_fwd_multi_kernel(MultiWtFwd by_value) {
+  (void)by_value;
+  const auto& m = ADNM_KERNARG(MultiWtFwd);
+  int k = 0;
+  while (k + 1 < m.count && (int)blockIdx.x >= m.blk_end[k]) ++k;
+  const int b0 = k ? m.blk_end[k - 1] : 0, bid = (int)blockIdx.x - b0, nblk = m.blk_end[k] - b0;
+  if (m.d[k].K == 3) wt_prep_fwd_body<9>(m.p[k], m.d[k].C, m.d[k].Cp, m.d[k].levels, bid, nblk);
+  else wt_prep_fwd_body<25>(m.p[k], m.d[k].C, m.d[k].Cp, m.d[k].levels, bid, nblk);
+}
+__global__ __launch_bounds__(kBlock) void wt_prep_bwd_multi_kernel(MultiWtBwd by_value) {
+  (void)by_value;
+  const auto& m = ADNM_KERNARG(MultiWtBwd);
+  int k = 0;
+  while (k + 1 < m.count && (int)blockIdx.x >= m.blk_end[k]) ++k;
+  const int b0 = k ? m.blk_end[k - 1] : 0, bid = (int)blockIdx.x - b0, nblk = m.blk_end[k] - b0;
+  if (m.d[k].K == 3) wt_prep_bwd_body<9>(m.p[k], m.g[k], m.dp[k], m.d[k].C, m.d[k].Cp, m.d[k].levels, bid, nblk);
+  else wt_prep_bwd_body<25>(m.p[k], m.g[k], m.dp[k], m.d[k].C, m.d[k].Cp, m.d[k].levels, bid, nblk);
 }
 
 int adn_check(const char* who, AdnDims d) {
@@ -353,5 +440,158 @@ extern "C" int adnm_wtprep_bwd(float* const* w, float* const* s, float* bias, fl
     else wt_prep_bwd_kernel<25><<<grid_for(total), kBlock, 0, st>>>(pp, gp, dp, (int)C, (int)Cp, (int)levels);
   }
   ADNM_CHECK_LAUNCH("wtprep_bwd");
+  return ADNM_OK;
+}
+
+
+// ---- grouped forms: every ADN-SSD mixer / every WTConv2d of a model stage in ONE launch each way (the per-module launches above are a
+// few microseconds of work each: 36 launches per step at config 2).  Tables are concatenated per module: params[15 * i ..], prepped[6 * i ..],
+// dims[5 * i ..] = {d_model, d_inner, gn, headdim, tap_ld}; at most 8 modules per launch (longer lists are cut into several launches).
+namespace {
+AdnDims adn_dims(const int64_t* v) {
+  const int64_t tap_ld = v[4];
+  return AdnDims{(int)v[0], (int)v[1], (int)v[2], (int)v[3], (int)(v[1] / (v[3] > 0 ? v[3] : 1)), (int)(tap_ld ? tap_ld : v[1] + 2 * v[2]),
+                 (int)(tap_ld ? tap_ld : v[1])};
+}
+int64_t adn_items_fwd(const AdnDims& d) {
+  return (int64_t)(2 * d.di + 2 * d.gn + d.nh) * d.dm + 9 * (d.di + 2 * d.gn) + 9 * d.di + 2 * d.di + (int64_t)d.dm * 2 * d.di;
+}
+int64_t adn_items_bwd(const AdnDims& d) {
+  const int cx = d.di + 2 * d.gn;
+  return (int64_t)(2 * d.di + 2 * d.gn + d.nh) * d.dm + (int64_t)(cx / 2) * 9 + 2 * 2 * (d.di / 4 + d.gn / 2) * 3 + 9 * d.di + 2 * d.di + (int64_t)d.dm * 2 * d.di;
+}
+// workgroups of one module inside a grouped launch: enough to stream its matrices, capped so that 8 modules stay a sane grid
+unsigned multi_blocks(int64_t items) {
+  int64_t g = adnm_cdiv(items / 4 + 1, kBlock);   // the big matrices move as float4 quads
+  return (unsigned)(g < 1 ? 1 : (g > 512 ? 512 : g));
+}
+}  // namespace
+
+extern "C" int adnm_adnprep_fwd_multi(int64_t n, float* const* params, float* const* prepped, const int64_t* dims, adnm_stream_t stream) {
+  ADNM_REQUIRE(n >= 1 && params && prepped && dims, "adnprep_fwd_multi: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  for (int64_t i0 = 0; i0 < n; i0 += kMaxMulti) {
+    MultiAdnFwd m;
+    m.count = (int)(n - i0 < kMaxMulti ? n - i0 : kMaxMulti);
+    int blocks = 0;
+    double bytes = 0;
+    for (int k = 0; k < m.count; ++k) {
+      const int64_t i = i0 + k;
+      for (int j = 0; j < 15; ++j) ADNM_REQUIRE(params[15 * i + j], "adnprep_fwd_multi: params[%lld][%d] is null", (long long)i, j);
+      for (int j = 0; j < 6; ++j) ADNM_REQUIRE(prepped[6 * i + j], "adnprep_fwd_multi: prepped[%lld][%d] is null", (long long)i, j);
+      m.p[k] = adn_params(params + 15 * i), m.o[k] = adn_prepped(prepped + 6 * i), m.d[k] = adn_dims(dims + 5 * i);
+      if (int rc = adn_check("adnprep_fwd_multi", m.d[k])) return rc;
+      blocks += (int)multi_blocks(adn_items_fwd(m.d[k]));
+      m.blk_end[k] = blocks;
+      bytes += 8.0 * adn_items_fwd(m.d[k]);
+    }
+    for (int k = m.count; k < kMaxMulti; ++k) m.blk_end[k] = blocks;
+    ADNM_PROF("adn_prep_fwd", st, bytes);
+    adn_prep_fwd_multi_kernel<<<(unsigned)blocks, kBlock, 0, st>>>(m);
+  }
+  ADNM_CHECK_LAUNCH("adnprep_fwd_multi");
+  return ADNM_OK;
+}
+
+extern "C" int64_t adnm_adnprep_bwd_multi_ws_bytes(int64_t n) { return n * 512 * (int64_t)sizeof(float); }
+
+extern "C" int adnm_adnprep_bwd_multi(int64_t n, float* const* params, float* const* gprepped, float* const* dparams, const int64_t* dims,
+                                      void* ws, int64_t ws_bytes, adnm_stream_t stream) {
+  ADNM_REQUIRE(n >= 1 && params && gprepped && dparams && dims, "adnprep_bwd_multi: bad arguments");
+  if (!ws || ws_bytes < adnm_adnprep_bwd_multi_ws_bytes(n)) {
+    adnm_set_error("adnprep_bwd_multi: workspace too small");
+    return ADNM_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  for (int64_t i0 = 0; i0 < n; i0 += kMaxMulti) {
+    MultiAdnBwd m;
+    m.count = (int)(n - i0 < kMaxMulti ? n - i0 : kMaxMulti);
+    int blocks = 0, nb[kMaxMulti];
+    double bytes = 0;
+    for (int k = 0; k < m.count; ++k) {
+      const int64_t i = i0 + k;
+      for (int j = 0; j < 15; ++j) ADNM_REQUIRE(params[15 * i + j] && dparams[15 * i + j], "adnprep_bwd_multi: params/dparams[%lld][%d] is null", (long long)i, j);
+      for (int j = 0; j < 6; ++j) ADNM_REQUIRE(gprepped[6 * i + j], "adnprep_bwd_multi: gprepped[%lld][%d] is null", (long long)i, j);
+      m.p[k] = adn_params(params + 15 * i), m.g[k] = adn_prepped(gprepped + 6 * i), m.dp[k] = adn_params(dparams + 15 * i), m.d[k] = adn_dims(dims + 5 * i);
+      if (int rc = adn_check("adnprep_bwd_multi", m.d[k])) return rc;
+      m.part[k] = (float*)ws + 512 * i;
+      nb[k] = (int)multi_blocks(adn_items_bwd(m.d[k]));
+      blocks += nb[k];
+      m.blk_end[k] = blocks;
+      bytes += 8.0 * adn_items_bwd(m.d[k]);
+    }
+    for (int k = m.count; k < kMaxMulti; ++k) m.blk_end[k] = blocks;
+    {
+      ADNM_PROF("adn_prep_bwd", st, bytes);
+      adn_prep_bwd_multi_kernel<<<(unsigned)blocks, kBlock, 0, st>>>(m);
+    }
+    for (int k = 0; k < m.count; ++k)
+      adnm_launch_fold("adn_prep_bwd_fold", m.part[k], nb[k], 1, {dparams[15 * (i0 + k) + 14], 1}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
+  }
+  ADNM_CHECK_LAUNCH("adnprep_bwd_multi");
+  return ADNM_OK;
+}
+
+// WTConv2d, grouped.  Tables per module i: w[5 i ..], s[5 i ..], taps[5 i ..] (entries 0 .. levels used), bias[i], bias_t[i] (both NULL or both
+// set), dims[4 i ..] = {C, Cp, K, levels}.
+extern "C" int adnm_wtprep_fwd_multi(int64_t n, float* const* w, float* const* s, float* const* bias, float* const* taps, float* const* bias_t,
+                                     const int64_t* dims, adnm_stream_t stream) {
+  ADNM_REQUIRE(n >= 1 && w && s && bias && taps && bias_t && dims, "wtprep_fwd_multi: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  for (int64_t i0 = 0; i0 < n; i0 += kMaxMulti) {
+    MultiWtFwd m;
+    m.count = (int)(n - i0 < kMaxMulti ? n - i0 : kMaxMulti);
+    int blocks = 0;
+    double bytes = 0;
+    for (int k = 0; k < m.count; ++k) {
+      const int64_t i = i0 + k, C = dims[4 * i], Cp = dims[4 * i + 1], K = dims[4 * i + 2], levels = dims[4 * i + 3];
+      ADNM_REQUIRE(C > 0 && Cp >= C && Cp % 4 == 0 && levels >= 0 && levels <= 4 && (K == 3 || K == 5) && (!bias[i] == !bias_t[i]),
+                   "wtprep_fwd_multi: bad arguments for module %lld (C=%lld Cp=%lld K=%lld levels=%lld)", (long long)i, (long long)C, (long long)Cp,
+                   (long long)K, (long long)levels);
+      for (int j = 0; j <= levels; ++j) ADNM_REQUIRE(w[5 * i + j] && s[5 * i + j] && taps[5 * i + j], "wtprep_fwd_multi: table entry %lld/%d is null", (long long)i, j);
+      m.p[k] = wt_ptrs(w + 5 * i, s + 5 * i, taps + 5 * i, bias[i], bias_t[i], (int)levels);
+      m.d[k] = WtDims{(int)C, (int)Cp, (int)K, (int)levels};
+      const int total = (int)(Cp + levels * 4 * Cp);
+      blocks += (int)grid_for(total);
+      m.blk_end[k] = blocks;
+      bytes += 8.0 * total * K * K;
+    }
+    for (int k = m.count; k < kMaxMulti; ++k) m.blk_end[k] = blocks;
+    ADNM_PROF("wt_prep_fwd", st, bytes);
+    wt_prep_fwd_multi_kernel<<<(unsigned)blocks, kBlock, 0, st>>>(m);
+  }
+  ADNM_CHECK_LAUNCH("wtprep_fwd_multi");
+  return ADNM_OK;
+}
+
+extern "C" int adnm_wtprep_bwd_multi(int64_t n, float* const* w, float* const* s, float* const* bias, float* const* gtaps, float* const* gbias_t,
+                                     float* const* dw, float* const* ds, float* const* dbias, const int64_t* dims, adnm_stream_t stream) {
+  ADNM_REQUIRE(n >= 1 && w && s && bias && gtaps && gbias_t && dw && ds && dbias && dims, "wtprep_bwd_multi: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  for (int64_t i0 = 0; i0 < n; i0 += kMaxMulti) {
+    MultiWtBwd m;
+    m.count = (int)(n - i0 < kMaxMulti ? n - i0 : kMaxMulti);
+    int blocks = 0;
+    double bytes = 0;
+    for (int k = 0; k < m.count; ++k) {
+      const int64_t i = i0 + k, C = dims[4 * i], Cp = dims[4 * i + 1], K = dims[4 * i + 2], levels = dims[4 * i + 3];
+      ADNM_REQUIRE(C > 0 && Cp >= C && levels >= 0 && levels <= 4 && (K == 3 || K == 5), "wtprep_bwd_multi: bad arguments for module %lld", (long long)i);
+      ADNM_REQUIRE((!bias[i] == !gbias_t[i]) && (!bias[i] == !dbias[i]), "wtprep_bwd_multi: bias pointers of module %lld must be all set or all null", (long long)i);
+      for (int j = 0; j <= levels; ++j)
+        ADNM_REQUIRE(w[5 * i + j] && s[5 * i + j] && gtaps[5 * i + j] && dw[5 * i + j] && ds[5 * i + j], "wtprep_bwd_multi: table entry %lld/%d is null", (long long)i, j);
+      m.p[k] = wt_ptrs(w + 5 * i, s + 5 * i, nullptr, bias[i], nullptr, (int)levels);
+      m.g[k] = wt_ptrs(nullptr, nullptr, gtaps + 5 * i, nullptr, gbias_t[i], (int)levels);
+      m.dp[k] = wt_ptrs(dw + 5 * i, ds + 5 * i, nullptr, dbias[i], nullptr, (int)levels);
+      m.d[k] = WtDims{(int)C, (int)Cp, (int)K, (int)levels};
+      const int total = (int)(C + levels * 4 * C);
+      blocks += (int)grid_for(total);
+      m.blk_end[k] = blocks;
+      bytes += 12.0 * total * K * K;
+    }
+    for (int k = m.count; k < kMaxMulti; ++k) m.blk_end[k] = blocks;
+    ADNM_PROF("wt_prep_bwd", st, bytes);
+    wt_prep_bwd_multi_kernel<<<(unsigned)blocks, kBlock, 0, st>>>(m);
+  }
+  ADNM_CHECK_LAUNCH("wtprep_bwd_multi");
   return ADNM_OK;
 }

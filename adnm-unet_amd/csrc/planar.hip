@@ -49,10 +49,12 @@ __global__ __launch_bounds__(kBlock) void haar_dwt_kernel(const T* __restrict__ 
   }
 }
 
-// s:(B,h,w,4C) (+ ll_add:(B,h,w,C) on the LL band) -> y:(B,H,W,C), cropped to H,W.
+// s:(B,h,w,4C) (+ ll_add:(B,h,w,C) on the LL band) -> y:(B,H,W,C), cropped to H,W.  ya / yb (optional, (B,H,W,C)): added to the result —
+// the last synthesis step of WTConv2d's backward sums its three input-gradient paths (wavelet pyramid, base conv, the tensor's other
+// consumer) in this one pass instead of two separate adds.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void haar_idwt_kernel(const T* __restrict__ s, const T* __restrict__ ll_add, T* __restrict__ y,
-                                                           int B, int H, int W, int C) {
+__global__ __launch_bounds__(kBlock) void haar_idwt_kernel(const T* __restrict__ s, const T* __restrict__ ll_add, const T* __restrict__ ya,
+                                                           const T* __restrict__ yb, T* __restrict__ y, int B, int H, int W, int C) {
   const int C4 = C >> 2, h2 = (H + 1) >> 1, w2 = (W + 1) >> 1;
   const int64_t total = (int64_t)B * h2 * w2 * C4;
   const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -81,8 +83,13 @@ __global__ __launch_bounds__(kBlock) void haar_idwt_kernel(const T* __restrict__
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int hh = 2 * i + (q >> 1), ww = 2 * j + (q & 1);
-    if (hh < H && ww < W)
-      Io<T>::st4(y + (((int64_t)b * H + hh) * W + ww) * C + cg * 4, make_float4(o[q][0], o[q][1], o[q][2], o[q][3]));
+    if (hh < H && ww < W) {
+      const int64_t at = (((int64_t)b * H + hh) * W + ww) * C + cg * 4;
+      float4 v = make_float4(o[q][0], o[q][1], o[q][2], o[q][3]);
+      if (ya) { const float4 a = Io<T>::ld4(ya + at); v.x += a.x, v.y += a.y, v.z += a.z, v.w += a.w; }
+      if (yb) { const float4 a = Io<T>::ld4(yb + at); v.x += a.x, v.y += a.y, v.z += a.z, v.w += a.w; }
+      Io<T>::st4(y + at, v);
+    }
   }
 }
 
@@ -470,18 +477,19 @@ extern "C" int adnm_haar_dwt(const void* x, int64_t ldx, int64_t cx, void* y, in
   return ADNM_OK;
 }
 
-extern "C" int adnm_haar_idwt(const void* s, const void* ll_add, void* y, int64_t B, int64_t H, int64_t W, int64_t C, int dtype,
-                              adnm_stream_t stream) {
+extern "C" int adnm_haar_idwt(const void* s, const void* ll_add, const void* y_add1, const void* y_add2, void* y, int64_t B, int64_t H, int64_t W,
+                              int64_t C, int dtype, adnm_stream_t stream) {
   ADNM_REQUIRE(s && y, "haar_idwt: null pointer");
   ADNM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "haar_idwt: bad shape (C=%lld must be a multiple of 4)", (long long)C);
   ADNM_REQUIRE(dtype == ADNM_F32 || dtype == ADNM_BF16, "haar_idwt: bad dtype %d", dtype);
   const int64_t total = B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
   const unsigned grid = (unsigned)adnm_cdiv(total, kBlock);
   hipStream_t st = (hipStream_t)stream;
+  const double units = (ll_add ? 2.25 : 2.0) + (y_add1 ? 1.0 : 0.0) + (y_add2 ? 1.0 : 0.0);
   if (dtype == ADNM_F32)
-    { ADNM_PROF("haar_idwt", st, 4.0 * B * H * W * C * (ll_add ? 2.25 : 2)); haar_idwt_kernel<float><<<grid, kBlock, 0, st>>>((const float*)s, (const float*)ll_add, (float*)y, (int)B, (int)H, (int)W, (int)C); }
+    { ADNM_PROF("haar_idwt", st, 4.0 * B * H * W * C * units); haar_idwt_kernel<float><<<grid, kBlock, 0, st>>>((const float*)s, (const float*)ll_add, (const float*)y_add1, (const float*)y_add2, (float*)y, (int)B, (int)H, (int)W, (int)C); }
   else
-    { ADNM_PROF("haar_idwt", st, 2.0 * B * H * W * C * (ll_add ? 2.25 : 2)); haar_idwt_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)s, (const uint16_t*)ll_add, (uint16_t*)y, (int)B, (int)H, (int)W, (int)C); }
+    { ADNM_PROF("haar_idwt", st, 2.0 * B * H * W * C * units); haar_idwt_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)s, (const uint16_t*)ll_add, (const uint16_t*)y_add1, (const uint16_t*)y_add2, (uint16_t*)y, (int)B, (int)H, (int)W, (int)C); }
   ADNM_CHECK_LAUNCH("haar_idwt");
   return ADNM_OK;
 }

@@ -330,10 +330,14 @@ class VisionMamba(nn.Module):
     # The same forward cut at the encoder / decoder boundary.  adnm_hip.trainer.FlatTrainer uses the cut for a two-stage
     # backward on multi-GPU runs: the decoder + refiner gradients are all-reduced over xGMI while the encoder's backward runs.
     def forward_stage1(self, x):
+        if x.is_cuda:
+            ops.prep_group(self.encoder)   # kernel-layout parameters of all its mixers / WTConv2ds: one launch per kind
         x, skips, res = self.encoder(x.squeeze(2))
         return (x, res, *skips)
 
     def forward_stage2(self, x, res, *skips):
+        if x.is_cuda:
+            ops.prep_group(self.decoder, self.refiner)
         return self.refiner(self.decoder(x, list(skips)), res).unsqueeze(2)
 
     def stage1_parameters(self):

@@ -140,6 +140,17 @@ class Mamba2(nn.Module):
         k_all = k_all.index_select(0, self._perm_xbc)
         return k_all.reshape(k_all.shape[0], 9).t().contiguous().float()
 
+    adnm_prep_kind = "adn"   # adnm_hip.ops.prep_group prepares every mixer of a model stage in one launch
+
+    def adnm_prep_ready(self):
+        return self.conv2d.bias is None and self.in_proj.bias is None and self.d_conv == 3 and not self.learnable_init_states
+
+    def adnm_prep_args(self):
+        return ((self.d_model, self.d_inner, self.ngroups * self.d_state, self.headdim),
+                [self.in_proj.weight, self.conv2d.weight, self.conv_31_x1.weight, self.conv_31_bc1.weight, self.conv_31_x2.weight,
+                 self.conv_31_bc2.weight, self.conv_13_x1.weight, self.conv_13_bc1.weight, self.conv_13_x2.weight, self.conv_13_bc2.weight,
+                 self.conv2d_z.weight, self.norm.weight, self.norm.bias, self.out_proj.weight, self.alpha1])
+
     def forward(self, u, H, W, seq_idx=None):
         """u: (B, L, d_model) tokens, L = H*W.  Returns the same shape (ADNssd.py:302-462 of the reference)."""
         scan_chunk = 0
@@ -153,12 +164,13 @@ class Mamba2(nn.Module):
             raise NotImplementedError("ADN-SSD HIP path covers the reference configuration: conv_bias=False, bias=False, d_conv=3")
         if self.learnable_init_states:
             raise NotImplementedError("learnable_init_states is only meaningful on the chunked-scan branch")
-        # one HIP launch builds the kernel-layout tensors (csrc/paramprep.hip); _effective_taps()/_rows_in state the same map in torch
-        w_in, taps, ln_w, ln_b, w_out = ops.adn_prep(
-            self.d_model, self.d_inner, self.ngroups * self.d_state, self.headdim,
-            [self.in_proj.weight, self.conv2d.weight, self.conv_31_x1.weight, self.conv_31_bc1.weight, self.conv_31_x2.weight,
-             self.conv_31_bc2.weight, self.conv_13_x1.weight, self.conv_13_bc1.weight, self.conv_13_x2.weight, self.conv_13_bc2.weight,
-             self.conv2d_z.weight, self.norm.weight, self.norm.bias, self.out_proj.weight, self.alpha1])
+        # the kernel-layout tensors (csrc/paramprep.hip; _effective_taps()/_rows_in state the same map in torch): prepared for the whole model
+        # stage in one launch by ops.prep_group (VisionMamba.forward_stage*), or here for this module alone
+        pre = self.__dict__.pop("_adnm_prepped", None)
+        if pre is None:
+            dims, params = self.adnm_prep_args()
+            pre = ops.adn_prep(*dims, params)
+        w_in, taps, ln_w, ln_b, w_out = pre
         return ops.adn_mixer(u, w_in, taps, None, self.dt_bias, self.A_log, self.D, ln_w, ln_b, w_out, H, W,
                              self.headdim, self.ngroups * self.d_state // 2, scan_chunk, self.ngroups,
                              qkeys=(self.in_proj.weight.data_ptr(), self.out_proj.weight.data_ptr()))

@@ -182,8 +182,8 @@ class Conv2dLayer(nn.Module):
 
     def forward_tokens(self, x, h, w):
         """(B, H*W, Cin) -> (B, H*W, Cout) (stride-1 'same' convs only)."""
-        if self.dropout:
-            x = tokens_of(self.dropout(nchw_view(x, h, w)))
+        if self.dropout and self.training:
+            raise RuntimeError("Conv2dLayer: Dropout2d has no HIP kernel (the reference configuration uses dropout=0; no PyTorch fallback)")
         code = _act_code(self.act)
         fused_act = False
         if self._is_depthwise_same() and not self.norm and code is not None:
@@ -243,10 +243,17 @@ class WTConvLayer(nn.Module):
             self.scale = nn.Parameter(torch.tensor(1.))
             self.shift = nn.Parameter(torch.tensor(0.))
 
-    def forward_tokens(self, x, h, w):
+    def forward_tokens(self, x, h, w, tap=False):
+        """tap=True: -> (y, alias of x): hand the alias to x's other consumer (the residual mix); its gradient is then added inside the
+        wavelet conv's last backward kernel instead of by a separate autograd add (ops.WTConvFn)."""
         if self.dropout:
-            x = tokens_of(self.dropout(nchw_view(x, h, w)))
-        x = self.conv.forward_tokens(x, h, w)
+            if self.training:
+                raise RuntimeError("WTConvLayer: Dropout2d has no HIP kernel (the reference configuration uses dropout=0; no PyTorch fallback)")
+        alias = None
+        if tap:
+            x, alias = self.conv.forward_tokens(x, h, w, tap=True)
+        else:
+            x = self.conv.forward_tokens(x, h, w)
         code = _act_code(self.act)
         fused = False
         if self.norm:
@@ -259,7 +266,7 @@ class WTConvLayer(nn.Module):
                                    "(affine-less InstanceNorm2d [+ GELU] on a multiple of 4 channels is implemented; no PyTorch fallback)")
         if self.act and not fused:
             x = _apply_act(self.act, x)
-        return x
+        return (x, alias) if tap else x
 
     def forward(self, x):
         b, c, h, w = x.shape
@@ -370,7 +377,8 @@ class PatchEmbed(nn.Module):
         res = x[..., -1].reshape(b, h, w)
         x = ops.lincomb([self.conv1[0].forward_tokens(x, h, w).contiguous(), x.contiguous()], [self.alpha1, self.beta1])
         shortcut = self.conv2[0].forward_tokens(x, h, w)
-        x = ops.lincomb([self.conv3[0].forward_tokens(shortcut, h, w), shortcut], [self.alpha2, self.beta2], self.gamma)
+        y, shortcut = self.conv3[0].forward_tokens(shortcut, h, w, tap=True)
+        x = ops.lincomb([y, shortcut], [self.alpha2, self.beta2], self.gamma)
         return x, res
 
 
@@ -401,7 +409,8 @@ class WTLayer(nn.Module):
             x = ops.lincomb([x, features], [None, self.gama3])
         b, l, d = x.shape
         h, w = _hw(l)
-        x = ops.lincomb([self.wtconv.forward_tokens(x, h, w), x], [self.alpha, self.beta])
+        y, x = self.wtconv.forward_tokens(x, h, w, tap=True)
+        x = ops.lincomb([y, x], [self.alpha, self.beta])
         x = self.mlp(x)
         if self.gamma is not None:
             x = ops.lincomb([x], [None], self.gamma)
@@ -478,13 +487,11 @@ class Channel_Att_Bridge(nn.Module):
             alias_out[:] = [a for a, _ in taps]
         att = torch.cat([m for _, m in taps], dim=-1).unsqueeze(1)  # (B,1,sum C)
         att = ops.conv1d3(att, self.get_all_att.weight, self.get_all_att.bias)
-        out = {}
-        for i in range(7):
-            if live is not None and i not in live:
-                continue
-            lin = getattr(self, f"att{i + 1}")
-            out[i] = self.sigmoid1(ops.linear(att, lin.weight, lin.bias))
-        return out
+        idx = [i for i in range(7) if live is None or i in live]
+        lins = [getattr(self, f"att{i + 1}") for i in idx]
+        # every live head = Linear + IntensityGate, all in ONE launch each way (csrc/bridge.hip)
+        gates = ops.bridge_heads(att, self.sigmoid1.enhance, self.sigmoid1.threshold, [l.weight for l in lins], [l.bias for l in lins])
+        return dict(zip(idx, gates))
 
 
 class EncoderToDecoder(nn.Module):
@@ -568,7 +575,8 @@ class OutProj(nn.Module):
         """x: (B, L, d) tokens, residual: last input frame (B, H, W) -> (B, T_out, H, W) (model_untils.py:871-892)."""
         h, w = self.img_size[0], self.img_size[1]
         b, l, d = x.shape
-        x = ops.lincomb([self.wtconv.forward_tokens(x, h, w), x], [self.alpha, self.beta], self.gamma)
+        y, x = self.wtconv.forward_tokens(x, h, w, tap=True)
+        x = ops.lincomb([y, x], [self.alpha, self.beta], self.gamma)
         x = self.conv[0].forward_tokens(x, h, w)
         x = self.conv[1].forward_tokens(x, h, w)
         if residual is not None:   # the last input frame, broadcast over the T_out channels (model_untils.py:886-888)

@@ -81,6 +81,11 @@ int adnm_foldq_bind(void* q); /* NULL unbinds */
 int64_t adnm_foldq_pending(void* q);
 int adnm_foldq_flush(void* q, adnm_stream_t stream);
 int adnm_foldq_clear(void* q); /* drop the queued folds without launching them (error path of the caller) */
+/* The NEXT fold queued on this thread adds to its destination segment q (instead of overwriting it) for every bit q of mask: a parameter
+ * used by two autograd nodes (Block's beta1 / beta2 feed both residual mixes, ADNMUNet.py:152,158) gets the second node's contribution
+ * added by the fold itself — flushes launch the overwriting folds first — instead of by a separate autograd add per node.  Only
+ * meaningful while a queue is bound (ignored otherwise: an immediate fold always overwrites). */
+int adnm_foldq_accumulate_next(int mask);
 
 /* ---------------------------------------------------------------- row norms (K2, K7)
  * y = scale * ( xhat * w + b ) + shift,  xhat = (x - mu) * rstd
@@ -190,8 +195,10 @@ int adnm_dwconv_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, fl
  * The butterfly is its own transpose, so dwt's backward is idwt and vice versa. */
 int adnm_haar_dwt(const void* x, int64_t ldx, int64_t cx, void* y, int64_t B, int64_t H, int64_t W, int64_t C,
                   int dtype, adnm_stream_t stream);
-int adnm_haar_idwt(const void* s, const void* ll_add, void* y, int64_t B, int64_t H, int64_t W, int64_t C,
-                   int dtype, adnm_stream_t stream);
+/* y_add1 / y_add2 (optional, (B,H,W,C) like y): added to the result in the same pass — WTConv2d's backward sums its input-gradient
+ * paths (pyramid + base conv + the input's other consumer) there instead of in separate adds. */
+int adnm_haar_idwt(const void* s, const void* ll_add, const void* y_add1, const void* y_add2, void* y, int64_t B, int64_t H,
+                   int64_t W, int64_t C, int dtype, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- max pooling, NHWC (K11)
  * nn.MaxPool2d on tokens: stride == kernel in [2,4] (DownSample, model_untils.py:472-487; floor mode) or stride 1 with
@@ -285,8 +292,26 @@ int adnm_attn4_bwd(const float* dout, const float* qkv, const float* out, const 
 int64_t adnm_tokmean_ws_bytes(int64_t B, int64_t L, int64_t C);
 int adnm_tokmean_fwd(const float* x, float* mean, void* ws, int64_t ws_bytes, int64_t B, int64_t L, int64_t C, adnm_stream_t stream);
 int adnm_tokmean_bwd(const float* dxa, const float* dmean, int64_t ldm, float* dx, int64_t B, int64_t L, int64_t C, adnm_stream_t stream);
+/* Channel pad / crop of a token matrix (row stride ldx): y[m, c] = x[m, c] for c < min(Cin, Cout), 0 for Cin <= c < Cout; y:(M, Cout)
+ * contiguous.  The 5-frame input stage (PatchEmbed.conv1: WTConv2d on 5 channels, model_untils.py:259) runs on 8 channels; pad and crop
+ * are each other's backward. */
+int adnm_chancopy(const float* x, int64_t ldx, int64_t Cin, float* y, int64_t Cout, int64_t M, adnm_stream_t stream);
 int adnm_conv1d3_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t n, adnm_stream_t stream);
 int adnm_conv1d3_bwd(const float* dy, const float* x, const float* w, float* dx, float* dwb, int64_t B, int64_t n, adnm_stream_t stream);
+/* The heads of Channel_Att_Bridge, grouped (model_untils.py:744-750 the seven nn.Linear(sum C, C_i), :594-613 sigmoid1 = IntensityGate):
+ *   z_i[b, :] = att[b, :] . W_i^T + bias_i,   gate_i = silu(enhance * (z_i - threshold)),   att:(B, S) fp32 contiguous, W_i:(C_i, S).
+ * W / bias / z / y / dy / dW / dbias: HOST arrays of nheads device pointers; C: HOST array of the head widths.  1 <= B <= 8, 4 | S <= 3072.
+ * One forward launch for all heads (a wave per output feature); backward = one launch (weight-gradient rows written as they are formed,
+ * dbias, per-workgroup partials of datt / denhance / dthreshold) + one fold that is never deferred (datt is read next).
+ * All outputs OVERWRITTEN; dbias may be NULL (or hold NULL entries). */
+int adnm_bridge_heads_fwd(const float* att, const float* const* W, const float* const* bias, const int64_t* C, int nheads,
+                          const float* enhance, const float* threshold, float* const* z, float* const* y, int64_t B, int64_t S,
+                          adnm_stream_t stream);
+int64_t adnm_bridge_heads_bwd_ws_bytes(int64_t total, int64_t B, int64_t S);
+int adnm_bridge_heads_bwd(const float* att, const float* const* W, const int64_t* C, int nheads, const float* enhance,
+                          const float* threshold, const float* const* z, const float* const* dy, float* datt, float* const* dW,
+                          float* const* dbias, float* denhance, float* dthreshold, void* ws, int64_t ws_bytes, int64_t B, int64_t S,
+                          adnm_stream_t stream);
 
 /* out[c] = sum_r x[r*n + c] for a contiguous (rows, n) fp32 matrix — nn.Linear's bias gradient (autograd's sum over the token
  * rows) when the weight gradient is computed elsewhere (the transposed conv's).  Deterministic (fixed tree), OVERWRITES out; matrices
@@ -462,6 +487,20 @@ int adnm_wtprep_fwd(float* const* w, float* const* s, float* bias, float* const*
 int adnm_wtprep_bwd(float* const* w, float* const* s, float* bias, float* const* gtaps, float* gbias_t,
                     float* const* dw, float* const* ds, float* dbias, int64_t C, int64_t Cp, int64_t K, int64_t levels,
                     adnm_stream_t stream);
+/* Grouped forms: every ADN-SSD mixer / every WTConv2d of a model stage in ONE launch each way (36 per-module launches of a few
+ * microseconds each at config 2).  Tables are concatenated per module i: params[15 i ..], prepped / gprepped[6 i ..], dparams[15 i ..],
+ * dims[5 i ..] = {d_model, d_inner, gn, headdim, tap_ld};  WTConv2d: w / s / taps / gtaps / dw / ds[5 i ..] (entries 0 .. levels), bias[i],
+ * bias_t[i], gbias_t[i], dbias[i] (all NULL or all set per module), dims[4 i ..] = {C, Cp, K, levels}.  More than 8 modules are cut into
+ * several launches.  Same results as the per-module entry points, bit for bit. */
+int adnm_adnprep_fwd_multi(int64_t n, float* const* params, float* const* prepped, const int64_t* dims, adnm_stream_t stream);
+int64_t adnm_adnprep_bwd_multi_ws_bytes(int64_t n);
+int adnm_adnprep_bwd_multi(int64_t n, float* const* params, float* const* gprepped, float* const* dparams, const int64_t* dims, void* ws,
+                           int64_t ws_bytes, adnm_stream_t stream);
+int adnm_wtprep_fwd_multi(int64_t n, float* const* w, float* const* s, float* const* bias, float* const* taps, float* const* bias_t,
+                          const int64_t* dims, adnm_stream_t stream);
+int adnm_wtprep_bwd_multi(int64_t n, float* const* w, float* const* s, float* const* bias, float* const* gtaps, float* const* gbias_t,
+                          float* const* dw, float* const* ds, float* const* dbias, const int64_t* dims, adnm_stream_t stream);
+
 
 #ifdef __cplusplus
 }

@@ -898,3 +898,38 @@ def test_fp8_amax_collection_and_update(fp8_mfma):
         ops.QUANT.update(xg.device)
         assert ops.QUANT.dump(xg.device)[(wg.data_ptr(), "fnt")][6] == 1.0   # step `period`: collect again
         ops.set_mfma_precision("f32")
+
+
+@pytest.mark.parametrize("B,Cs", [(4, [256, 512, 1024]), (2, [32, 64, 128, 128, 256, 512, 1024]), (7, [36, 20])])
+def test_bridge_heads(B, Cs):
+    """every head of Channel_Att_Bridge (Linear + IntensityGate, model_untils.py:594-613,744-750) in one launch each way vs fp64 torch ops;
+    the enhance / threshold scalars are shared by all heads"""
+    S = sum(Cs) if len(Cs) == 7 else 2144
+    tag = f"bh{B}{len(Cs)}"
+    att, e, t = T(tag + "a", (B, 1, S)), torch.tensor(1.3), torch.tensor(0.1)
+    Ws, bs = [T(f"{tag}w{i}", (c, S), 0.05) for i, c in enumerate(Cs)], [T(f"{tag}b{i}", (c,), 0.1) for i, c in enumerate(Cs)]
+    cots = [T(f"{tag}c{i}", (B, 1, c)) for i, c in enumerate(Cs)]
+    lo = [leaf(v.double()) for v in [att, e, t] + Ws + bs]
+    n = len(Cs)
+    ys = [O.silu(lo[1] * (lo[0] @ lo[3 + i].t() + lo[3 + n + i] - lo[2])) for i in range(n)]
+    sum((y * c.double()).sum() for y, c in zip(ys, cots)).backward()
+    lg = [leaf(v, DEV) for v in [att, e, t] + Ws + bs]
+    yg = ops.bridge_heads(lg[0], lg[1], lg[2], lg[3:3 + n], lg[3 + n:])
+    sum((y * c.to(DEV)).sum() for y, c in zip(yg, cots)).backward()
+    for i in range(n):
+        assert_close(yg[i], ys[i], OUT_TOL, f"gate {i}")
+    names = ["datt", "denhance", "dthreshold"] + [f"dW{i}" for i in range(n)] + [f"db{i}" for i in range(n)]
+    for nm, a, b in zip(names, lg, lo):
+        assert_close(a.grad, b.grad, GRAD_TOL, nm, atol=1e-6)
+
+
+def test_chanpad_roundtrip():
+    x = T("cp.x", (3, 50, 5))
+    xg = leaf(x, DEV)
+    y = ops.chanpad(xg, 8)
+    assert torch.equal(y[..., :5].cpu(), x) and float(y[..., 5:].abs().max()) == 0.0
+    z = ops.chanpad(y, 5)
+    assert torch.equal(z.cpu(), x)
+    cot = T("cp.c", (3, 50, 5)).to(DEV)
+    (z * cot).sum().backward()
+    assert torch.equal(xg.grad, cot)
