@@ -312,7 +312,10 @@ class FoldRegistry:
         with self._lock:
             ent = self._q.get(device.index)
             if ent is None:
-                ent = self._q[device.index] = {"h": lib.load().adnm_foldq_create(), "keep": [], "on": False}
+                # "lh": the leaf queue (grouped weight-gradient GEMMs, include/adnm_hip.h adnm_leafq_*): bound / flushed together with the
+                # fold queue — its launches come first, the folds of their partials behind them
+                ent = self._q[device.index] = {"h": lib.load().adnm_foldq_create(), "keep": [], "on": False,
+                                               "lh": lib.load().adnm_leafq_create() if os.environ.get("ADNM_LEAF_DEFER", "1") != "0" else None}
         if not on:
             self.flush(device)
         ent["on"] = bool(on)
@@ -350,6 +353,9 @@ class FoldRegistry:
         ent.pop("hold", None)
         try:
             lib.load().adnm_foldq_bind(None)
+            lib.load().adnm_leafq_bind(None)
+            if ent["lh"] is not None:
+                lib.load().adnm_leafq_clear(ent["lh"])
             if lib.query("adnm_foldq_pending", ent["h"]) > 0:
                 lib.load().adnm_foldq_clear(ent["h"])
         finally:
@@ -362,6 +368,8 @@ class FoldRegistry:
             return
         with torch.cuda.device(device):
             SIDE.join(device)   # queued folds (and whoever asked for the flush) read what weight-gradient kernels wrote on the side stream
+            if ent["lh"] is not None and lib.query("adnm_leafq_pending", ent["lh"]) > 0:
+                lib.call("adnm_leafq_flush", ent["lh"], _stream())   # the grouped leaf launches first: the folds read their partials
             if lib.query("adnm_foldq_pending", ent["h"]) > 0:
                 lib.call("adnm_foldq_flush", ent["h"], _stream())
         with self._lock:
@@ -392,11 +400,14 @@ class _Deferred:
     def __enter__(self):
         if self.ent is not None:
             lib.load().adnm_foldq_bind(self.ent["h"])
+            if self.ent["lh"] is not None:
+                lib.load().adnm_leafq_bind(self.ent["lh"])
         return self.ent is not None
 
     def __exit__(self, *exc):
         if self.ent is not None:
             lib.load().adnm_foldq_bind(None)
+            lib.load().adnm_leafq_bind(None)
             with self.lock:
                 self.ent["keep"].extend(t for t in self.keep if t is not None)
         return False
@@ -697,12 +708,13 @@ def k_instnorm_bwd(dy, x, scale, shift, mu, rstd, B, HW, C, act, want_affine=Tru
     dev = x.device
     assert dy.is_contiguous() and x.is_contiguous()
     dx = torch.empty_like(x)
-    dsc = torch.empty((), dtype=torch.float32, device=dev) if want_affine else None
-    dsh = torch.empty((), dtype=torch.float32, device=dev) if want_affine else None
+    dsc = grad_dst(scale.data_ptr() if scale is not None else 0, (), dev) if want_affine else None
+    dsh = grad_dst(shift.data_ptr() if shift is not None else 0, (), dev) if want_affine else None
     nb = lib.query("adnm_instnorm_ws_bytes", B, HW, C)
     ws = _ws(nb, dev)
-    lib.call("adnm_instnorm_bwd", dy.data_ptr(), x.data_ptr(), _p(scale), _p(shift), mu.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
-             _p(dsc), _p(dsh), ws.data_ptr(), nb, B, HW, C, act, _dt(x), _stream())
+    with FOLDS.defer(dev, ws):   # d scale / d shift: parameter gradients (per-workgroup partials + the shared fold)
+        lib.call("adnm_instnorm_bwd", dy.data_ptr(), x.data_ptr(), _p(scale), _p(shift), mu.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                 _p(dsc), _p(dsh), ws.data_ptr(), nb, B, HW, C, act, _dt(x), _stream())
     return dx, dsc, dsh
 
 
@@ -1512,8 +1524,8 @@ def _skgemm(op, a, b, bias, c, dbias, M, N, K, defer=False, side=False, q=None, 
         prec, qp = _gemm_prec(q, role)
     call = lambda: lib.call("adnm_skgemm", op, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _p(bias), pc, ldc, pdb,
                             ws.data_ptr(), nb, M, N, K, prec, qp, _stream())
-    if side:
-        SIDE.submit(a.device, (a, b), FOLDS.defer(a.device, ws) if defer else _NODEFER, call)
+    if side:   # (a, b are kept with the workspace: under a bound leaf queue the launch itself waits for the grouped flush)
+        SIDE.submit(a.device, (a, b), FOLDS.defer(a.device, ws, a, b) if defer else _NODEFER, call)
     else:
         with FOLDS.defer(a.device, ws) if defer else _NODEFER:
             call()

@@ -39,6 +39,20 @@ int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, in
                       int64_t ws_bytes, int64_t I, int64_t J, int64_t R, int nbs, int prec, float* q, hipStream_t st);
 int* adnm_take_tickets(int n, hipStream_t st);
 
+// Deferred LEAF launches (core.hip, include/adnm_hip.h: adnm_leafq_*).  A weight-gradient kernel is a leaf of the backward pass: nothing reads
+// its result before the optimiser.  While the calling thread has bound a leaf queue (AND a fold queue: the fold of a leaf's partials must
+// stay behind it) such an entry point stores its fully prepared launch here instead of making it; adnm_leafq_flush launches the stored
+// problems grouped — many per launch — through the per-kind function below.  args: the kernel's argument struct, copied byte for byte.
+struct AdnmLeaf {
+  int kind, grid, prec;
+  const char* prof;
+  double bytes;
+  alignas(16) unsigned char args[200];
+};
+enum { ADNM_LEAF_SKGEMM_TN = 0, ADNM_LEAF_KINDS = 1 };
+bool adnm_leafq_push(const AdnmLeaf& leaf);                                  // false: no queue bound on this thread (launch now)
+int adnm_skgemm_tn_launch_multi(const AdnmLeaf* const* items, int n, hipStream_t st);   // skgemm.hip
+
 #define ADNM_REQUIRE(cond, ...)            \
   do {                                     \
     if (!(cond)) {                         \

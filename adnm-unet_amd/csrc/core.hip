@@ -307,6 +307,50 @@ extern "C" int adnm_foldq_flush(void* q, adnm_stream_t stream) {
   return ADNM_OK;
 }
 
+// ---- deferred leaf launches (adnm_common.h: AdnmLeaf)
+namespace {
+struct LeafQueue {
+  std::vector<AdnmLeaf> items;
+};
+thread_local LeafQueue* tls_leafq = nullptr;
+}  // namespace
+bool adnm_leafq_push(const AdnmLeaf& leaf) {
+  if (!tls_leafq || !tls_foldq) return false;   // (a leaf's partials are folded by a QUEUED fold: without the fold queue the order would break)
+  tls_leafq->items.push_back(leaf);
+  return true;
+}
+extern "C" void* adnm_leafq_create(void) { return new LeafQueue(); }
+extern "C" int adnm_leafq_destroy(void* q) {
+  if (tls_leafq == q) tls_leafq = nullptr;
+  delete (LeafQueue*)q;
+  return ADNM_OK;
+}
+extern "C" int adnm_leafq_bind(void* q) {
+  tls_leafq = (LeafQueue*)q;
+  return ADNM_OK;
+}
+extern "C" int64_t adnm_leafq_pending(void* q) { return q ? (int64_t)((LeafQueue*)q)->items.size() : 0; }
+extern "C" int adnm_leafq_clear(void* q) {
+  ADNM_REQUIRE(q, "leafq_clear: null queue");
+  ((LeafQueue*)q)->items.clear();
+  return ADNM_OK;
+}
+extern "C" int adnm_leafq_flush(void* q, adnm_stream_t stream) {
+  ADNM_REQUIRE(q, "leafq_flush: null queue");
+  LeafQueue* lq = (LeafQueue*)q;
+  if (lq->items.empty()) return ADNM_OK;
+  int rc = ADNM_OK;
+  for (int kind = 0; kind < ADNM_LEAF_KINDS && rc == ADNM_OK; ++kind) {
+    std::vector<const AdnmLeaf*> sel;
+    for (const AdnmLeaf& l : lq->items)
+      if (l.kind == kind) sel.push_back(&l);
+    if (sel.empty()) continue;
+    if (kind == ADNM_LEAF_SKGEMM_TN) rc = adnm_skgemm_tn_launch_multi(sel.data(), (int)sel.size(), (hipStream_t)stream);
+  }
+  lq->items.clear();
+  return rc;
+}
+
 // Column sums of a contiguous (rows, n) fp32 matrix — a bias gradient whose weight gradient is computed elsewhere (the transposed
 // conv's, ops.ConvT2xFn).  Tall matrices (65 536 x 32 at config 2) first go through colsum_partial_kernel: each workgroup adds a
 // contiguous band of rows (lanes along the columns, 256 / ncol row lanes, LDS tree), then the shared fold adds the bands.

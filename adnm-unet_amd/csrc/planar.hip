@@ -340,8 +340,8 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void instnorm_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                                     const float* __restrict__ mu_in, const float* __restrict__ rstd_in,
-                                                                    float* __restrict__ part, int64_t HW, int C, int cgb, int ppc,
-                                                                    int act) {
+                                                                    float* __restrict__ part, float* __restrict__ spart, int64_t HW, int C,
+                                                                    int cgb, int ppc, int act) {
   __shared__ __attribute__((aligned(16))) float smem[3 * 2 * 64 * 4];
   const int C4 = C >> 2;
   const int cgl = threadIdx.x & (cgb - 1), slot = threadIdx.x / cgb, slots = kBlock / cgb;
@@ -368,10 +368,23 @@ __global__ __launch_bounds__(kBlock) void instnorm_bwd_stats_kernel(const T* __r
       acc[1].z = fmaf(dp.z, xh.z, acc[1].z); acc[1].w = fmaf(dp.w, xh.w, acc[1].w);
     }
   fold_slots<2>(acc, cgb, smem);
-  if ((threadIdx.x >> 6) == 0 && (threadIdx.x & 63) < cgb && cv) {
-    float* dst = part + ((int64_t)b * gridDim.y + blockIdx.y) * 2 * C;
-    *reinterpret_cast<float4*>(dst + c) = acc[0];
-    *reinterpret_cast<float4*>(dst + C + c) = acc[1];
+  if ((threadIdx.x >> 6) == 0) {
+    const bool mine = (threadIdx.x & 63) < cgb && cv;
+    if (mine) {
+      float* dst = part + ((int64_t)b * gridDim.y + blockIdx.y) * 2 * C;
+      *reinterpret_cast<float4*>(dst + c) = acc[0];
+      *reinterpret_cast<float4*>(dst + C + c) = acc[1];
+    }
+    // this workgroup's share of the two scalar gradients (d shift = sum dpre, d scale = sum dpre * xhat over everything): one partial row
+    // per workgroup for the shared — deferrable — fold
+    if (spart) {
+      float a = mine ? (acc[0].x + acc[0].y) + (acc[0].z + acc[0].w) : 0.f, q = mine ? (acc[1].x + acc[1].y) + (acc[1].z + acc[1].w) : 0.f;
+      a = wave_sum(a), q = wave_sum(q);
+      if (threadIdx.x == 0) {
+        float* sp = spart + (((int64_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 2;
+        sp[0] = a, sp[1] = q;
+      }
+    }
   }
 }
 
@@ -415,44 +428,6 @@ __global__ __launch_bounds__(kBlock) void instnorm_bwd_apply_kernel(const T* __r
   }
 }
 
-// dshift = sum part[.,0,.], dscale = sum part[.,1,.] over all (b,chunk,c): one block, deterministic.
-__global__ __launch_bounds__(256) void instnorm_bwd_scalar_kernel(const float* __restrict__ part, int rows, int C,
-                                                                  float* __restrict__ dscale, float* __restrict__ dshift) {
-  __shared__ float sm[2][4];
-  float a = 0.f, q = 0.f;
-  // float4 loads, four rows in flight per thread: this is one workgroup walking a few thousand floats, so what matters is the
-  // number of dependent load round trips (it took 15 us as a scalar loop)
-  const int C4 = C >> 2;
-  const int64_t n4 = (int64_t)rows * C4;
-  for (int64_t i0 = threadIdx.x; i0 < n4; i0 += 4 * 256) {
-    float4 va[4], vq[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t i = i0 + (int64_t)u * 256;
-      const bool ok = i < n4;
-      const int64_t r = ok ? i / C4 : 0;
-      const int c = ok ? (int)(i % C4) * 4 : 0;
-      va[u] = ok ? *reinterpret_cast<const float4*>(part + r * 2 * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      vq[u] = ok ? *reinterpret_cast<const float4*>(part + r * 2 * C + C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      a += (va[u].x + va[u].y) + (va[u].z + va[u].w);
-      q += (vq[u].x + vq[u].y) + (vq[u].z + vq[u].w);
-    }
-  }
-  a = wave_sum(a);
-  q = wave_sum(q);
-  if ((threadIdx.x & 63) == 0) {
-    sm[0][threadIdx.x >> 6] = a;
-    sm[1][threadIdx.x >> 6] = q;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (dshift) *dshift = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]);
-    if (dscale) *dscale = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
-  }
-}
 
 }  // namespace
 
@@ -544,7 +519,8 @@ extern "C" int adnm_maxpool_bwd(const void* dy, const void* x, void* dx, int64_t
 
 extern "C" int64_t adnm_instnorm_ws_bytes(int64_t B, int64_t HW, int64_t C) {
   if (B <= 0 || HW <= 0 || C < 4) return 0;
-  return B * igeo(HW, C).nchunk * 2 * C * (int64_t)sizeof(float);
+  const IGeo g = igeo(HW, C);
+  return (B * g.nchunk * 2 * C + B * g.nchunk * (int64_t)g.gx * 2) * (int64_t)sizeof(float);   // channel partials + per-workgroup scalar partials
 }
 
 static int instnorm_check(const char* who, int64_t B, int64_t HW, int64_t C, int act, int dtype, void* ws, int64_t ws_bytes) {
@@ -589,18 +565,21 @@ extern "C" int adnm_instnorm_bwd(const void* dy, const void* x, const float* sca
   const dim3 grid(g.gx, g.nchunk, (unsigned)B);
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)ws;
+  float* spart = (dscale || dshift) ? part + B * g.nchunk * 2 * C : nullptr;
   if (dtype == ADNM_F32) {
-    { ADNM_PROF("instnorm_bwd_stats", st, 4.0 * B * HW * C * 2); instnorm_bwd_stats_kernel<float><<<grid, kBlock, 0, st>>>((const float*)dy, (const float*)x, scale, shift, mu, rstd, part, HW, (int)C,
+    { ADNM_PROF("instnorm_bwd_stats", st, 4.0 * B * HW * C * 2); instnorm_bwd_stats_kernel<float><<<grid, kBlock, 0, st>>>((const float*)dy, (const float*)x, scale, shift, mu, rstd, part, spart, HW, (int)C,
                                                               g.cgb, g.pix_per_chunk, act); }
     { ADNM_PROF("instnorm_bwd_apply", st, 4.0 * B * HW * C * 3); instnorm_bwd_apply_kernel<float><<<grid, kBlock, 0, st>>>((const float*)dy, (const float*)x, part, scale, shift, mu, rstd, (float*)dx,
                                                               HW, (int)C, g.cgb, g.pix_per_chunk, g.nchunk, act); }
   } else {
-    { ADNM_PROF("instnorm_bwd_stats", st, 2.0 * B * HW * C * 2); instnorm_bwd_stats_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)dy, (const uint16_t*)x, scale, shift, mu, rstd, part, HW,
+    { ADNM_PROF("instnorm_bwd_stats", st, 2.0 * B * HW * C * 2); instnorm_bwd_stats_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)dy, (const uint16_t*)x, scale, shift, mu, rstd, part, spart, HW,
                                                                  (int)C, g.cgb, g.pix_per_chunk, act); }
     { ADNM_PROF("instnorm_bwd_apply", st, 2.0 * B * HW * C * 3); instnorm_bwd_apply_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)dy, (const uint16_t*)x, part, scale, shift, mu, rstd,
                                                                  (uint16_t*)dx, HW, (int)C, g.cgb, g.pix_per_chunk, g.nchunk, act); }
   }
-  if (dscale || dshift) { ADNM_PROF("instnorm_bwd_scalar", st, 4.0 * B * g.nchunk * 2 * C); instnorm_bwd_scalar_kernel<<<1, 256, 0, st>>>(part, (int)(B * g.nchunk), (int)C, dscale, dshift); }
+  ADNM_CHECK_LAUNCH("instnorm_bwd");
+  // d shift / d scale: parameter gradients through the shared fold (deferrable: the caller may have bound a fold queue)
+  if (spart) adnm_launch_fold("instnorm_bwd_scalar", spart, (int)(B * g.nchunk * g.gx), 2, {dshift, 1}, {dscale, 1}, {nullptr, 0}, {nullptr, 0}, st);
   ADNM_CHECK_LAUNCH("instnorm_bwd");
   return ADNM_OK;
 }

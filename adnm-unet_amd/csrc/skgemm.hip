@@ -56,23 +56,24 @@ struct SkArgs {
 
 // A_RC / B_RC: operand contiguous along the reduction axis.  TM x TN blocks of 16 x 16 per wave, KC 16-step groups per chunk.
 // PREC: ADNM_MFMA_* (the matrix-core precision); A_BF8: in the fp8 mode the A operand is a gradient (e5m2).
-template <bool A_RC, bool B_RC, int PREC, bool A_BF8, int TM, int TN, int KC>
-__global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
+// (bid, nblk): this workgroup's index and the workgroup count of ITS problem — the whole grid of the single-problem launch, a block range of
+// the grouped weight-gradient launch (skgemm_tn_multi_kernel).  Args: SkArgs, possibly in the constant address space.
+template <bool A_RC, bool B_RC, int PREC, bool A_BF8, int TM, int TN, int KC, typename Args>
+__device__ __forceinline__ void skgemm_body(const Args& p, const int bid, const int nblk) {
   static_assert((A_RC || TM == 4) && (B_RC || TN == 4), "an operand contiguous along the output axis is 4 interleaved blocks wide");
   constexpr int kAcc = TM * TN * 256;        // one wave's accumulators ...
   constexpr int kBuf = kAcc + 4 * 64;        // ... + its bias-gradient lanes, in LDS
   __shared__ __attribute__((aligned(16))) float red[(kWaves / 2) * kBuf];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, and the compiler should know it
   const int gw = wave % p.wpt, group = wave / p.wpt;                 // slice within the tile's wave group, group within the block
-  int ts = blockIdx.x * (kWaves / p.wpt) + group;
+  int ts = bid * (kWaves / p.wpt) + group;
   const bool active = ts < p.ntiles * p.nbs;
   int tile, bslice;
   if (p.tickets) {
     // one tile slice per workgroup.  Workgroups go round-robin over the 8 XCDs: give each XCD a contiguous run of (tile, slice) pairs so
     // that the slices of a tile (whose slabs the last of them reads back) and neighbouring tiles (which share A rows) meet in one L2.
     // A speed choice only: the combine below is correct for any placement.
-    const int nblk = gridDim.x;
-    if ((nblk & 7) == 0) ts = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    if ((nblk & 7) == 0) ts = (bid & 7) * (nblk >> 3) + (bid >> 3);
     tile = ts / p.nbs, bslice = ts % p.nbs;
   } else {
     tile = active ? ts % p.ntiles : 0, bslice = active ? ts / p.ntiles : 0;
@@ -345,6 +346,31 @@ __global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
       *reinterpret_cast<float4*>(p.out + (int64_t)ig * p.ldo + jg) = sum;
     }
   }
+}
+
+template <bool A_RC, bool B_RC, int PREC, bool A_BF8, int TM, int TN, int KC>
+__global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
+  skgemm_body<A_RC, B_RC, PREC, A_BF8, TM, TN, KC>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Grouped weight gradients: the TN problems of a backward pass are leaves (nothing reads dW before the optimiser) and individually small
+// (a few tiles x a few reduction slices: 70 launches of ~10 us at config 2), so a caller that has bound a leaf queue gets them QUEUED and
+// launched up to kMaxSk at a time — every workgroup looks up its problem in the descriptor table (kernel arguments, constant address space)
+// and runs the unchanged tile code on it.  Same arithmetic per problem: bitwise the same results as separate launches.
+constexpr int kMaxSk = 16;
+struct MultiSk {
+  int count, blk_end[kMaxSk];
+  SkArgs p[kMaxSk];
+};
+static_assert(sizeof(MultiSk) <= 4096, "the descriptor table must fit the kernel argument segment");
+template <int PREC>
+__global__ __launch_bounds__(kBlock) void skgemm_tn_multi_kernel(MultiSk by_value) {
+  (void)by_value;
+  const auto& m = *(const __attribute__((address_space(4))) MultiSk*)__builtin_amdgcn_kernarg_segment_ptr();
+  int k = 0;
+  while (k + 1 < m.count && (int)blockIdx.x >= m.blk_end[k]) ++k;
+  const int b0 = k ? m.blk_end[k - 1] : 0;
+  skgemm_body<false, false, PREC, false, 4, 4, 1>(m.p[k], (int)blockIdx.x - b0, m.blk_end[k] - b0);
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------------
@@ -625,7 +651,15 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
     ADNM_REQUIRE(p.tickets, "skgemm: no arrival counters (first split launch of a device under stream capture, or hipMalloc failed)");
   }
   const unsigned grid = (unsigned)adnm_cdiv((int64_t)pl.ntiles * pl.nbs, kWaves / pl.wpt);
-  {
+  bool queued = false;
+  if (op == ADNM_SKGEMM_TN && (prec == ADNM_MFMA_F32 || prec == ADNM_MFMA_BF16)) {   // a leaf: may wait for the grouped launch
+    static_assert(sizeof(SkArgs) <= sizeof(AdnmLeaf::args), "SkArgs must fit a leaf record");
+    AdnmLeaf leaf;
+    leaf.kind = ADNM_LEAF_SKGEMM_TN, leaf.grid = (int)grid, leaf.prec = prec, leaf.prof = scope, leaf.bytes = algo_bytes;
+    memcpy(leaf.args, &p, sizeof(SkArgs));
+    queued = adnm_leafq_push(leaf);
+  }
+  if (!queued) {
     ADNM_PROF(scope, st, algo_bytes);
     if (op == ADNM_SKGEMM_NT) {
       if (pl.tm == 1) launch<true, true, 1, 1, 4>(prec, grid, st, p);
@@ -644,5 +678,33 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
     adnm_launch_fold("skgemm_fold", part, pl.nbs, (int)rowlen, {c, (int)(I * J)}, {dbias, dbias ? (int)I : 0}, {nullptr, 0}, {nullptr, 0}, st);
     ADNM_CHECK_LAUNCH("skgemm_fold");
   }
+  return ADNM_OK;
+}
+
+
+// the queued weight-gradient problems, kMaxSk per launch (fp32 and bf16 problems in separate launches)
+int adnm_skgemm_tn_launch_multi(const AdnmLeaf* const* items, int n, hipStream_t st) {
+  for (int prec = ADNM_MFMA_F32; prec <= ADNM_MFMA_BF16; ++prec) {
+    int i = 0;
+    while (i < n) {
+      MultiSk m;
+      m.count = 0;
+      int blocks = 0;
+      double bytes = 0;
+      for (; i < n && m.count < kMaxSk; ++i) {
+        if (items[i]->prec != prec) continue;
+        memcpy(&m.p[m.count], items[i]->args, sizeof(SkArgs));
+        blocks += items[i]->grid;
+        m.blk_end[m.count++] = blocks;
+        bytes += items[i]->bytes;
+      }
+      if (!m.count) break;
+      for (int k = m.count; k < kMaxSk; ++k) m.blk_end[k] = blocks;
+      ADNM_PROF("skgemm_tn", st, bytes);
+      if (prec == ADNM_MFMA_BF16) skgemm_tn_multi_kernel<ADNM_MFMA_BF16><<<(unsigned)blocks, kBlock, 0, st>>>(m);
+      else skgemm_tn_multi_kernel<ADNM_MFMA_F32><<<(unsigned)blocks, kBlock, 0, st>>>(m);
+    }
+  }
+  ADNM_CHECK_LAUNCH("skgemm_tn (grouped)");
   return ADNM_OK;
 }

@@ -87,6 +87,18 @@ int adnm_foldq_clear(void* q); /* drop the queued folds without launching them (
  * meaningful while a queue is bound (ignored otherwise: an immediate fold always overwrites). */
 int adnm_foldq_accumulate_next(int mask);
 
+/* Deferred leaf launches.  The weight-gradient GEMMs of a backward pass (ADNM_SKGEMM_TN) are leaves — nothing reads dW before
+ * clip_grad_norm_ / the optimiser (train.py:140-144) — and individually small (70 launches of ~10 us at config 2).  While the calling
+ * thread has bound BOTH a leaf queue and a fold queue, adnm_skgemm(TN) stores its prepared launch instead of making it (operands,
+ * workspace and destination must stay alive); adnm_leafq_flush launches the stored problems grouped, 16 per launch, and must be called
+ * BEFORE adnm_foldq_flush (the folds of split problems read the partials those launches write).  Results are bitwise the same either way. */
+void* adnm_leafq_create(void);
+int adnm_leafq_destroy(void* q);
+int adnm_leafq_bind(void* q); /* NULL unbinds */
+int64_t adnm_leafq_pending(void* q);
+int adnm_leafq_flush(void* q, adnm_stream_t stream);
+int adnm_leafq_clear(void* q);
+
 /* ---------------------------------------------------------------- row norms (K2, K7)
  * y = scale * ( xhat * w + b ) + shift,  xhat = (x - mu) * rstd
  *   RMSNorm   (mamba_ssm RMSNorm bound at ADNMUNet.py:278, used ADNMUNet.py:149,155): subtract_mean=0, b=NULL
