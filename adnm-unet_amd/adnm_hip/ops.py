@@ -663,7 +663,8 @@ def k_dwconv_bwd(dy, x, wt, bias, B, H, W, C, K, act, dx=None, want_bias=False, 
     g, ldg = (dpre.data_ptr(), C) if dpre is not None else (pdy, lddy)
     pdw, pdb, dt_ = _p(dwt), _p(db), _dt(x)
     # taps / bias gradients: parameters, or prep intermediates flushed at the prep node
-    SIDE.submit(dev, (dy, x, dpre), FOLDS.defer(dev, ws), lambda: lib.call(
+    # (the operands are kept with the workspace: under a bound leaf queue the launch itself waits for the grouped flush)
+    SIDE.submit(dev, (dy, x, dpre), FOLDS.defer(dev, ws, dy, x, dpre), lambda: lib.call(
         "adnm_dwconv_wgrad", g, ldg, px, ldx, pdw, pdb, ws.data_ptr(), nb, B, H, W, C, K, K, int(chan_major), dt_, _stream()))
     return dx, dwt, db
 

@@ -346,6 +346,7 @@ extern "C" int adnm_leafq_flush(void* q, adnm_stream_t stream) {
       if (l.kind == kind) sel.push_back(&l);
     if (sel.empty()) continue;
     if (kind == ADNM_LEAF_SKGEMM_TN) rc = adnm_skgemm_tn_launch_multi(sel.data(), (int)sel.size(), (hipStream_t)stream);
+    else rc = adnm_dwconv_wgrad_launch_multi(sel.data(), (int)sel.size(), kind == ADNM_LEAF_DWCONV_WGRAD_K3 ? 3 : 5, (hipStream_t)stream);
   }
   lq->items.clear();
   return rc;

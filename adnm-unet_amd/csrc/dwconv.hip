@@ -121,10 +121,12 @@ __global__ __launch_bounds__(kBlock) void dwconv_kernel(const T* __restrict__ x,
 // part[blockIdx.y, tap, c]  (tap index K*K holds dbias)
 constexpr int kWgSlices = 2;  // waves per tap row: more memory-level parallelism without more partial rows
 
+// (bx, by, nby): this workgroup's position in ITS problem's (channel-quad block, pixel block) grid — blockIdx / gridDim of the single-problem
+// launch, a block range of the grouped launch (dwconv_wgrad_multi_kernel: the tap gradients of a backward pass are leaves).
 template <typename T, int K>
-__global__ __launch_bounds__(64 * K * kWgSlices) void dwconv_wgrad_kernel(const T* __restrict__ dpre, int64_t ldd, const T* __restrict__ x,
-                                                              int64_t ldx, float* __restrict__ part, int B, int H, int W, int C,
-                                                              int cgb, int wcm) {
+__device__ __forceinline__ void dwconv_wgrad_body(const T* __restrict__ dpre, int64_t ldd, const T* __restrict__ x, int64_t ldx,
+                                                  float* __restrict__ part, int B, int H, int W, int C, int cgb, int wcm, const int bx,
+                                                  const int by, const int nby) {
   constexpr int R = K / 2;
   constexpr int NT = K * K;
   const int C4 = C >> 2;
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(64 * K * kWgSlices) void dwconv_wgrad_kernel(const 
   const int cgl = lane & (cgb - 1);
   const int slot = lane / cgb;
   const int slots = 64 / cgb;
-  const int cg = blockIdx.x * cgb + cgl;
+  const int cg = bx * cgb + cgl;
   const bool cv = cg < C4;
   const int c = cv ? cg * 4 : 0;
   const int WT = (W + TW - 1) / TW;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(64 * K * kWgSlices) void dwconv_wgrad_kernel(const 
     // Each block owns a CONTIGUOUS range of tiles (XCD-aware: the ranges of one XCD are adjacent, so the x / dpre rows
     // shared by its K tap-row waves and by vertically adjacent tiles are served by that XCD's L2), and keeps two tiles
     // in flight per lane (memory-level parallelism).
-    const unsigned nb = gridDim.y, q8 = nb >> 3, r8 = nb & 7, xcd = blockIdx.y & 7, loc = blockIdx.y >> 3;
+    const unsigned nb = (unsigned)nby, q8 = nb >> 3, r8 = nb & 7, xcd = (unsigned)by & 7, loc = (unsigned)by >> 3;
     const int64_t bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
     const int64_t tpb = (tiles + nb - 1) / nb;
     const int64_t tbeg = bid * tpb, tend = (tbeg + tpb < tiles) ? tbeg + tpb : tiles;
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(64 * K * kWgSlices) void dwconv_wgrad_kernel(const 
   }
   __syncthreads();
   if (sl == 0) {
-    float* dst = part + (int64_t)blockIdx.y * (NT + 1) * C;
+    float* dst = part + (int64_t)by * (NT + 1) * C;
 #pragma unroll
     for (int j = 0; j <= K; ++j) {
       if (j == K && i != R) break;
@@ -222,6 +224,39 @@ __global__ __launch_bounds__(64 * K * kWgSlices) void dwconv_wgrad_kernel(const 
       }
     }
   }
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(64 * K * kWgSlices) void dwconv_wgrad_kernel(const T* __restrict__ dpre, int64_t ldd, const T* __restrict__ x,
+                                                              int64_t ldx, float* __restrict__ part, int B, int H, int W, int C,
+                                                              int cgb, int wcm) {
+  dwconv_wgrad_body<T, K>(dpre, ldd, x, ldx, part, B, H, W, C, cgb, wcm, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
+
+// grouped form: up to kMaxWg queued problems per launch (fp32 tokens), descriptors in the kernel argument segment
+constexpr int kMaxWg = 16;
+struct WgLeaf {
+  const float* dpre;
+  int64_t ldd;
+  const float* x;
+  int64_t ldx;
+  float* part;
+  int B, H, W, C, cgb, wcm, gx, npb;
+};
+struct MultiWg {
+  int count, blk_end[kMaxWg];
+  WgLeaf p[kMaxWg];
+};
+template <int K>
+__global__ __launch_bounds__(64 * K * kWgSlices) void dwconv_wgrad_multi_kernel(MultiWg by_value) {
+  (void)by_value;
+  const auto& m = *(const __attribute__((address_space(4))) MultiWg*)__builtin_amdgcn_kernarg_segment_ptr();
+  int k = 0;
+  while (k + 1 < m.count && (int)blockIdx.x >= m.blk_end[k]) ++k;
+  const int lin = (int)blockIdx.x - (k ? m.blk_end[k - 1] : 0);
+  const int gx = m.p[k].gx;
+  dwconv_wgrad_body<float, K>(m.p[k].dpre, m.p[k].ldd, m.p[k].x, m.p[k].ldx, m.p[k].part, m.p[k].B, m.p[k].H, m.p[k].W, m.p[k].C, m.p[k].cgb,
+                              m.p[k].wcm, lin % gx, lin / gx, m.p[k].npb);
 }
 
 // (c') 3x3 weight / bias gradients, "column walker": a lane owns one channel quad and one 4-pixel-wide strip of SEG rows and
@@ -405,10 +440,24 @@ void launch_wgrad(const void* dpre, int64_t ldd, const void* x, int64_t ldx, flo
   const dim3 grid(g.gx, g.npb);
   if (K == 3 && g.seg > 0)
     { ADNM_PROF("dwconv_wgrad_k3", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad3_roll_kernel<T><<<grid, kBlock, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb, g.seg, g.nseg, wcm); }
-  else if (K == 3)
-    { ADNM_PROF("dwconv_wgrad_k3", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 3><<<grid, 64 * 3 * kWgSlices, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb, wcm); }
-  else
-    { ADNM_PROF("dwconv_wgrad_k5", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 5><<<grid, 64 * 5 * kWgSlices, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb, wcm); }
+  else {
+    bool queued = false;
+    if (sizeof(T) == 4) {   // a leaf of the backward pass: may wait for the grouped launch (fp32 tokens)
+      static_assert(sizeof(WgLeaf) <= sizeof(AdnmLeaf::args), "WgLeaf must fit a leaf record");
+      WgLeaf w{(const float*)dpre, ldd, (const float*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb, wcm, (int)g.gx, (int)g.npb};
+      AdnmLeaf leaf;
+      leaf.kind = K == 3 ? ADNM_LEAF_DWCONV_WGRAD_K3 : ADNM_LEAF_DWCONV_WGRAD_K5, leaf.grid = (int)(g.gx * g.npb), leaf.prec = 0;
+      leaf.prof = K == 3 ? "dwconv_wgrad_k3" : "dwconv_wgrad_k5", leaf.bytes = 4.0 * B * H * W * C * 2;
+      memcpy(leaf.args, &w, sizeof(w));
+      queued = adnm_leafq_push(leaf);
+    }
+    if (!queued) {
+      if (K == 3)
+        { ADNM_PROF("dwconv_wgrad_k3", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 3><<<grid, 64 * 3 * kWgSlices, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb, wcm); }
+      else
+        { ADNM_PROF("dwconv_wgrad_k5", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad_kernel<T, 5><<<grid, 64 * 5 * kWgSlices, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb, wcm); }
+    }
+  }
   adnm_launch_fold("dwconv_wgrad_fold", part, g.rows, (K * K + 1) * (int)C, {dwgt, K * K * (int)C}, {dbias, (int)C}, {nullptr, 0}, {nullptr, 0}, st);
 }
 
@@ -486,5 +535,28 @@ extern "C" int adnm_dwconv_wgrad(const void* g, int64_t ldg, const void* x, int6
   if (dtype == ADNM_F32) launch_wgrad<float>(g, ldg, x, ldx, (float*)ws, dwgt, dbias, B, H, W, C, KH, wlayout, st);
   else launch_wgrad<uint16_t>(g, ldg, x, ldx, (float*)ws, dwgt, dbias, B, H, W, C, KH, wlayout, st);
   ADNM_CHECK_LAUNCH("dwconv_wgrad");
+  return ADNM_OK;
+}
+
+
+// the queued depthwise tap-gradient problems of one kernel size, kMaxWg per launch
+int adnm_dwconv_wgrad_launch_multi(const AdnmLeaf* const* items, int n, int K, hipStream_t st) {
+  for (int i = 0; i < n;) {
+    MultiWg m;
+    m.count = 0;
+    int blocks = 0;
+    double bytes = 0;
+    for (; i < n && m.count < kMaxWg; ++i) {
+      memcpy(&m.p[m.count], items[i]->args, sizeof(WgLeaf));
+      blocks += items[i]->grid;
+      m.blk_end[m.count++] = blocks;
+      bytes += items[i]->bytes;
+    }
+    for (int k = m.count; k < kMaxWg; ++k) m.blk_end[k] = blocks;
+    ADNM_PROF(K == 3 ? "dwconv_wgrad_k3" : "dwconv_wgrad_k5", st, bytes);
+    if (K == 3) dwconv_wgrad_multi_kernel<3><<<(unsigned)blocks, 64 * 3 * kWgSlices, 0, st>>>(m);
+    else dwconv_wgrad_multi_kernel<5><<<(unsigned)blocks, 64 * 5 * kWgSlices, 0, st>>>(m);
+  }
+  ADNM_CHECK_LAUNCH("dwconv_wgrad (grouped)");
   return ADNM_OK;
 }
