@@ -1085,10 +1085,13 @@ class ADNMixerFn(torch.autograd.Function):
         nh = di // P
         u2 = u.reshape(M, dm)
         u2 = u2 if u2.is_contiguous() else u2.contiguous()
-        proj = k_linear(u2, w_in, None, qkey=qkeys[0])  # (M, 2di+2gN+nh) = [z | xBC | dt]
+        # storage type of the node's wide internal tensors (proj, wide, y and their gradients): bf16 at the full-resolution level in the
+        # bf16 configuration (low_storage), fp32 otherwise; u, the result and every parameter gradient stay fp32
+        st = low_storage(M, [(w_in.shape[0], dm), (dm, 2 * di), (2 * di, dm), (dm, w_in.shape[0])]) if scan_chunk == 0 else u.dtype
+        proj = k_linear(u2, w_in, None, qkey=qkeys[0], out_dtype=st)  # (M, 2di+2gN+nh) = [z | xBC | dt]
         # one wide buffer [LN(y) | silu(conv_z(z)) | silu(conv(xBC))]: its first 2di columns are out_proj's input, the rest K1's operands;
         # z and xBC are adjacent in `proj` and their conv outputs adjacent here, so ONE depthwise launch (taps = [czw | cw]) does both
-        wide = torch.empty((M, 2 * di + cx), dtype=u.dtype, device=u.device)
+        wide = torch.empty((M, 2 * di + cx), dtype=st, device=u.device)
         cat, xbc = wide[:, :2 * di], wide[:, 2 * di:]
         k_dwconv_fwd(proj[:, :di + cx], taps, tb, Bsz, H, W, di + cx, 3, lib.ACT_SILU, y=wide[:, di:])
         if scan_chunk == 0:   # linear_attn_duality=True: the global reduction (K1), both halves in one launch
@@ -1108,7 +1111,7 @@ class ADNMixerFn(torch.autograd.Function):
             mu = None
         if mu is None:
             _, mu, rstd = k_rownorm_fwd(y, ln_w, ln_b, None, None, 1e-5, True, out=cat[:, :di])
-        out = k_linear(cat, w_out, None, qkey=qkeys[1])
+        out = k_linear(cat, w_out, None, qkey=qkeys[1], out_dtype=u.dtype)
         ctx.save_for_backward(u2, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, proj, wide, y, kv, mu, rstd)
         ctx.dims = (Bsz, L, dm, H, W, P, N, di, cx, nh, scan_chunk, scan_groups)
         ctx.qkeys = qkeys
@@ -1143,7 +1146,7 @@ class ADNMixerFn(torch.autograd.Function):
             ddtb, dA, dD = (torch.stack((parts[0][k], parts[1][k]), dim=1).reshape(nh) for k in range(3))
         _, dtaps, dtb = k_dwconv_bwd(dwide[:, di:], proj[:, :di + cx], taps, tb, Bsz, H, W, di + cx, 3, lib.ACT_SILU, dx=dproj[:, :di + cx],
                                      want_bias=tb is not None)
-        du = k_linear_dx(dproj, w_in, qkey=ctx.qkeys[0])
+        du = k_linear_dx(dproj, w_in, qkey=ctx.qkeys[0], out_dtype=u2.dtype)
         dw_in, _ = k_linear_dw(dproj, u2, False)
         return (du.view(Bsz, L, dm), dw_in, dtaps, dtb, ddtb, dA, dD, dln_w, dln_b, dw_out, None, None, None, None, None, None, None)
 
@@ -1152,6 +1155,59 @@ def adn_mixer(u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, 
     """qkeys: stable identities (data_ptr of in_proj.weight / out_proj.weight) of the two projections for the fp8 call-site records —
     w_in / w_out themselves are per-step temporaries."""
     return ADNMixerFn.apply(u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk, scan_groups, qkeys)
+
+
+class FeedForwardFn(torch.autograd.Function):
+    """FeedForward.forward (model_untils.py:192-197 of the reference) as ONE autograd node with a hand-written backward:
+    1x1 d -> 4d (+bias), depthwise 3x3 on 4d (+bias), gelu(x1) * sigmoid(x2), 1x1 2d -> d (+bias) on (B, H*W, d) tokens.  The three wide
+    intermediates (4d, 4d, 2d columns) are internal: at the full-resolution level of the bf16 configuration they are stored in bf16
+    (low_storage), which halves the bytes of the kernels that are bound by them; input, output and parameter gradients stay fp32.
+    Weights: w_in (4d, d), dw (4d, 1, 3, 3) in nn.Conv2d's own layout, w_out (d, 2d)."""
+
+    @staticmethod
+    def forward(ctx, x, w_in, b_in, dw, b_dw, w_out, b_out, H, W):
+        B, L, d = x.shape
+        M = B * L
+        F4, F2 = w_in.shape[0], w_out.shape[1]
+        x2 = x.reshape(M, d)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        w_in, w_out = w_in.contiguous(), w_out.contiguous()
+        wt = dw.reshape(F4, 9)
+        if wt.dtype != torch.float32 or not wt.is_contiguous():
+            wt = wt.contiguous().float()
+        st = low_storage(M, [(F4, d), (d, F4), (d, F2), (F2, d)])
+        h1 = k_linear(x2, w_in, b_in, out_dtype=st)                                    # project_in
+        h2 = k_dwconv_fwd(h1, wt, b_dw, B, H, W, F4, 3, lib.ACT_NONE, chan_major=True)   # dwconv
+        g = k_gate_fwd(h2, F2)                                                          # gelu(x1) * sigmoid(x2)
+        out = k_linear(g, w_out, b_out, out_dtype=x.dtype)                              # project_out
+        ctx.save_for_backward(x2, w_in, b_in, wt, b_dw, w_out, b_out, h1, h2, g)
+        ctx.meta = (B, L, d, H, W, F4, F2, dw.shape)
+        return out.view(B, L, w_out.shape[0])
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, w_in, b_in, wt, b_dw, w_out, b_out, h1, h2, g = ctx.saved_tensors
+        B, L, d, H, W, F4, F2, dwshape = ctx.meta
+        M = B * L
+        do = dout.reshape(M, w_out.shape[0])
+        do = do if do.is_contiguous() else do.contiguous()
+        dg = k_linear_dx(do, w_out, out_dtype=g.dtype)
+        dw_out, db_out = k_linear_dw(do, g, b_out is not None, w_out.data_ptr(), b_out.data_ptr() if b_out is not None else 0)
+        dh2 = k_gate_bwd(dg, h2, F2)
+        dh1, dwt, db_dw = k_dwconv_bwd(dh2, h1, wt, b_dw, B, H, W, F4, 3, lib.ACT_NONE, want_bias=b_dw is not None, chan_major=True)
+        dx = k_linear_dx(dh1, w_in, out_dtype=x2.dtype) if ctx.needs_input_grad[0] else None
+        dw_in, db_in = k_linear_dw(dh1, x2, b_in is not None, w_in.data_ptr(), b_in.data_ptr() if b_in is not None else 0)
+        return (dx.view(B, L, d) if dx is not None else None, dw_in, db_in, dwt.view(dwshape), db_dw, dw_out, db_out, None, None)
+
+
+def feedforward(x, w_in, b_in, dw, b_dw, w_out, b_out, H, W):
+    _need_gpu(x)
+    F4, F2 = w_in.shape[0], w_out.shape[1]
+    if (x.dtype != torch.float32 or x.dim() != 3 or x.shape[1] != H * W or F4 != 2 * F2 or F2 % 4 or tuple(dw.shape) != (F4, 1, 3, 3)
+            or w_in.shape[1] != x.shape[-1]):
+        _unsupported("feedforward", f"is 1x1 d->4d, depthwise 3x3, gelu*sigmoid gate, 1x1 2d->d on fp32 (B, H*W, d) tokens with 8 | 4d, got "
+                                    f"{x.dtype} {tuple(x.shape)}, weights {tuple(w_in.shape)}, {tuple(dw.shape)}, {tuple(w_out.shape)}")
+    return FeedForwardFn.apply(x, w_in, b_in, dw, b_dw, w_out, b_out, H, W)
 
 
 class LinCombFn(torch.autograd.Function):
@@ -1493,11 +1549,27 @@ SK_NT, SK_NN, SK_TN = 0, 1, 2
 
 
 def ts_ok_nt(M, N, K, x):
-    return (x.is_cuda and x.dtype == torch.float32 and M >= TS_MIN_ROWS and x.stride(0) % 4 == 0 and lib.query("adnm_tsgemm_supported", M, N, K) == 1)
+    return (x.is_cuda and x.dtype in _DT and M >= TS_MIN_ROWS and x.stride(0) % 4 == 0 and lib.query("adnm_tsgemm_supported", M, N, K) == 1)
 
 
 def ts_ok_tn(M, N, K, x):
-    return (x.is_cuda and x.dtype == torch.float32 and M >= TS_MIN_ROWS and lib.query("adnm_tsgemm_tn_supported", M, N, K) == 1)
+    return (x.is_cuda and x.dtype in _DT and M >= TS_MIN_ROWS and lib.query("adnm_tsgemm_tn_supported", M, N, K) == 1)
+
+
+def low_storage(M, shapes):
+    """torch.bfloat16 when the wide INTERNAL tensors of a fused node (ADNMixerFn, FeedForwardFn) over M token rows may be kept in bf16,
+    else torch.float32: the matrix-core precision of these GEMMs is bf16 (so the values are rounded to bf16 on their way into the MFMA
+    anyway), every GEMM of the node — shapes = [(N, K), ...] — runs on the tall-skinny kernel (the only GEMM kernel with bf16 token
+    I/O: the full-resolution level, where these kernels are bound by exactly those bytes), and ADNM_BF16_STORAGE != 0.  The node's
+    inputs, outputs and parameter gradients stay fp32."""
+    if MFMA_PREC[0] == 0 or M < TS_MIN_ROWS or os.environ.get("ADNM_BF16_STORAGE", "1") == "0":
+        return torch.float32
+    if MFMA_PREC[0] == 2 and M <= QUANT.max_rows:   # fp8 operands for this many rows: fp32 storage, quantised on load
+        return torch.float32
+    for N, K in shapes:
+        if lib.query("adnm_tsgemm_supported", M, N, K) != 1 or lib.query("adnm_tsgemm_tn_supported", M, N, K) != 1:
+            return torch.float32
+    return torch.bfloat16
 
 
 def _sk_operand(t, what):
@@ -1536,7 +1608,7 @@ def _out_view_ok(out):
     return out.stride(-1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0
 
 
-def k_linear(x2, w, bias, out=None, qkey=None, role="f"):
+def k_linear(x2, w, bias, out=None, qkey=None, role="f", out_dtype=None):
     """Y = X W^T (+bias) for row views X (M,K) [stride (ld,1)], W (N,K) contiguous.
     qkey: stable identity of the weight for the fp8 call-site record (default: its data_ptr — right for parameters, wrong for
     per-step temporaries such as the mixer's prepared weights, whose callers pass the parameter's); role "f": X are activations,
@@ -1546,9 +1618,10 @@ def k_linear(x2, w, bias, out=None, qkey=None, role="f"):
     _need_gpu(x2)
     q = QUANT.record(x2.device, w.data_ptr() if qkey is None else qkey, role + "nt", M)
     if ts_ok_nt(M, N, K, x2):
-        y = out if out is not None else torch.empty((M, N), dtype=x2.dtype, device=x2.device)
+        y = out if out is not None else torch.empty((M, N), dtype=out_dtype or x2.dtype, device=x2.device)
         prec, qp = _gemm_prec(q, role)
-        lib.call("adnm_tsgemm_nt", x2.data_ptr(), x2.stride(0), w.data_ptr(), K, 1, _p(bias), y.data_ptr(), y.stride(0), M, N, K, prec, qp, _stream())
+        lib.call("adnm_tsgemm_nt", x2.data_ptr(), x2.stride(0), w.data_ptr(), K, 1, _p(bias), y.data_ptr(), y.stride(0), M, N, K, prec, qp, _dt(x2),
+                 _dt(y), _stream())
         return y
     x2, w = _sk_operand(x2, "input"), _sk_operand(w, "weight")
     y = out if out is not None and _out_view_ok(out) else torch.empty((M, N), dtype=x2.dtype, device=x2.device)
@@ -1559,16 +1632,17 @@ def k_linear(x2, w, bias, out=None, qkey=None, role="f"):
     return y
 
 
-def k_linear_dx(dy2, w, out=None, qkey=None, role="g"):
+def k_linear_dx(dy2, w, out=None, qkey=None, role="g", out_dtype=None):
     """dX = dY W for dY (M,N) row view, W (N,K) contiguous.  (qkey / role: see k_linear; the transposed conv's FORWARD is this product
     with activations as the first operand, role "f".)"""
     M, N = dy2.shape
     K = w.shape[1]
     q = QUANT.record(dy2.device, w.data_ptr() if qkey is None else qkey, role + "nn", M)
     if ts_ok_nt(M, K, N, dy2):
-        dx = out if out is not None else torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
+        dx = out if out is not None else torch.empty((M, K), dtype=out_dtype or dy2.dtype, device=dy2.device)
         prec, qp = _gemm_prec(q, role)
-        lib.call("adnm_tsgemm_nt", dy2.data_ptr(), dy2.stride(0), w.data_ptr(), 1, K, None, dx.data_ptr(), dx.stride(0), M, K, N, prec, qp, _stream())
+        lib.call("adnm_tsgemm_nt", dy2.data_ptr(), dy2.stride(0), w.data_ptr(), 1, K, None, dx.data_ptr(), dx.stride(0), M, K, N, prec, qp, _dt(dy2),
+                 _dt(dx), _stream())
         return dx
     dy2, w = _sk_operand(dy2, "output gradient"), _sk_operand(w, "weight")
     dx = out if out is not None and _out_view_ok(out) else torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
@@ -1606,8 +1680,9 @@ def k_linear_dw(dy2, x2, want_bias, w_ptr=0, b_ptr=0, dw_out=None):
         nb = lib.query("adnm_tsgemm_tn_ws_bytes", M, N, K)
         ws = _ws(nb, dev)
         pdw, pdb = dw.data_ptr(), _p(db)
+        dty, dtx = _dt(dy2), _dt(x2)
         SIDE.submit(dev, (dy2, x2), FOLDS.defer(dev, ws), lambda: lib.call(
-            "adnm_tsgemm_tn", dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), pdw, pdb, ws.data_ptr(), nb, M, N, K, _stream()))
+            "adnm_tsgemm_tn", dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), pdw, pdb, ws.data_ptr(), nb, M, N, K, dty, dtx, _stream()))
         return dw, db
     dy2, x2 = _sk_operand(dy2, "output gradient"), _sk_operand(x2, "input")
     _skgemm(SK_TN, dy2, x2, None, dw, db, M, N, K, defer=True, side=True)

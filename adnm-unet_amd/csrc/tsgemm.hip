@@ -30,10 +30,12 @@ struct WImg {   // bytes of one (column block, reduction group, lane) entry of t
   static constexpr int kEntry = PREC == ADNM_MFMA_F32 ? 4 : (PREC == ADNM_MFMA_BF16 ? 16 : 8);
   static constexpr int kSteps = PREC == ADNM_MFMA_F32 ? 1 : 8;   // per lane
 };
-template <int KQ, int NB, int PREC, bool A_BF8>
-__global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+// AT / CT: storage type of the token rows read / written (float, or uint16_t = bf16: the wide intermediates of the full-resolution level
+// are kept in bf16 when the matrix-core precision is bf16 anyway — half the bytes of the kernels that are bound by exactly those bytes).
+template <int KQ, int NB, int PREC, bool A_BF8, typename AT, typename CT>
+__global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const AT* __restrict__ x, int64_t ldx, const float* __restrict__ w,
                                                            int64_t ws_n, int64_t ws_k, const float* __restrict__ bias,
-                                                           float* __restrict__ y, int64_t ldy, int64_t M, int N, int K, AdnmQuant* q) {
+                                                           CT* __restrict__ y, int64_t ldy, int64_t M, int N, int K, AdnmQuant* q) {
   // fp32: [NB][K/4][64] floats, one per (column block, k step, lane).  bf16 / fp8: [NB][KP][64] entries of 8 bf16 / 8 fp8 = the lane's
   // eight reduction steps of ONE v_mfma_f32_16x16x32 (KP = ceil(KQ / 2) groups of 32 steps; an odd last half is zeros)
   extern __shared__ __attribute__((aligned(16))) float wl[];
@@ -95,9 +97,9 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
     const int64_t row = b * 16 + i;
     const bool rv = b < nrb && row < M;
 #pragma unroll
-    for (int qq = 0; qq < KQ; ++qq) dst[qq] = rv ? *reinterpret_cast<const float4*>(x + row * ldx + 16 * qq + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int qq = 0; qq < KQ; ++qq) dst[qq] = rv ? Io<AT>::ld4(x + row * ldx + 16 * qq + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
-  const bool vec_ok = (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
+  const bool vec_ok = (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & (4 * sizeof(CT) - 1)) == 0 && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
   constexpr bool kPrefetch = KQ < 16 && NB < 16;   // the widest variants have no registers to spare for a second row block
   const float inv = 1.0f / (q_sa * q_sb);
   fetch(rb, xa);
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
             const int r = (lane >> 4) + 4 * t;
             const int64_t orow = rb * 16 + r;
             const float4 v = *reinterpret_cast<const float4*>(tb + r * kTStride + (lane & 15) * 4);
-            if (orow < M) *reinterpret_cast<float4*>(y + orow * ldy + col) = make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
+            if (orow < M) Io<CT>::st4(y + orow * ldy + col, make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w));
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
           const int n = cb * 16 + kk * 4;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (n + r < N) y[orow * ldy + n + r] = acc[cb][r] + (bias ? bias[n + r] : 0.f);
+            if (n + r < N) Io<CT>::st(y + orow * ldy + n + r, acc[cb][r] + (bias ? bias[n + r] : 0.f));
         }
       }
     }
@@ -209,8 +211,8 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const float* __restri
 
 // ---------------------------------------------------------------------------------------------- tn: dW = dY^T . X
 // part[blockIdx.x][n][k]; A = dY^T (16 n x 4 m), B = X (4 m x 16 k)
-template <int NBN, int NBK>
-__global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+template <int NBN, int NBK, typename YT, typename XT>
+__global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const YT* __restrict__ dy, int64_t lddy, const XT* __restrict__ x,
                                                            int64_t ldx, float* __restrict__ part, float* __restrict__ bpart, int64_t M,
                                                            int N, int K) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // 4 x (NBN*NBK*256 + NBN*16)
@@ -234,12 +236,12 @@ __global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const float* __restri
 #pragma unroll
     for (int a = 0; a < NBN; ++a) {
       const int n = nb0 + a * 16 + i;
-      a_[a] = (mv && n < N) ? dy[m * lddy + n] : 0.f;
+      a_[a] = (mv && n < N) ? Io<YT>::ld(dy + m * lddy + n) : 0.f;
     }
 #pragma unroll
     for (int b = 0; b < NBK; ++b) {
       const int k = b * 16 + i;
-      b_[b] = (mv && k < K) ? x[m * ldx + k] : 0.f;
+      b_[b] = (mv && k < K) ? Io<XT>::ld(x + m * ldx + k) : 0.f;
     }
   };
   int64_t mb = (int64_t)blockIdx.x * kWaves + wave;
@@ -330,33 +332,45 @@ int tn_blocks(int64_t M) {
 }
 
 template <int KQ, int NB>
-int launch_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, float* y, int64_t ldy, int64_t M,
-               int N, int K, int prec, AdnmQuant* q, hipStream_t st) {
+int launch_nt(const void* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, void* y, int64_t ldy, int64_t M,
+               int N, int K, int prec, AdnmQuant* q, int a_bf16, int c_bf16, hipStream_t st) {
   const bool narrow = prec != ADNM_MFMA_F32;
   const size_t entries = narrow ? (size_t)NB * ((KQ + 1) / 2) * 64 : (size_t)NB * (K / 4) * 64;
   const size_t wbytes = (entries * (prec == ADNM_MFMA_F32 ? 4 : (prec == ADNM_MFMA_BF16 ? 16 : 8)) + 15) / 16 * 16;
   const size_t smem = wbytes + (size_t)kWaves * 16 * 68 * sizeof(float);   // weight image + one 16 x 64 output staging tile per wave
-  ADNM_PROF("tsgemm_nt", st, 4.0 * ((double)M * (K + N) + (double)N * K));
-#define TS_GO(PRECV, BF8V)                                                                                                               \
+  ADNM_PROF("tsgemm_nt", st, (double)M * (K * (a_bf16 ? 2.0 : 4.0) + N * (c_bf16 ? 2.0 : 4.0)) + 4.0 * (double)N * K);
+#define TS_GO(PRECV, BF8V, ATV, CTV)                                                                                                     \
   do {                                                                                                                                   \
-    ADNM_ALLOW_LDS((tsgemm_nt_kernel<KQ, NB, PRECV, BF8V>), smem, "tsgemm_nt"); /* > 64 KB of dynamic LDS for the widest weights */      \
-    tsgemm_nt_kernel<KQ, NB, PRECV, BF8V><<<nt_blocks(M, narrow), kBlock, smem, st>>>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, N, K, q);   \
+    ADNM_ALLOW_LDS((tsgemm_nt_kernel<KQ, NB, PRECV, BF8V, ATV, CTV>), smem, "tsgemm_nt"); /* > 64 KB of dynamic LDS for the widest weights */ \
+    tsgemm_nt_kernel<KQ, NB, PRECV, BF8V, ATV, CTV><<<nt_blocks(M, narrow), kBlock, smem, st>>>((const ATV*)x, ldx, w, ws_n, ws_k, bias, (CTV*)y, ldy, M, N, K, q); \
   } while (0)
-  if (prec == ADNM_MFMA_BF16) TS_GO(ADNM_MFMA_BF16, false);
-  else if (prec == ADNM_MFMA_FP8) TS_GO(ADNM_MFMA_FP8, false);
-  else if (prec == ADNM_MFMA_FP8_GRAD) TS_GO(ADNM_MFMA_FP8, true);
-  else TS_GO(ADNM_MFMA_F32, false);
+  if (a_bf16 || c_bf16) {   // bf16 token storage exists for the bf16 matrix-core precision only (host-checked)
+    if (a_bf16 && c_bf16) TS_GO(ADNM_MFMA_BF16, false, uint16_t, uint16_t);
+    else if (a_bf16) TS_GO(ADNM_MFMA_BF16, false, uint16_t, float);
+    else TS_GO(ADNM_MFMA_BF16, false, float, uint16_t);
+  } else if (prec == ADNM_MFMA_BF16) TS_GO(ADNM_MFMA_BF16, false, float, float);
+  else if (prec == ADNM_MFMA_FP8) TS_GO(ADNM_MFMA_FP8, false, float, float);
+  else if (prec == ADNM_MFMA_FP8_GRAD) TS_GO(ADNM_MFMA_FP8, true, float, float);
+  else TS_GO(ADNM_MFMA_F32, false, float, float);
 #undef TS_GO
   return ADNM_OK;
 }
 
 template <int NBN, int NBK>
-int launch_tn(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* part, float* bpart, int64_t M, int N, int K, int nblk,
-               int ntiles, hipStream_t st) {
+int launch_tn(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* part, float* bpart, int64_t M, int N, int K, int nblk,
+               int ntiles, int y_bf16, int x_bf16, hipStream_t st) {
   const size_t smem = (size_t)(kWaves / 2) * (NBN * NBK * 256 + NBN * 16) * sizeof(float);
-  ADNM_ALLOW_LDS((tsgemm_tn_kernel<NBN, NBK>), smem, "tsgemm_tn");   // > 64 KB of dynamic LDS: per-device opt-in (host-side attribute)
-  ADNM_PROF("tsgemm_tn", st, 4.0 * ((double)M * (K + N) + (double)N * K));
-  tsgemm_tn_kernel<NBN, NBK><<<dim3(nblk, ntiles), kBlock, smem, st>>>(dy, lddy, x, ldx, part, bpart, M, N, K);
+  ADNM_PROF("tsgemm_tn", st, (double)M * (K * (x_bf16 ? 2.0 : 4.0) + N * (y_bf16 ? 2.0 : 4.0)) + 4.0 * (double)N * K);
+#define TN_GO(YTV, XTV)                                                                                                              \
+  do {                                                                                                                               \
+    ADNM_ALLOW_LDS((tsgemm_tn_kernel<NBN, NBK, YTV, XTV>), smem, "tsgemm_tn"); /* > 64 KB of dynamic LDS: per-device opt-in */         \
+    tsgemm_tn_kernel<NBN, NBK, YTV, XTV><<<dim3(nblk, ntiles), kBlock, smem, st>>>((const YTV*)dy, lddy, (const XTV*)x, ldx, part, bpart, M, N, K); \
+  } while (0)
+  if (y_bf16 && x_bf16) TN_GO(uint16_t, uint16_t);
+  else if (y_bf16) TN_GO(uint16_t, float);
+  else if (x_bf16) TN_GO(float, uint16_t);
+  else TN_GO(float, float);
+#undef TN_GO
   return ADNM_OK;
 }
 
@@ -389,21 +403,24 @@ extern "C" int adnm_tsgemm_supported(int64_t M, int64_t N, int64_t K) {
 }
 
 // Y[M,N] = X[M,K] . Wp^T (+bias), Wp[n][k] = w[n*ws_n + k*ws_k].  K % 16 == 0, K <= 256, N <= 256.
-extern "C" int adnm_tsgemm_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, float* y,
-                              int64_t ldy, int64_t M, int64_t N, int64_t K, int prec, float* q, adnm_stream_t stream) {
+extern "C" int adnm_tsgemm_nt(const void* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, void* y,
+                              int64_t ldy, int64_t M, int64_t N, int64_t K, int prec, float* q, int x_dtype, int y_dtype, adnm_stream_t stream) {
   ADNM_REQUIRE(x && w && y, "tsgemm_nt: null pointer");
   ADNM_REQUIRE(prec >= ADNM_MFMA_F32 && prec <= ADNM_MFMA_FP8_GRAD, "tsgemm_nt: bad prec %d", prec);
   ADNM_REQUIRE((prec != ADNM_MFMA_FP8 && prec != ADNM_MFMA_FP8_GRAD) || q, "tsgemm_nt: the fp8 modes need a quantisation record");
   ADNM_REQUIRE(adnm_tsgemm_supported(M, N, K), "tsgemm_nt: unsupported shape M=%lld N=%lld K=%lld (need K%%16==0, K<=256, N<=256)", (long long)M,
                (long long)N, (long long)K);
   ADNM_REQUIRE(ldx >= K && ldx % 4 == 0 && ldy >= N, "tsgemm_nt: bad row strides");
+  ADNM_REQUIRE((x_dtype == ADNM_F32 || x_dtype == ADNM_BF16) && (y_dtype == ADNM_F32 || y_dtype == ADNM_BF16), "tsgemm_nt: bad storage dtype");
+  ADNM_REQUIRE((x_dtype == ADNM_F32 && y_dtype == ADNM_F32) || prec == ADNM_MFMA_BF16, "tsgemm_nt: bf16 token storage needs prec = ADNM_MFMA_BF16");
+  ADNM_REQUIRE(((uintptr_t)x & (x_dtype == ADNM_BF16 ? 7 : 15)) == 0, "tsgemm_nt: input rows must be aligned to 4 elements");
   const int kq = pick((int)(K / 16), kKQ, 6), nb = pick((int)adnm_cdiv(N, 16), kNB, 6);
   ADNM_REQUIRE(kq == K / 16, "tsgemm_nt: K/16=%lld not in {1,2,4,8,13,16}", (long long)(K / 16));
   hipStream_t st = (hipStream_t)stream;
   // only the variants adnm_tsgemm_supported admits (N*K <= 8192, i.e. KQ*NB <= 32 blocks: <= 64 accumulator + 64 operand VGPRs,
   // no scratch) are instantiated
   int rc = ADNM_EINVAL;
-#define NT(KQ, NB) if (kq == KQ && nb == NB) rc = launch_nt<KQ, NB>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, (int)N, (int)K, prec, reinterpret_cast<AdnmQuant*>(q), st)
+#define NT(KQ, NB) if (kq == KQ && nb == NB) rc = launch_nt<KQ, NB>(x, ldx, w, ws_n, ws_k, bias, y, ldy, M, (int)N, (int)K, prec, reinterpret_cast<AdnmQuant*>(q), x_dtype == ADNM_BF16, y_dtype == ADNM_BF16, st)
   NT(1, 1); NT(1, 2); NT(1, 4); NT(1, 8); NT(1, 13); NT(1, 16);
   NT(2, 1); NT(2, 2); NT(2, 4); NT(2, 8); NT(2, 13); NT(2, 16);
   NT(4, 1); NT(4, 2); NT(4, 4); NT(4, 8);
@@ -424,11 +441,12 @@ extern "C" int adnm_tsgemm_tn_supported(int64_t M, int64_t N, int64_t K) {
 extern "C" int64_t adnm_tsgemm_tn_ws_bytes(int64_t M, int64_t N, int64_t K) { return (int64_t)tn_blocks(M) * (N * K + N) * (int64_t)sizeof(float); }
 
 // dW[N,K] = dY[M,N]^T . X[M,K]  (+ dbias[N] = column sums of dY when dbias != NULL).  OVERWRITES dW / dbias.
-extern "C" int adnm_tsgemm_tn(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* dbias, void* ws, int64_t ws_bytes,
-                              int64_t M, int64_t N, int64_t K, adnm_stream_t stream) {
+extern "C" int adnm_tsgemm_tn(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, float* dbias, void* ws, int64_t ws_bytes,
+                              int64_t M, int64_t N, int64_t K, int dy_dtype, int x_dtype, adnm_stream_t stream) {
   ADNM_REQUIRE(dy && x && dw, "tsgemm_tn: null pointer");
   ADNM_REQUIRE(adnm_tsgemm_tn_supported(M, N, K), "tsgemm_tn: unsupported shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   ADNM_REQUIRE(lddy >= N && ldx >= K, "tsgemm_tn: bad row strides");
+  ADNM_REQUIRE((dy_dtype == ADNM_F32 || dy_dtype == ADNM_BF16) && (x_dtype == ADNM_F32 || x_dtype == ADNM_BF16), "tsgemm_tn: bad storage dtype");
   if (!ws || ws_bytes < adnm_tsgemm_tn_ws_bytes(M, N, K)) {
     adnm_set_error("tsgemm_tn: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_tsgemm_tn_ws_bytes(M, N, K));
     return ADNM_EWORKSPACE;
@@ -446,7 +464,7 @@ extern "C" int adnm_tsgemm_tn(const float* dy, int64_t lddy, const float* x, int
   float* bpart = dbias ? part : nullptr;   // non-null = "emit the bias sums at the end of every partial row"
   hipStream_t st = (hipStream_t)stream;
   int rc = ADNM_EINVAL;
-#define TN(A, B) if (a == A && b == B) rc = launch_tn<A, B>(dy, lddy, x, ldx, part, bpart, M, (int)N, (int)K, nblk, ntiles, st)
+#define TN(A, B) if (a == A && b == B) rc = launch_tn<A, B>(dy, lddy, x, ldx, part, bpart, M, (int)N, (int)K, nblk, ntiles, dy_dtype == ADNM_BF16, x_dtype == ADNM_BF16, st)
   TN(1, 1); TN(1, 2); TN(1, 4); TN(1, 8); TN(1, 13); TN(1, 16); TN(2, 1); TN(2, 2); TN(2, 4); TN(2, 8); TN(2, 13);
   TN(4, 1); TN(4, 2); TN(4, 4); TN(8, 1); TN(8, 2); TN(13, 1); TN(13, 2); TN(16, 1);
 #undef TN

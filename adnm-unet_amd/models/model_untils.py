@@ -321,10 +321,10 @@ class FeedForward(nn.Module):
         self.project_out = Conv2dLayer(hidden, dim, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0), bias=bias)
 
     def forward_tokens(self, x, h, w):
-        x = self.project_in.forward_tokens(x, h, w)
-        x = self.dwconv.forward_tokens(x, h, w)
-        x = ops.gate(x)   # gelu(x1) * sigmoid(x2): the kernel rejects widths that are not multiples of 8
-        return self.project_out.forward_tokens(x, h, w)
+        """the whole chain as one autograd node (ops.FeedForwardFn): GEMM, HIP stencil, HIP gate, GEMM"""
+        pi, dc, po = self.project_in.conv, self.dwconv.conv, self.project_out.conv
+        return ops.feedforward(x, pi.weight.reshape(pi.out_channels, -1), pi.bias, dc.weight, dc.bias, po.weight.reshape(po.out_channels, -1), po.bias,
+                               h, w)
 
     def forward(self, x):
         b, c, h, w = x.shape

@@ -468,12 +468,14 @@ int adnm_cast_bf16_f32(const void* src, void* dst, int64_t n, float scale, adnm_
  *   tn: dW[N,K] = dY[M,N]^T . X[M,K], dbias[N] = column sums of dY (NULL skips); OVERWRITTEN; ws from *_ws_bytes.
  * *_supported() return 1 when the shape fits the kernels (callers use the library GEMM otherwise). */
 int adnm_tsgemm_supported(int64_t M, int64_t N, int64_t K);
-int adnm_tsgemm_nt(const float* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, float* y,
-                   int64_t ldy, int64_t M, int64_t N, int64_t K, int prec, float* q, adnm_stream_t stream);
+/* x_dtype / y_dtype (ADNM_F32 | ADNM_BF16): storage type of the token rows read / written; bf16 storage needs prec = ADNM_MFMA_BF16
+ * (the wide intermediates of the full-resolution level are kept in bf16 in the bf16 configuration: half the bytes). */
+int adnm_tsgemm_nt(const void* x, int64_t ldx, const float* w, int64_t ws_n, int64_t ws_k, const float* bias, void* y,
+                   int64_t ldy, int64_t M, int64_t N, int64_t K, int prec, float* q, int x_dtype, int y_dtype, adnm_stream_t stream);
 int adnm_tsgemm_tn_supported(int64_t M, int64_t N, int64_t K);
 int64_t adnm_tsgemm_tn_ws_bytes(int64_t M, int64_t N, int64_t K);
-int adnm_tsgemm_tn(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* dbias, void* ws,
-                   int64_t ws_bytes, int64_t M, int64_t N, int64_t K, adnm_stream_t stream);
+int adnm_tsgemm_tn(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, float* dbias, void* ws,
+                   int64_t ws_bytes, int64_t M, int64_t N, int64_t K, int dy_dtype, int x_dtype, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- parameter-side preparation (one launch each way)
  * ADN-SSD mixer: reference-layout parameters -> kernel-layout tensors (row-permuted in_proj, effective 3x3 taps of

@@ -933,3 +933,27 @@ def test_chanpad_roundtrip():
     cot = T("cp.c", (3, 50, 5)).to(DEV)
     (z * cot).sum().backward()
     assert torch.equal(xg.grad, cot)
+
+
+@pytest.mark.parametrize("M,K,N", [(65536, 32, 208), (65536, 128, 32), (40000, 208, 32)])
+def test_tsgemm_bf16_token_storage(M, K, N, bf16_mfma):
+    """the tall-skinny kernels with bf16 token rows in and / or out (the wide internal tensors of ADNMixerFn / FeedForwardFn at the
+    full-resolution level): the result is the fp32-accumulated product of the bf16 inputs, rounded once (RNE) when stored as bf16"""
+    x, w, cot = T(f"tbs.x{M}{K}", (M, K)), T(f"tbs.w{N}{K}", (N, K), 0.05), T(f"tbs.c{M}{N}", (M, N))
+    xb, cb = x.to(torch.bfloat16).to(DEV), cot.to(torch.bfloat16).to(DEV)
+    wd = w.to(DEV)
+    ref = (xb.double() @ _bf16_round(w).double().to(DEV).t())
+    y32 = ops.k_linear(xb, wd, None, out_dtype=torch.float32)             # bf16 rows in, fp32 out
+    assert y32.dtype == torch.float32
+    assert_close(y32, ref, 2e-6, "bf16 in / fp32 out")
+    y16 = ops.k_linear(x.to(DEV), wd, None, out_dtype=torch.bfloat16)     # fp32 rows in, bf16 out
+    assert y16.dtype == torch.bfloat16
+    ref2 = _bf16_round(x).double().to(DEV) @ _bf16_round(w).double().to(DEV).t()
+    assert_close(y16.double(), ref2, 4e-3, "fp32 in / bf16 out (one rounding to bf16)")
+    assert torch.equal(y16, ops.k_linear(x.to(DEV), wd, None, out_dtype=torch.float32).to(torch.bfloat16)), "the bf16 result is the fp32 result rounded once"
+    dx = ops.k_linear_dx(cb, wd, out_dtype=torch.float32)                 # bf16 gradient rows in
+    assert_close(dx, cb.double() @ _bf16_round(w).double().to(DEV), 2e-6, "dx from bf16 rows")
+    dw, _ = ops.k_linear_dw(cb, xb, False)                                # both operands bf16 rows, exact fp32 products
+    assert_close(dw, cb.double().t() @ xb.double(), 1e-5, "dw from bf16 rows")
+    dw2, _ = ops.k_linear_dw(cot.to(DEV), xb, False)                      # mixed: fp32 gradient rows, bf16 activations
+    assert_close(dw2, cot.double().to(DEV).t() @ xb.double(), 1e-5, "dw from fp32 x bf16 rows")
