@@ -1560,9 +1560,12 @@ def low_storage(M, shapes):
     """torch.bfloat16 when the wide INTERNAL tensors of a fused node (ADNMixerFn, FeedForwardFn) over M token rows may be kept in bf16,
     else torch.float32: the matrix-core precision of these GEMMs is bf16 (so the values are rounded to bf16 on their way into the MFMA
     anyway), every GEMM of the node — shapes = [(N, K), ...] — runs on the tall-skinny kernel (the only GEMM kernel with bf16 token
-    I/O: the full-resolution level, where these kernels are bound by exactly those bytes), and ADNM_BF16_STORAGE != 0.  The node's
-    inputs, outputs and parameter gradients stay fp32."""
-    if MFMA_PREC[0] == 0 or M < TS_MIN_ROWS or os.environ.get("ADNM_BF16_STORAGE", "1") == "0":
+    I/O: the full-resolution level), and ADNM_BF16_STORAGE=1.  The node's inputs, outputs and parameter gradients stay fp32.
+    OFF by default: measured on MI355X at config 2 (profiles/r03_bf16_storage_ab.txt) the step is 0.2 ms SLOWER with it (9.78 vs 9.56 ms) —
+    the full-resolution kernels are bound by load issue / latency, not by HBM bytes: halving the bytes leaves the stencils, K1 and the
+    forward GEMMs where they were (+-0.02 ms each) and the element-per-lane loaders of the weight-gradient kernels (tsgemm_tn,
+    dwconv_wgrad3_roll) get slower on 2-byte elements (+0.18 / +0.13 ms).  The paths stay (tested) for kernels that move 16 B of bf16 per lane."""
+    if MFMA_PREC[0] == 0 or M < TS_MIN_ROWS or os.environ.get("ADNM_BF16_STORAGE", "0") != "1":
         return torch.float32
     if MFMA_PREC[0] == 2 and M <= QUANT.max_rows:   # fp8 operands for this many rows: fp32 storage, quantised on load
         return torch.float32
