@@ -1,14 +1,16 @@
 """The training step around the hot path, MI355X-style:
 
-    [hipGraph A]   forward -> loss -> backward of the LATE stage (refiner + decoder)  -> its gradients land in flat_g[0:n_late]
-    [RCCL]         all-reduce of flat_g[0:n_late] on RCCL's stream over xGMI ..........  runs beside:
-    [hipGraph B]   backward of the EARLY stage (encoder)                               -> flat_g[n_late:n]
-    [RCCL]         all-reduce of flat_g[n_late:n]
+    [hipGraph 0]   forward -> loss -> backward of the LAST stage (refiner)       -> its gradients land in flat_g[bucket 0]
+    [RCCL]         all-reduce of bucket 0 on RCCL's stream over xGMI ............  runs beside:
+    [hipGraph 1]   backward of the stage before it (decoder blocks)             -> flat_g[bucket 1]
+    [RCCL]         all-reduce of bucket 1 ........................................  beside graph 2 (e2ds + fusion), and so on down to the
+    [hipGraph K-1] backward of the FIRST stage (encoder1-3)                     -> the last, smallest bucket: the only exposed all-reduce
     [3 HIP launches]   global grad-norm, clip_grad_norm_ scaling, AdamW on flat p / g / m / v
 
 replacing the reference's nn.DataParallel scatter/replicate/gather (train.py:99-102), its per-tensor
 clip_grad_norm_ (train.py:140) and torch.optim.AdamW over 669 tensors (train_untils.py:35-42).  On one GPU (or with
-overlap=False) graphs A and B are ONE graph and there is one bucket.
+overlap=False) there is ONE graph and one bucket.  The stage cuts come from the model (forward_stages(): SURVEY.md §8e's order
+refiner -> decoder -> e2ds / fusion -> encoder4-6 -> encoder1-3; or the older two-stage forward_stage1 / forward_stage2).
 
   * Parameters that receive gradients are re-homed as views into one flat buffer (state_dict unchanged), so the
     optimiser is a single streaming kernel and the gradient collective is a few LARGE messages in reverse execution order
@@ -48,10 +50,12 @@ class _Both:
 
 class FlatTrainer:
     def __init__(self, model, loss_fn, lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2, max_norm=0.0,
-                 process_group=None, use_graph=True, fused=True, overlap="auto", reduce_dtype="f32", stages=None, defer_folds=True, side_stream=False):
-        """overlap: cut the backward at model.forward_stage1 / forward_stage2 (ADNM-UNet: encoder | decoder + refiner) and all-reduce
-        the late stage's gradients while the early stage's backward runs.  "auto" = whenever there is more than one rank.
-        `stages` is the older name of the same switch (True / False)."""
+                 process_group=None, use_graph=True, fused=True, overlap="auto", reduce_dtype="f32", stages=None, defer_folds=True, side_stream=False,
+                 nstages=None):
+        """overlap: cut the backward at the model's stage boundaries and all-reduce every stage's gradients while the backward of the
+        stages before it runs.  "auto" = whenever there is more than one rank.  `stages` is the older name of the same switch
+        (True / False).  nstages: None = every stage the model offers (forward_stages(): 5 for ADNM-UNet); 2 = the two-stage cut
+        (encoder | decoder + refiner)."""
         self.model, self.loss_fn = model, loss_fn
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.group = process_group
@@ -59,8 +63,26 @@ class FlatTrainer:
         self.use_graph, self.fused = use_graph, fused
         if stages is not None:
             overlap = bool(stages) if stages != "auto" else "auto"
-        can_stage = hasattr(model, "forward_stage1") and hasattr(model, "forward_stage2") and hasattr(model, "stage1_parameters")
-        self.staged = can_stage and (self.world > 1 if overlap == "auto" else bool(overlap))
+        two = hasattr(model, "forward_stage1") and hasattr(model, "forward_stage2") and hasattr(model, "stage1_parameters")
+        multi = hasattr(model, "forward_stages")
+        self.staged = (two or multi) and (self.world > 1 if overlap == "auto" else bool(overlap))
+        self.stage_defs = None   # [(function, set of parameter ids)] in forward order
+        if self.staged:
+            if multi and nstages != 2:
+                defs = [(fn, {id(p) for m in mods for p in m.parameters()}) for fn, mods in model.forward_stages()]
+                if nstages is not None and nstages < len(defs):   # merge the FIRST stages (the last buckets) down to nstages
+                    k = len(defs) - nstages + 1
+                    fns, ids = [f for f, _ in defs[:k]], set().union(*[i for _, i in defs[:k]])
+
+                    def merged(*a, _fns=fns):
+                        for f in _fns:
+                            a = f(*a)
+                        return a
+                    defs = [(merged, ids)] + defs[k:]
+                self.stage_defs = defs
+            else:
+                first = {id(p) for p in model.stage1_parameters()}
+                self.stage_defs = [(model.forward_stage1, first), (model.forward_stage2, None)]   # None: every other parameter
         assert reduce_dtype in ("f32", "bf16")
         self.reduce_dtype = reduce_dtype
         self.defer_folds = defer_folds
@@ -70,7 +92,8 @@ class FlatTrainer:
         self.side_stream = side_stream
         self.used = None
         self.graph = self.graph2 = None
-        self.static_loss = self._carry = self.sx = self.st = None
+        self.graphs = []
+        self.static_loss = self._carry = self._cuts = self.sx = self.st = None
         self.flat_g = None
         self.buckets = []
         self._steps = 0
@@ -94,19 +117,34 @@ class FlatTrainer:
     @torch.no_grad()
     def _flatten(self):
         used = [p for p in self.model.parameters() if p.requires_grad and p.grad is not None]
-        self.late, self.early = used, []
-        if self.staged:   # flat layout [late-stage parameters | early-stage parameters]: each stage's gradients are one range
-            first = {id(p) for p in self.model.stage1_parameters()}
-            self.late = [p for p in used if id(p) not in first]
-            self.early = [p for p in used if id(p) in first]
-            used = self.late + self.early
+        # flat layout = the stages in BACKWARD order (last stage first): every stage's gradients are one contiguous range = one bucket,
+        # in the order the buckets become ready.  groups[j] = parameters of the j-th bucket.
+        groups = [used]
+        if self.staged:
+            K = len(self.stage_defs)
+            claimed = set().union(*[ids for _, ids in self.stage_defs if ids is not None])
+            groups = []
+            for k in range(K - 1, -1, -1):
+                ids = self.stage_defs[k][1]
+                groups.append([p for p in used if (id(p) in ids if ids is not None else id(p) not in claimed)])
+            left = {id(p) for p in used} - {id(p) for g in groups for p in g}
+            groups[0] += [p for p in used if id(p) in left]   # a parameter no stage names rides in the first bucket (ready first: safe only
+            used = [p for g in groups for p in g]             # if its gradient is complete there — the model's stage lists are exhaustive)
+        self.late, self.early = groups[0], [p for g in groups[1:] for p in g]
         dev, dt = used[0].device, used[0].dtype
-        offs, total = [], 0
+        offs, total, bounds = [], 0, []
+        starts = set()
+        n = 0
+        for g in groups:
+            starts.add(n)
+            n += len(g)
         for i, p in enumerate(used):
-            if i == len(self.late):
-                total = (total + 7) // 8 * 8  # the stage boundary is also a bucket boundary of the bf16 wire buffer (16-byte aligned there too)
+            if i in starts:
+                total = (total + 7) // 8 * 8  # a stage boundary is also a bucket boundary of the bf16 wire buffer (16-byte aligned there too)
+                bounds.append(total)
             offs.append(total)
             total += (p.numel() + 3) // 4 * 4  # keep every tensor 16-byte aligned inside the flat buffers
+        self.groups = groups
         self.flat_p = torch.zeros(total, dtype=dt, device=dev)
         self.flat_g = torch.zeros(total, dtype=dt, device=dev)
         self.exp_avg = torch.zeros(total, dtype=dt, device=dev)
@@ -132,9 +170,13 @@ class FlatTrainer:
             self.g_views.append(shaped(self.flat_g, o, p))
             p.grad = None
         self.used, self.n = used, total
-        self.n_late = offs[len(self.late)] if self.staged and self.early else total
-        # gradient buckets in the order they become ready (= the order they are all-reduced)
-        self.buckets = [(0, self.n_late)] + ([(self.n_late, total)] if self.n_late < total else [])
+        # gradient buckets in the order they become ready (= the order they are all-reduced); an empty stage leaves an empty bucket
+        self.buckets = [(bounds[j], bounds[j + 1] if j + 1 < len(bounds) else total) for j in range(len(bounds))]
+        self.n_late = self.buckets[0][1]
+        self.group_ranges, lo = [], 0
+        for g in groups:
+            self.group_ranges.append((lo, lo + len(g)))
+            lo += len(g)
         if self.world > 1 and self.reduce_dtype == "bf16":
             self.comm = torch.empty(total, dtype=torch.bfloat16, device=dev)
         # backward functions that allocate parameter gradients write them straight into these slices (ops.GRADS)
@@ -150,10 +192,11 @@ class FlatTrainer:
         were finalised by the cyclic GC in the middle of a NEW trainer's warm-up / stream capture: destroying a hipGraph (and
         freeing its private pool) while another capture is in flight on the device is not allowed by the runtime.  prepare()
         therefore also collects BEFORE it starts and keeps the collector off until both captures have ended."""
+        self.graphs = []
         self.graph2 = None
         self.graph = None
         self.static_loss = None
-        self._carry = None
+        self._carry = self._cuts = None
         self.sx = self.st = None
         try:
             ops.GRADS.drop(id(self))   # lock-free for a finaliser: queued, drained by the next register / take
@@ -176,38 +219,52 @@ class FlatTrainer:
         if pairs:
             torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
 
-    # two-stage backward: A = forward + backward of the late stage (down to the cut), B = backward of the early stage
-    def _stage_a(self, x, tgt):
+    # staged backward.  part 0 = the whole forward + the backward of the LAST stage (down to its input cut); part j = the backward of
+    # stage K-1-j, started from the gradients the part before left at its output cut.
+    def _stage_part0(self, x, tgt):
         ops.GRADS.reset_claims(id(self))
-        cut = self.model.forward_stage1(x)
-        # a true cut: the late stage runs on detached twins, so stage A's backward stops there (a skip tensor also reaches the loss
-        # THROUGH the rest of the encoder; that path belongs to stage B, which starts from the originals with the twins' gradients)
-        twins, origs, args = {}, [], []
-        for t in cut:
-            if torch.is_tensor(t) and t.requires_grad:
-                if id(t) not in twins:   # a tensor handed over twice gets one twin, so its gradient is the sum over both uses
-                    twins[id(t)] = t.detach().requires_grad_(True)
-                    origs.append(t)
-                args.append(twins[id(t)])
-            else:
-                args.append(t)
-        loss = self.loss_fn(self.model.forward_stage2(*args), tgt)
-        uniq = [twins[id(t)] for t in origs]
-        # backward(inputs=...) accumulates through the ordinary AccumulateGrad path (which keeps a fresh gradient without copying it;
-        # autograd.grad() was measured to cost ~290 extra device copies per step here)
-        for t in uniq:
-            t.grad = None
-        with self._deferred():
-            torch.autograd.backward(loss, inputs=self.late + uniq)
-        self._carry = [(t, tw.grad) for t, tw in zip(origs, uniq) if tw.grad is not None]
-        self._gather(0, len(self.late))
+        K = len(self.stage_defs)
+        self._cuts = [None] * K   # stage k >= 1: (tensors the stage before produced, their detached twins)
+        args = (x,)
+        for k, (fn, _) in enumerate(self.stage_defs):
+            if k > 0:
+                # a true cut: the stage runs on detached twins, so a later stage's backward stops there (a skip tensor also reaches the
+                # loss THROUGH later layers of its own stage; that path belongs to the earlier part, which starts from the originals
+                # with the twins' gradients)
+                twins, origs, targs = {}, [], []
+                for t in args:
+                    if torch.is_tensor(t) and t.requires_grad:
+                        if id(t) not in twins:   # a tensor handed over twice gets one twin: its gradient is the sum over both uses
+                            twins[id(t)] = t.detach().requires_grad_(True)
+                            origs.append(t)
+                        targs.append(twins[id(t)])
+                    else:
+                        targs.append(t)
+                self._cuts[k] = (origs, [twins[id(t)] for t in origs])
+                args = tuple(targs)
+            args = fn(*args)
+            args = args if isinstance(args, tuple) else (args,)
+        loss = self.loss_fn(args[0], tgt)
+        self._backward_stage(K - 1, [loss], None)
         return loss
 
-    def _stage_b(self):
-        ts, gs = [t for t, _ in self._carry], [g for _, g in self._carry]
+    def _backward_stage(self, k, roots, grads):
+        """backward of stage k from `roots` (the loss, or the stage's outputs with the gradients carried over the cut) down to its own
+        parameters and the twins at its input cut; leaves the twins' gradients as the next part's carry"""
+        twins = self._cuts[k][1] if k > 0 else []
+        # backward(inputs=...) accumulates through the ordinary AccumulateGrad path (which keeps a fresh gradient without copying it;
+        # autograd.grad() was measured to cost ~290 extra device copies per step here)
+        for t in twins:
+            t.grad = None
+        j = len(self.stage_defs) - 1 - k
         with self._deferred():
-            torch.autograd.backward(ts, grad_tensors=gs, inputs=self.early)
-        self._gather(len(self.late), len(self.used))
+            torch.autograd.backward(roots, grad_tensors=grads, inputs=self.groups[j] + twins)
+        self._carry = [(o, tw.grad) for o, tw in zip(self._cuts[k][0], twins) if tw.grad is not None] if k > 0 else []
+        self._gather(*self.group_ranges[j])
+
+    def _stage_part(self, j):
+        k = len(self.stage_defs) - 1 - j
+        self._backward_stage(k, [t for t, _ in self._carry], [g for _, g in self._carry])
 
     def prepare(self, x, tgt):
         """Dry-run backward (finds the parameters that receive gradients), flatten, and capture the graph(s).
@@ -241,10 +298,11 @@ class FlatTrainer:
                     reg.abort(dev)
                 except Exception:
                     pass
+        self.graphs = []
         self.graph2 = None
         self.graph = None
         self.static_loss = None
-        self._carry = None
+        self._carry = self._cuts = None
 
     def _prepare(self, x, tgt):
         self.model.zero_grad(set_to_none=True)
@@ -294,20 +352,26 @@ class FlatTrainer:
                 self._gather()
         else:
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.static_loss = self._stage_a(self.sx, self.st)
-            self.graph2 = torch.cuda.CUDAGraph()   # same memory pool: stage B reads what stage A saved for it
-            with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode="thread_local"):
-                self._stage_b()
+                self.static_loss = self._stage_part0(self.sx, self.st)
+            self.graphs = []   # same memory pool: every part reads what the parts before saved for it
+            for j in range(1, len(self.stage_defs)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                    self._stage_part(j)
+                self.graphs.append(g)
+            self.graph2 = self.graphs[0] if self.graphs else None
 
     def _run_eager(self, x, tgt, between=None):
+        """between(j): called after part j (its bucket is complete) while parts remain — the N > 1 flow starts the bucket's all-reduce there"""
         if not self.staged:
             loss = self._fwd_bwd(x, tgt)
             self._gather()
             return loss
-        loss = self._stage_a(x, tgt)
-        if between is not None:
-            between()
-        self._stage_b()
+        loss = self._stage_part0(x, tgt)
+        for j in range(1, len(self.stage_defs)):
+            if between is not None:
+                between(j - 1)
+            self._stage_part(j)
         return loss
 
     # ------------------------------------------------------------------ the collective
@@ -350,6 +414,7 @@ class FlatTrainer:
         if self.used is None:
             self.prepare(x, tgt)
         pending = []
+        nb = len(self.buckets)
         if self.graph is not None and not eager:
             if x.data_ptr() != self.sx.data_ptr():
                 self.sx.copy_(x, non_blocking=True)
@@ -357,17 +422,17 @@ class FlatTrainer:
             self.graph.replay()
             self._reduce_begin(*self.buckets[0], pending)
             if self.staged:
-                self.graph2.replay()
-                if len(self.buckets) > 1:
-                    self._reduce_begin(*self.buckets[1], pending)
+                for j, g in enumerate(self.graphs, start=1):
+                    g.replay()
+                    if j < nb:
+                        self._reduce_begin(*self.buckets[j], pending)
             loss = self.static_loss
         else:
             for p in self.used:
                 p.grad = None
             if self.staged:
-                loss = self._run_eager(x, tgt, between=lambda: self._reduce_begin(*self.buckets[0], pending))
-                if len(self.buckets) > 1:
-                    self._reduce_begin(*self.buckets[1], pending)
+                loss = self._run_eager(x, tgt, between=lambda j: self._reduce_begin(*self.buckets[j], pending))
+                self._reduce_begin(*self.buckets[nb - 1], pending)
             else:
                 loss = self._run_eager(x, tgt)
                 self._reduce_begin(*self.buckets[0], pending)

@@ -189,6 +189,12 @@ class Encoder(nn.Module):
 
     def forward(self, x):
         """x: (B, T_in, H, W) -> (bottleneck tokens, [7 skips], last input frame) (ADNMUNet.py:437-483)."""
+        x, lo, res = self.forward_lo(x)
+        x, hi = self.forward_hi(x)
+        return x, lo + hi, res
+
+    # the same forward in two halves (a stage cut of adnm_hip.trainer.FlatTrainer): the conv stages down to 16x16, then the mixer stages
+    def forward_lo(self, x):
         x = x.flatten(2).transpose(1, 2)
         skips = []
         x, res = self.encoder1(x)
@@ -199,6 +205,10 @@ class Encoder(nn.Module):
         skips.append(x)
         x = self.attn(self.down_sample3(x))
         skips.append(x)
+        return x, skips, res
+
+    def forward_hi(self, x):
+        skips = []
         x = self.encoder4(x)
         skips.append(x)
         x = self.encoder5(self.down_sample4(x))
@@ -206,7 +216,13 @@ class Encoder(nn.Module):
         x = self.encoder6(self.down_sample5(x))
         skips.append(x)
         x = self.attn2(x)
-        return x, skips, res
+        return x, skips
+
+    def lo_modules(self):
+        return [self.encoder1, self.down_sample1, self.encoder2, self.down_sample2, self.encoder3, self.down_sample3, self.attn]
+
+    def hi_modules(self):
+        return [self.encoder4, self.down_sample4, self.encoder5, self.down_sample5, self.encoder6, self.attn2]
 
 
 class Decoder(nn.Module):
@@ -237,49 +253,39 @@ class Decoder(nn.Module):
         self.e2ds = nn.ModuleList([EncoderToDecoder(embed_dim=c_list[len(c_list) - 1 - i], InstanceNorm=InstanceNorm)
                                    for i in range(len(c_list))])
 
-    def _side_streams(self, x):
-        key = (x.device.index, torch.cuda.current_stream().cuda_stream)
-        cache = self.__dict__.setdefault("_streams", {})
-        if key not in cache:
-            cache[key] = (torch.cuda.Stream(device=x.device), torch.cuda.Stream(device=x.device))
-        return cache[key]
-
     def forward(self, x, skips):
         """(ADNMUNet.py:603-636 of the reference).  skips[i] = encoder_layer_residual[i]."""
+        skips, feats = self.forward_skips(skips)
+        return self.forward_blocks(x, skips, feats)
+
+    # the same forward in two halves (a stage cut of adnm_hip.trainer.FlatTrainer): the skip path (channel-attention bridge + the
+    # EncoderToDecoder gates), then the decoder blocks
+    def forward_skips(self, skips):
+        """-> (skip aliases, feats): feats[i] = e2ds[i](skip 6 - i) for the live branches (i < 3; all 7 with compute_dead_branches)."""
         dead = self.compute_dead_branches
         aliases = []
         gates = self.fusion(skips, live=None if dead else {4, 5, 6}, alias_out=aliases)
         skips = aliases   # same tensors; their gradients now meet the bridge pool's inside one kernel
-        feats = {}
-        feats[0] = self.e2ds[0](x=skips[6], res=gates[6])
-        # e2ds[1], e2ds[2] are only consumed by decoder2 / decoder3: run them on side streams so their ~100 tiny,
-        # latency-bound launches (and, through autograd, their backward) overlap the main chain; inside a hipGraph
-        # capture this becomes a fork/join in the graph.
-        # measured on MI355X: inside the captured graph the fork/join costs more than it hides (23.3 vs 20.2 ms/step),
-        # so the side streams stay off unless asked for
-        side = self._side_streams(x) if (x.is_cuda and getattr(self, "use_side_streams", False)) else None
-        for j, i in enumerate(range(1, 7 if dead else 3)):
-            if side is not None and i in (1, 2):
-                st = side[j]
-                st.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(st):
-                    feats[i] = self.e2ds[i](x=skips[6 - i], res=gates[6 - i])
-            else:
-                feats[i] = self.e2ds[i](x=skips[6 - i], res=gates[6 - i])
-        x = self.up_sample1(self.decoder1(x, features=feats[0]))
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side[0])
-            feats[1].record_stream(torch.cuda.current_stream())
-        x = self.up_sample2(self.decoder2(x, residual=skips[5], features=feats[1]))
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side[1])
-            feats[2].record_stream(torch.cuda.current_stream())
-        x = self.decoder3(x, residual=skips[4], features=feats[2])
+        feats = [self.e2ds[i](x=skips[6 - i], res=gates[6 - i]) for i in range(7 if dead else 3)]
+        return skips, feats
+
+    def forward_blocks(self, x, skips, feats):
+        f = lambda i: feats[i] if i < len(feats) else None
+        x = self.up_sample1(self.decoder1(x, features=f(0)))
+        x = self.up_sample2(self.decoder2(x, residual=skips[5], features=f(1)))
+        x = self.decoder3(x, residual=skips[4], features=f(2))
         x = self.up_sample3(self.attn(x))
-        x = self.up_sample4(self.decoder4(x, residual=skips[2], features=feats.get(4)))
-        x = self.up_sample5(self.decoder5(x, residual=skips[1], features=feats.get(5)))
-        x = self.decoder6(x, residual=skips[0], features=feats.get(6))
+        x = self.up_sample4(self.decoder4(x, residual=skips[2], features=f(4)))
+        x = self.up_sample5(self.decoder5(x, residual=skips[1], features=f(5)))
+        x = self.decoder6(x, residual=skips[0], features=f(6))
         return self.decoder6_s.forward_tokens(x, self.img_size, self.img_size)
+
+    def skip_modules(self):
+        return [self.fusion, self.e2ds]
+
+    def block_modules(self):
+        return [self.decoder1, self.up_sample1, self.decoder2, self.up_sample2, self.decoder3, self.attn, self.up_sample3, self.decoder4,
+                self.up_sample4, self.decoder5, self.up_sample5, self.decoder6, self.decoder6_s]
 
 
 class Refiner(nn.Module):
@@ -327,8 +333,38 @@ class VisionMamba(nn.Module):
         """x: (B, T_in, 1, H, W) float32 -> (B, T_out, 1, H, W) (ADNMUNet.py:824-829 of the reference)."""
         return self.forward_stage2(*self.forward_stage1(x))
 
-    # The same forward cut at the encoder / decoder boundary.  adnm_hip.trainer.FlatTrainer uses the cut for a two-stage
-    # backward on multi-GPU runs: the decoder + refiner gradients are all-reduced over xGMI while the encoder's backward runs.
+    # The same forward, cut into stages.  adnm_hip.trainer.FlatTrainer uses the cuts for a staged backward on multi-GPU runs: the gradients
+    # of a stage are all-reduced over xGMI while the backward of the stages before it runs (SURVEY.md §8e: refiner -> decoder ->
+    # e2ds / fusion -> encoder4-6 -> encoder1-3).  forward_stages() = [(function, modules whose parameters it owns), ...] in forward
+    # order; every function takes and returns a flat tuple of tensors.  forward_stage1 / forward_stage2 is the older two-stage form
+    # (encoder | decoder + refiner) of the same cut.
+    def forward_stages(self):
+        enc, dec = self.encoder, self.decoder
+
+        def s0(x):                      # encoder1-3 + attn: 128x128 .. 16x16 conv stages
+            ops.prep_group(*enc.lo_modules()) if x.is_cuda else None
+            x, skips, res = enc.forward_lo(x.squeeze(2))
+            return (x, res, *skips)
+
+        def s1(x, res, *lo):            # encoder4-6 + attn2: the mixer stages
+            ops.prep_group(*enc.hi_modules()) if x.is_cuda else None
+            x, hi = enc.forward_hi(x)
+            return (x, res, *lo, *hi)
+
+        def s2(x, res, *skips):         # channel-attention bridge + EncoderToDecoder gates
+            skips, feats = dec.forward_skips(list(skips))
+            return (x, res, *skips, *feats)
+
+        def s3(x, res, *rest):          # decoder blocks
+            ops.prep_group(*dec.block_modules()) if x.is_cuda else None
+            return (dec.forward_blocks(x, list(rest[:7]), list(rest[7:])), res)
+
+        def s4(x, res):                 # refiner + output head
+            ops.prep_group(self.refiner) if x.is_cuda else None
+            return (self.refiner(x, res).unsqueeze(2),)
+
+        return [(s0, enc.lo_modules()), (s1, enc.hi_modules()), (s2, dec.skip_modules()), (s3, dec.block_modules()), (s4, [self.refiner])]
+
     def forward_stage1(self, x):
         if x.is_cuda:
             ops.prep_group(self.encoder)   # kernel-layout parameters of all its mixers / WTConv2ds: one launch per kind

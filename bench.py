@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--overlap", type=int, default=-1,
                     help="gradient all-reduce overlapped with backward in bucket order (N>1): 1 on, 0 one blocking all-reduce after "
                          "backward, -1 (default) = on whenever N>1")
+    ap.add_argument("--stages", type=int, default=0, help="stage cuts of the overlapped backward: 0 = every stage the model offers (5), 2 = encoder | rest")
     ap.add_argument("--reduce-dtype", default="f32", choices=["f32", "bf16"], help="wire dtype of the gradient all-reduce (N>1)")
     ap.add_argument("--dump-prof", default="", help="write the per-(kernel, shape) HIP-event table of the instrumented steps to this file")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): replay fwd+bwd as captured hipGraphs; 0: eager launches")
@@ -315,7 +316,7 @@ def main():
     overlap = (world > 1) if args.overlap < 0 else bool(args.overlap)
     # AdamW recipe of train_untils.py:35-42; clip threshold = norm_max of the warm-up epochs (train.py:87,122-124)
     trainer = FlatTrainer(model, criterion, lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2, max_norm=0.025,
-                          use_graph=bool(args.graph), overlap=overlap, reduce_dtype=args.reduce_dtype)
+                          use_graph=bool(args.graph), overlap=overlap, reduce_dtype=args.reduce_dtype, nstages=args.stages or None)
     frames = recipe.radar_batch(args.batch, args.in_frames + args.out_frames, args.size, salt=rank, name="bench").to(dev)
     x, tgt = frames[:, :args.in_frames].contiguous(), frames[:, args.in_frames:].contiguous()
     trainer.prepare(x, tgt)

@@ -56,6 +56,36 @@ class Toy(nn.Module):
         return self.a.parameters()
 
 
+class Toy3(nn.Module):
+    """three stages through forward_stages() (the form ADNM-UNet offers: five stages); `skip` crosses TWO cuts unchanged, as the U-Net's
+    skip tensors do, and is used again in the last stage"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.a, self.m, self.b = nn.Linear(8, 16), nn.Linear(16, 16), nn.Linear(16, 4)
+        self.dead = nn.Linear(16, 16)
+        self.s = nn.Parameter(torch.tensor(1.0))
+
+    def forward(self, x):
+        a = (x,)
+        for fn, _ in self.forward_stages():
+            a = fn(*a)
+        return a[0]
+
+    def forward_stages(self):
+        s0 = lambda x: (torch.tanh(self.a(x)),)
+        s1 = lambda h: (torch.tanh(self.m(h)) + h, h)             # (new, skip)
+        s2 = lambda h, skip: (self.b(h + 0.5 * skip) * self.s,)
+        return [(s0, [self.a]), (s1, [self.m]), (s2, [self.b, _Holder(self.s)])]
+
+
+class _Holder(nn.Module):
+    def __init__(self, p):
+        super().__init__()
+        self.p = p
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -265,3 +295,99 @@ def test_flat_trainer_default_overlap_and_bf16_wire():
     for k in res[0]["final"]:
         assert torch.equal(res[0]["final"][k], res[1]["final"][k]), f"replicas diverged at {k}"
     assert torch.equal(res[0]["g"], res[1]["g"])
+
+
+def _trainer3_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adnm-unet_amd"))
+    from adnm_hip.trainer import FlatTrainer
+    model = Toy3()
+    tr = FlatTrainer(model, lambda o, t: (o - t).pow(2).mean(), lr=1e-2, eps=1e-9, weight_decay=1e-2, max_norm=0.5, use_graph=False, fused=False)
+    torch.manual_seed(100 + rank)
+    xs = [torch.randn(5, 8) for _ in range(3)]
+    ts = [torch.randn(5, 4) for _ in range(3)]
+    for x, t in zip(xs, ts):
+        tr.step(x, t)
+    assert tr.staged and len(tr.stage_defs) == 3 and len(tr.buckets) == 3
+    assert [len(g) for g in tr.groups] == [3, 2, 2]            # backward order: (b.weight, b.bias, s) | m | a
+    assert all(lo % 8 == 0 for lo, _ in tr.buckets)           # bucket boundaries are 16-byte aligned in the bf16 wire buffer too
+    q.put((rank, _plain({"final": {k: p.detach().clone() for k, p in model.named_parameters()}, "xs": xs, "ts": ts, "buckets": list(tr.buckets)})))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_trainer_three_stages_four_ranks():
+    """4 ranks x batch 5, staged backward over THREE stages (a bucket per stage, all-reduced while the earlier stages' backward runs)
+    == 1 process with the concatenated batch of 20; the bucket map is identical on every rank."""
+    world = 4
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer3_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: _torchify(o) for r, o in (q.get(timeout=180) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(1, world):
+        assert res[r]["buckets"] == res[0]["buckets"]
+        for k in res[0]["final"]:
+            assert torch.equal(res[0]["final"][k], res[r]["final"][k]), f"replicas diverged at {k}"
+    model = Toy3()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, eps=1e-9, weight_decay=1e-2)
+    for i in range(3):
+        x = torch.cat([res[r]["xs"][i] for r in range(world)])
+        t = torch.cat([res[r]["ts"][i] for r in range(world)])
+        (model(x) - t).pow(2).mean().backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    for k, p in model.named_parameters():
+        if k.startswith("dead"):
+            continue
+        assert torch.allclose(res[0]["final"][k], p, atol=2e-6, rtol=1e-5), k
+
+
+def test_real_model_bucket_map_is_deterministic():
+    """The flat layout / bucket map of the REAL model (669 used, 307 unused tensors at config 2; five stages in backward order:
+    refiner | decoder blocks | e2ds + fusion | encoder4-6 | encoder1-3), derived on the CPU from the reference fixture's list of
+    parameters that receive a gradient: identical for two independently built replicas, every tensor and every bucket boundary
+    16-byte aligned (fp32 and bf16 wire buffers), every used parameter in exactly one bucket."""
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "adnm-unet_amd"))
+    from adnm_hip.trainer import FlatTrainer
+    z = np.load(os.path.join(root, "tests", "golden", "visionmamba_64_b2.npz"), allow_pickle=False)
+    names, gn = [str(n) for n in z["names"]], z["grad_norms"]
+    used_names = {n for n, g in zip(names, gn) if g >= 0}
+
+    def plan():
+        from models.ADNMUNet import create_ADNMUNet
+        model = create_ADNMUNet(5, 20, 6, img_size=64)
+        for n, p in model.named_parameters():
+            p.grad = torch.zeros_like(p) if n in used_names else None      # a marker: _flatten only asks "is there a gradient"
+        tr = FlatTrainer(model, None, use_graph=False, fused=False, overlap=True)
+        tr._flatten()
+        name_of = {id(p): n for n, p in model.named_parameters()}
+        offs = {name_of[id(p)]: int((p.data_ptr() - tr.flat_p.data_ptr()) // 4) for p in tr.used}
+        return offs, list(tr.buckets), [len(g) for g in tr.groups], tr.n
+
+    a, b = plan(), plan()
+    assert a == b
+    offs, buckets, sizes, n = a
+    assert len(offs) == len(used_names) == 669 and sum(sizes) == 669 and len(buckets) == 5
+    assert all(o % 4 == 0 for o in offs.values()) and all(lo % 8 == 0 for lo, _ in buckets)
+    assert buckets[0][0] == 0 and buckets[-1][1] == n and all(buckets[i][1] <= buckets[i + 1][0] for i in range(4))
+    bucket_of = lambda o: next(i for i, (lo, hi) in enumerate(buckets) if lo <= o < hi)
+    assert bucket_of(offs["refiner.refiner1.mixer_layers.0.in_proj.weight"]) == 0
+    assert bucket_of(offs["decoder.decoder1.mixer_layers.0.in_proj.weight"]) == 1
+    assert bucket_of(offs["decoder.e2ds.0.ffd.project_in.conv.weight"]) == 2 and bucket_of(offs["decoder.fusion.att7.weight"]) == 2
+    assert bucket_of(offs["encoder.encoder6.mixer_layers.0.in_proj.weight"]) == 3 and bucket_of(offs["encoder.attn2.attn_mlp.fc1.weight"]) == 3
+    assert bucket_of(offs["encoder.encoder1.conv2.0.conv.weight"]) == 4 and bucket_of(offs["encoder.attn.attn_mlp.fc1.weight"]) == 4

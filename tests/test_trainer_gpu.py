@@ -70,8 +70,9 @@ def test_whole_model_step_vs_reference_fixture(use_graph, stages):
     loss = tr.step(x, tgt)
     assert abs(float(loss) - float(z["loss"])) <= 1e-4 * abs(float(z["loss"]))
     assert abs(float(tr.grad_norm()) - float(z["clip_pre_norm"])) <= 1e-3 * float(z["clip_pre_norm"])
-    if stages:
-        assert 0 < tr.n_late < tr.n and len(tr.early) > 100 and len(tr.late) > 100
+    if stages:   # five stages (refiner | decoder blocks | e2ds + fusion | encoder4-6 | encoder1-3): five graphs, five buckets
+        assert len(tr.stage_defs) == 5 and len(tr.buckets) == 5 and len(tr.graphs) == (4 if use_graph else 0)
+        assert 0 < tr.n_late < tr.n and all(len(g) > 20 for g in tr.groups)
     names, ref_sums, gn = [str(n) for n in z["names"]], z["param_sum_after_step"].numpy(), z["grad_norms"].numpy()
     named = dict(model.named_parameters())
     for i, k in enumerate(names):
