@@ -140,8 +140,8 @@ def test_deferred_folds_are_bitwise_neutral():
 
 def test_bf16_wire_casts_on_the_real_bucket_boundaries():
     """The bf16 wire format of the gradient all-reduce (reduce_dtype="bf16"): the HIP cast kernels need 16-byte aligned ranges on both
-    sides, so the stage boundary of the two-stage layout must fall on a multiple of 8 elements — checked on the benchmarked model's
-    real buckets, with the round trip through the wire buffer (a single process cannot run the collective itself)."""
+    sides, so every stage boundary of the staged layout must fall on a multiple of 8 elements — checked on the benchmarked model's
+    real five buckets, with the round trip through the wire buffer (a single process cannot run the collective itself)."""
     from models.ADNMUNet import create_ADNMUNet
     from models.loss import enRainfallLoss
     model = create_ADNMUNet(5, 20, 6, img_size=64)
@@ -152,15 +152,16 @@ def test_bf16_wire_casts_on_the_real_bucket_boundaries():
     tr = FlatTrainer(model, enRainfallLoss(0.57, 0.25, gamma=0.0), max_norm=0.025, use_graph=False, overlap=True, reduce_dtype="bf16")
     tr.prepare(x, tgt)
     tr._run_eager(x, tgt)
-    assert len(tr.buckets) == 2 and all(lo % 8 == 0 for lo, _ in tr.buckets)
-    comm = torch.empty(tr.n, dtype=torch.bfloat16, device=DEV)
+    assert len(tr.buckets) == 5 and all(lo % 8 == 0 for lo, _ in tr.buckets)
+    comm = torch.zeros(tr.n, dtype=torch.bfloat16, device=DEV)   # (zeros: the alignment gaps between buckets belong to no bucket)
     back = torch.empty_like(tr.flat_g)
     for lo, hi in tr.buckets:
         tr._cast(tr.flat_g[lo:hi], comm[lo:hi])
         tr._cast(comm[lo:hi], back[lo:hi], 0.5)
     torch.cuda.synchronize()
-    assert torch.equal(comm, tr.flat_g.to(torch.bfloat16))
-    assert torch.equal(back, comm.float() * 0.5)
+    for lo, hi in tr.buckets:
+        assert torch.equal(comm[lo:hi], tr.flat_g[lo:hi].to(torch.bfloat16))
+        assert torch.equal(back[lo:hi], comm[lo:hi].float() * 0.5)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
