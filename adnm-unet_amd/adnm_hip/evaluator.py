@@ -7,8 +7,10 @@ model.eval() under no_grad, copies every prediction to numpy and walks Simplifie
     csrc/dataio.hip::eval_counts) and only reads a (frames, 18) table back in done().
 
 GpuEvaluator mirrors SimplifiedEvaluator's surface: __init__(seq_len, value_scale, thresholds), evaluate(true_batch, pred_batch),
-done() -> {"threshold_metrics": {thr: TP, TN, FP, FN, CSI, POD, HSS}, "FAR", "RMSE", "SSIM", "LPIPS"}, reset().  SSIM (cv2) and
-LPIPS (a downloaded AlexNet) are outside the hot path and not reproduced: their entries are None."""
+done() -> {"threshold_metrics": {thr: TP, TN, FP, FN, CSI, POD, HSS}, "FAR", "RMSE", "SSIM", "LPIPS"}, reset().  SSIM is the reference's
+cal_ssim (Shanghai_metrics.py:132-152: 11x11 Gaussian windows, valid region, float64) as one HIP pass per batch (csrc/dataio.hip::eval_ssim),
+pinned by the reference's own code run with the two cv2 calls replaced by their documented formulas (cv2 is not installed in the build
+container).  LPIPS (a downloaded AlexNet) is outside the hot path and not reproduced: its entry is None."""
 import ctypes
 
 import numpy as np
@@ -59,6 +61,7 @@ class GpuEvaluator:
 
     def reset(self):
         self._tables = []   # one (B, T, 4*nthr+2) device tensor per evaluate() call
+        self._ssim = []     # one (B, T) device tensor of SSIM-map sums per evaluate() call (None for frames too small for the window)
         self.total = 0
 
     def evaluate(self, true_batch, pred_batch):
@@ -76,7 +79,15 @@ class GpuEvaluator:
         ws = torch.empty(max(int(nb), 16), dtype=torch.uint8, device=t.device)
         lib.call("adnm_eval_counts", t.data_ptr(), p.data_ptr(), out.data_ptr(), self._thr, nthr, self.value_scale, ws.data_ptr(), nb, B * T, H * W,
                  torch.cuda.current_stream().cuda_stream)
+        ssim = None
+        if H > 10 and W > 10:   # 11 x 11 windows need a valid region
+            ssim = torch.empty((B, T), dtype=torch.float32, device=t.device)
+            nb2 = lib.query("adnm_eval_ssim_ws_bytes", B * T, H, W)
+            ws2 = torch.empty(max(int(nb2), 16), dtype=torch.uint8, device=t.device)
+            lib.call("adnm_eval_ssim", t.data_ptr(), p.data_ptr(), ssim.data_ptr(), self.value_scale, ws2.data_ptr(), nb2, B * T, H, W,
+                     torch.cuda.current_stream().cuda_stream)
         self._tables.append((out, H * W))
+        self._ssim.append((ssim, (H - 10) * (W - 10)))
         self.total += B
 
     def done(self):
@@ -97,4 +108,6 @@ class GpuEvaluator:
                 metrics[key] = {"TP": TP, "TN": TN, "FP": FP, "FN": FN, "CSI": csi, "POD": pod, "HSS": hss}
             rmse = float(np.mean(np.sqrt(np.mean(mse, axis=0))))
         return {"threshold_metrics": metrics, "FAR": float(np.mean(all_far)), "RMSE": rmse, "MAE": float(mae.mean()), "MSE": float(mse.mean()),
-                "SSIM": None, "LPIPS": None}
+                "SSIM": (float(np.mean(np.concatenate([s.double().cpu().numpy() / area for s, area in self._ssim], axis=0)))
+                         if self._ssim and all(s is not None for s, _ in self._ssim) else None),
+                "LPIPS": None}

@@ -2016,6 +2016,39 @@ def igate(x, enhance, threshold):
     return IGateFn.apply(x, enhance, threshold)
 
 
+class EMulFn(torch.autograd.Function):
+    """a * b on (…, C) fp32 tokens (row views allowed): one HIP pass each way."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_gpu(a)
+        C = a.shape[-1]
+        a2, b2 = a.reshape(-1, C), b.reshape(-1, C)
+        a2 = a2 if a2.stride(-1) == 1 and a2.stride(0) % 4 == 0 else a2.contiguous()
+        b2 = b2 if b2.stride(-1) == 1 and b2.stride(0) % 4 == 0 else b2.contiguous()
+        y = torch.empty((a2.shape[0], C), dtype=torch.float32, device=a.device)
+        lib.call("adnm_emul_fwd", a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), y.data_ptr(), a2.shape[0], C, _stream())
+        ctx.save_for_backward(a2, b2)
+        ctx.shp = a.shape
+        return y.view(a.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a2, b2 = ctx.saved_tensors
+        M, C = a2.shape
+        g = dy.reshape(M, C)
+        g = g if g.is_contiguous() else g.contiguous()
+        da, db = torch.empty((M, C), dtype=torch.float32, device=g.device), torch.empty((M, C), dtype=torch.float32, device=g.device)
+        lib.call("adnm_emul_bwd", g.data_ptr(), a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), da.data_ptr(), db.data_ptr(), M, C, _stream())
+        return da.view(ctx.shp), db.view(ctx.shp)
+
+
+def emul(a, b):
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or a.shape != b.shape or a.shape[-1] % 4:
+        _unsupported("emul", f"needs two fp32 token tensors of one shape with 4 | C, got {a.dtype} {tuple(a.shape)}, {b.dtype} {tuple(b.shape)}")
+    return EMulFn.apply(a, b)
+
+
 class ChanPadFn(torch.autograd.Function):
     """(…, Cin) tokens -> (…, Cout): zero-padded (Cout > Cin) or cropped channels in one HIP pass; backward is the same kernel the other way."""
 

@@ -453,6 +453,48 @@ extern "C" int adnm_igate_res_bwd(const float* dy, const float* x, const float* 
   return ADNM_OK;
 }
 
+// Elementwise product of two token matrices (row strides lda / ldb): VSSD's gate LayerNorm(y) * z (Vssd.py:280-281), one pass each way.
+namespace {
+__global__ __launch_bounds__(kBlock) void emul_fwd_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                                                          float* __restrict__ y, int64_t M, int C4) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < M * C4; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t m = i / C4;
+    const int c = (int)(i - m * C4) * 4;
+    const float4 u = Io<float>::ld4(a + m * lda + c), v = Io<float>::ld4(b + m * ldb + c);
+    Io<float>::st4(y + i * 4, make_float4(u.x * v.x, u.y * v.y, u.z * v.z, u.w * v.w));
+  }
+}
+__global__ __launch_bounds__(kBlock) void emul_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ a, int64_t lda,
+                                                          const float* __restrict__ b, int64_t ldb, float* __restrict__ da, float* __restrict__ db,
+                                                          int64_t M, int C4) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < M * C4; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t m = i / C4;
+    const int c = (int)(i - m * C4) * 4;
+    const float4 g = Io<float>::ld4(dy + i * 4), u = Io<float>::ld4(a + m * lda + c), v = Io<float>::ld4(b + m * ldb + c);
+    Io<float>::st4(da + i * 4, make_float4(g.x * v.x, g.y * v.y, g.z * v.z, g.w * v.w));
+    Io<float>::st4(db + i * 4, make_float4(g.x * u.x, g.y * u.y, g.z * u.z, g.w * u.w));
+  }
+}
+}  // namespace
+
+extern "C" int adnm_emul_fwd(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t M, int64_t C, adnm_stream_t stream) {
+  ADNM_REQUIRE(a && b && y && M > 0 && C > 0 && C % 4 == 0 && lda >= C && ldb >= C && lda % 4 == 0 && ldb % 4 == 0, "emul_fwd: bad arguments (4 | C, 4 | strides)");
+  hipStream_t st = (hipStream_t)stream;
+  ADNM_PROF("emul_fwd", st, 12.0 * M * C);
+  emul_fwd_kernel<<<grid_for(M * C / 4), kBlock, 0, st>>>(a, lda, b, ldb, y, M, (int)(C / 4));
+  ADNM_CHECK_LAUNCH("emul_fwd");
+  return ADNM_OK;
+}
+extern "C" int adnm_emul_bwd(const float* dy, const float* a, int64_t lda, const float* b, int64_t ldb, float* da, float* db, int64_t M, int64_t C,
+                             adnm_stream_t stream) {
+  ADNM_REQUIRE(dy && a && b && da && db && M > 0 && C > 0 && C % 4 == 0 && lda >= C && ldb >= C && lda % 4 == 0 && ldb % 4 == 0, "emul_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  ADNM_PROF("emul_bwd", st, 20.0 * M * C);
+  emul_bwd_kernel<<<grid_for(M * C / 4), kBlock, 0, st>>>(dy, a, lda, b, ldb, da, db, M, (int)(C / 4));
+  ADNM_CHECK_LAUNCH("emul_bwd");
+  return ADNM_OK;
+}
+
 // Channel pad / crop of a token matrix: y[m, c] = x[m, c] for c < min(Cin, Cout), 0 for Cin <= c < Cout.  The 5-frame input stage is run on
 // 8 channels (every stencil kernel moves 16-byte channel quads): pad on the way in, crop on the way out, and each is the other's backward.
 namespace {

@@ -68,7 +68,7 @@ class Mamba2(nn.Module):
             raise NotImplementedError("only d_conv=3")
         b, l, _ = u.shape
         di, gn, nh = self.d_inner, self.ngroups * self.d_state, self.nheads
-        proj = self.in_proj(u)
+        proj = ops.linear(u, self.in_proj.weight, self.in_proj.bias)
         z, xBC, dt = proj[..., :di], proj[..., di:2 * di + 2 * gn], proj[..., 2 * di + 2 * gn:]
         xBC = ops.dwconv(xBC, self.conv2d.weight, self.conv2d.bias, H, W, lib.ACT_SILU)       # Vssd.py:232-234
         x = xBC[..., :di].reshape(b, l, nh, self.headdim)
@@ -88,5 +88,5 @@ class Mamba2(nn.Module):
                 halves.append(ops.ssd_scan(x[:, :, sl], Bm[..., gs], Cm[..., gs], dt[..., sl], self.dt_bias[sl], self.A_log[sl], self.D[sl],
                                            g2, int(self.chunk_size), e == 1))
             y = torch.cat(halves, dim=2)
-        y = ops.rownorm(y.reshape(b, l, di), self.norm.weight, self.norm.bias, None, None, self.norm.eps, True) * z  # :280-281
-        return self.out_proj(y)
+        y = ops.emul(ops.rownorm(y.reshape(b, l, di), self.norm.weight, self.norm.bias, None, None, self.norm.eps, True), z)  # :280-281
+        return ops.linear(y, self.out_proj.weight, self.out_proj.bias)

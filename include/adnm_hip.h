@@ -304,6 +304,11 @@ int adnm_attn4_bwd(const float* dout, const float* qkv, const float* out, const 
 int64_t adnm_tokmean_ws_bytes(int64_t B, int64_t L, int64_t C);
 int adnm_tokmean_fwd(const float* x, float* mean, void* ws, int64_t ws_bytes, int64_t B, int64_t L, int64_t C, adnm_stream_t stream);
 int adnm_tokmean_bwd(const float* dxa, const float* dmean, int64_t ldm, float* dx, int64_t B, int64_t L, int64_t C, adnm_stream_t stream);
+/* Elementwise product y = a * b of two (M, C) fp32 token matrices with row strides lda / ldb (y, da, db contiguous): VSSD's output gate
+ * LayerNorm(y) * z (Vssd.py:280-281).  4 | C. */
+int adnm_emul_fwd(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t M, int64_t C, adnm_stream_t stream);
+int adnm_emul_bwd(const float* dy, const float* a, int64_t lda, const float* b, int64_t ldb, float* da, float* db, int64_t M, int64_t C,
+                  adnm_stream_t stream);
 /* Channel pad / crop of a token matrix (row stride ldx): y[m, c] = x[m, c] for c < min(Cin, Cout), 0 for Cin <= c < Cout; y:(M, Cout)
  * contiguous.  The 5-frame input stage (PatchEmbed.conv1: WTConv2d on 5 channels, model_untils.py:259) runs on 8 channels; pad and crop
  * are each other's backward. */
@@ -441,6 +446,13 @@ int adnm_radar_ingest(const void* src_u8, float* dst, int64_t frames, int64_t H0
 int64_t adnm_eval_counts_ws_bytes(int64_t frames, int64_t hw, int64_t nthr);
 int adnm_eval_counts(const float* truth, const float* pred, float* out, const float* thresholds_host, int64_t nthr, float value_scale,
                      void* ws, int64_t ws_bytes, int64_t frames, int64_t hw, adnm_stream_t stream);
+/* adnm_eval_ssim: SimplifiedEvaluator.cal_ssim (datasets/Shanghai_metrics.py:132-152) — out[frame] = SUM over the valid (H-10) x (W-10)
+ * region of the SSIM map (11x11 Gaussian window, sigma 1.5, C1 = (0.01 s)^2, C2 = (0.03 s)^2, float64 arithmetic like the reference) of
+ * the [0,1]-clipped fields times value_scale s; the caller divides by the region's area (the reference takes the mean).  truth, pred:
+ * (frames, H, W) fp32 contiguous.  The window is the normalised sampled Gaussian cv2.getGaussianKernel(11, 1.5) documents. */
+int64_t adnm_eval_ssim_ws_bytes(int64_t frames, int64_t H, int64_t W);
+int adnm_eval_ssim(const float* truth, const float* pred, float* out, float value_scale, void* ws, int64_t ws_bytes, int64_t frames,
+                   int64_t H, int64_t W, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- stand-alone activations
  * act_fwd / act_bwd: y = act(x), dpre = dy * act'(pre) over flat fp32 arrays (n % 4 == 0), act in {ADNM_ACT_SILU, ADNM_ACT_GELU}: nn.GELU

@@ -237,8 +237,11 @@ def whole_model_case(name, size, batch, radar, cin=5, cout=20, full_out=False, d
 
 def evaluator_case():
     """SimplifiedEvaluator (datasets/Shanghai_metrics.py:14-290) on a recipe batch: the contingency counts, MSE / MAE per frame and the
-    aggregated CSI / POD / HSS / FAR / RMSE of done().  lpips (a weight download) and cv2 (SSIM) are absent here: lpips.LPIPS is a stub
-    returning zeros and cv2's two functions are scipy stand-ins, so the SSIM / LPIPS entries are NOT recorded."""
+    aggregated CSI / POD / HSS / FAR / RMSE of done().  lpips (a weight download) and cv2 are absent here: lpips.LPIPS is a stub
+    returning zeros, so LPIPS is NOT recorded.  SSIM (round 3) IS recorded, from the reference's own cal_ssim code (:132-152) with
+    the two cv2 calls it makes replaced by their documented formulas — cv2.getGaussianKernel(11, 1.5) = the normalised sampled Gaussian
+    (OpenCV's formula for ksize > 7), cv2.filter2D = correlation (the border mode is irrelevant: cal_ssim crops to the valid region) —
+    i.e. pinned to the reference's arithmetic around those two calls, not to OpenCV's binaries."""
     name = "evaluator_b3_t5"
     if not wanted(name):
         return
@@ -275,7 +278,8 @@ def evaluator_case():
     ev.evaluate(truth.numpy(), pred.numpy())
     res = ev.done()
     arrays = dict(truth=truth, pred=pred, value_scale=np.array(90.0), thresholds=np.array([20, 30, 35, 40]),
-                  mse=np.array(ev.losses["mse"]), mae=np.array(ev.losses["mae"]), FAR=np.array(res["FAR"]), RMSE=np.array(res["RMSE"]))
+                  mse=np.array(ev.losses["mse"]), mae=np.array(ev.losses["mae"]), FAR=np.array(res["FAR"]), RMSE=np.array(res["RMSE"]),
+                  ssim=np.array(ev.losses["ssim"]), SSIM=np.array(res["SSIM"]))
     for thr in (20, 30, 35, 40):
         for k in ("hits", "misses", "falsealarms", "correctnegs"):
             arrays[f"{k}.{thr}"] = np.array(ev.metrics[thr][k])

@@ -32,6 +32,10 @@ def test_oracle_evaluator_vs_reference():
         for k in ("CSI", "POD", "HSS"):
             assert abs(res[thr][k] - float(z[f"{k}.{thr}"])) <= 1e-9, (thr, k)
     assert abs(far - float(z["FAR"])) <= 1e-9 and abs(rmse - float(z["RMSE"])) <= 1e-5 * float(z["RMSE"])
+    # SSIM: the reference's cal_ssim, run by oracle/make_golden.py with the two cv2 calls replaced by their documented formulas
+    ssim = O.evaluator_ssim(z["truth"], z["pred"], float(z["value_scale"]))
+    assert_close(ssim, z["ssim"], 1e-9, "per-frame SSIM")
+    assert abs(float(ssim.mean()) - float(z["SSIM"])) <= 1e-9
 
 
 def test_checkpoint_roundtrip_with_dataparallel_prefix(tmp_path):
@@ -123,6 +127,7 @@ def test_gpu_evaluator_vs_reference():
         for k in ("CSI", "POD", "HSS"):
             assert abs(m[k] - float(z[f"{k}.{thr}"])) <= 1e-9, (thr, k)
     assert abs(res["FAR"] - float(z["FAR"])) <= 1e-9
+    assert abs(res["SSIM"] - float(z["SSIM"])) <= 1e-6, (res["SSIM"], float(z["SSIM"]))   # float64 moments on the device; per-tile sums folded in fp32
     assert abs(res["RMSE"] - float(z["RMSE"])) <= 1e-5 * float(z["RMSE"])
     assert abs(res["MSE"] - float(z["mse"].mean())) <= 1e-5 * float(z["mse"].mean())
 
