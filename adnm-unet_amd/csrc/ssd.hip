@@ -323,13 +323,17 @@ __global__ __launch_bounds__(kBlock) void ssd_bwd_kernel(
     int64_t lddx, T* __restrict__ dBm, int64_t lddb, T* __restrict__ dCm, int64_t lddc, T* __restrict__ ddt_raw, int64_t ldddt,
     float* __restrict__ hpart, float* __restrict__ bcpart, int64_t L, int H, int tok_per_block, int nblk, int nhb) {
   constexpr int KW = G * N, HBK = kCols / P, CPG = 4 / G, NS = N / 4, LPH = P / 4;   // LPH: kk-lanes that share a head
-  constexpr int kSlab = 2 * kTile * kSX + 2 * kTile * HBK;
+  // row stride of the per-(token, head) scalars sW / sS: the fragment-side reads walk the 16 tokens of a tile (one per lane) at a fixed
+  // head — with a stride of HBK = 16 words that is an 8-way bank conflict per 32-lane half (round 2 measured 37 % of this kernel's LDS
+  // cycles as conflict cycles); 17 spreads the tokens over distinct banks
+  constexpr int kSW = HBK + 1;
+  constexpr int kSlab = 2 * kTile * kSX + 2 * kTile * kSW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* sDY = smem + wave * kSlab;
   float* sX = sDY + kTile * kSX;          // x, then dx in place
   float* sW = sX + kTile * kSX;           // w per (token, head of the block)
-  float* sS = sW + kTile * HBK;           // a * sigmoid(z), then ddt_raw in place
+  float* sS = sW + kTile * kSW;           // a * sigmoid(z), then ddt_raw in place
   const int b = blockIdx.z, hb0 = blockIdx.y * HBK, col0 = hb0 * P;
   const int64_t l_begin = (int64_t)blockIdx.x * tok_per_block;
   const int64_t l_end = l_begin + tok_per_block < L ? l_begin + tok_per_block : L;
@@ -389,8 +393,8 @@ __global__ __launch_bounds__(kBlock) void ssd_bwd_kernel(
         const int t = kk + 4 * r;
         lds_st4(sDY + t * kSX + 4 * q, gv[r]);
         lds_st4(sX + t * kSX + 4 * q, xv[r]);
-        sW[t * HBK + hl_q] = wv[r];    // P = 8: the two lanes of a head write the same value
-        sS[t * HBK + hl_q] = sv[r];
+        sW[t * kSW + hl_q] = wv[r];    // P = 8: the two lanes of a head write the same value
+        sS[t * kSW + hl_q] = sv[r];
       }
     }
     // Bm of token j in fragment order: n = kk*NS + s (the permutation dkvA uses)
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(kBlock) void ssd_bwd_kernel(
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float4 gf = lds_ld4(sDY + j * kSX + cb[c]), xf = lds_ld4(sX + j * kSX + cb[c]);
-      const float wf = sW[j * HBK + hf[c]], sf = sS[j * HBK + hf[c]];
+      const float wf = sW[j * kSW + hf[c]], sf = sS[j * kSW + hf[c]];
       const float ge[4] = {gf.x, gf.y, gf.z, gf.w}, xe[4] = {xf.x, xf.y, xf.z, xf.w};
       // dCm^T += KV_g . dy_g^T,  dBm^T += dKV_g . (x w)_g^T     (rows = n, columns = tokens; k = this block's 16 columns)
 #pragma unroll
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(kBlock) void ssd_bwd_kernel(
       lds_st4(sX + j * kSX + cb[c], make_float4(fmaf(wf, tt[0], Dh[c] * ge[0]), fmaf(wf, tt[1], Dh[c] * ge[1]), fmaf(wf, tt[2], Dh[c] * ge[2]),
                                                 fmaf(wf, tt[3], Dh[c] * ge[3])));
       if ((cb[c] % P) == 0) {   // one lane per (token, head)
-        sS[j * HBK + hf[c]] = dz;
+        sS[j * kSW + hf[c]] = dz;
         stD[c] += dd;
         stB[c] += dz;
         stA[c] += dw * wf;
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(kBlock) void ssd_bwd_kernel(
 #pragma unroll
       for (int r = 0; r < IT; ++r) {
         const int f = lane + 64 * r, t = f / HBK, hh = f % HBK;
-        if (f < kTile * HBK && t < nvalid && hb0 + hh < H) Io<T>::st(ddt_raw + (row0 + t) * ldddt + (int64_t)(hb0 + hh) * dt_hs, sS[t * HBK + hh]);
+        if (f < kTile * HBK && t < nvalid && hb0 + hh < H) Io<T>::st(ddt_raw + (row0 + t) * ldddt + (int64_t)(hb0 + hh) * dt_hs, sS[t * kSW + hh]);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -616,7 +620,7 @@ int run_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void
             int64_t lddx, void* dBm, int64_t lddb, void* dCm, int64_t lddc, void* ddt_raw, int64_t ldddt, float* hpart, float* bcpart,
             float* ddt_bias, float* dA_log, float* dD, int64_t B, int64_t L, int64_t H, hipStream_t st) {
   const Geo g = make_geo(B, L, H, P, false);
-  constexpr int HBK = kCols / P, kSlab = 2 * kTile * kSX + 2 * kTile * HBK;
+  constexpr int HBK = kCols / P, kSlab = 2 * kTile * kSX + 2 * kTile * (HBK + 1);
   const size_t smem = sizeof(float) * (size_t)kWaves * kSlab;
   const dim3 grid(g.nchunk, g.nhb, (unsigned)B);
   {

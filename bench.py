@@ -19,7 +19,7 @@ MEDIAN window, every window is listed in `windows_ms_per_step`.  Rank 0 prints O
 stream the kernels run on, during extra eagerly-launched steps after the timed region.  The reported kernel is the one with
 the largest AGGREGATE time over the library's kernels; `families` lists every north-star kernel family (K1 SSD reduction,
 depthwise stencils, wavelet transform, row norms, MFMA GEMMs, dense convs, optimiser) the same way.  `traffic` is the
-PMC-measured HBM bytes of that kernel from profiles/r02_pmc_traffic.json — used only if that file was made from the same
+PMC-measured HBM bytes of that kernel from profiles/pmc_traffic.json — used only if that file was made from the same
 kernel sources (hash of csrc/), else null.  `cpu_baseline` times the oracle (oracle/adnm_oracle.py, the CPU restatement of
 the reference's algorithm) on the host cores for the same workload, rank 0 / N=1 only.
 """
@@ -204,17 +204,17 @@ def csrc_hash():
 
 
 def pmc_table():
-    """profiles/r02_pmc_traffic.json: {"csrc_hash": ..., "commit": ..., "kernels": {scope: {"hbm_bytes_per_step": ...,
+    """profiles/pmc_traffic.json: {"csrc_hash": ..., "commit": ..., "kernels": {scope: {"hbm_bytes_per_step": ...,
     "launches_per_step": ...}}} made by tools/pmc_traffic.py from two rocprofv3 --pmc passes of this command.  Only trusted for
     the kernel sources it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None, "no committed PMC pass"
     with open(path) as f:
         t = json.load(f)
     if t.get("csrc_hash") != csrc_hash():
-        return None, f"profiles/r02_pmc_traffic.json was measured on other kernel sources (csrc hash {t.get('csrc_hash')}), not used"
-    return t, f"profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE; commit {t.get('commit')})"
+        return None, f"profiles/pmc_traffic.json was measured on other kernel sources (csrc hash {t.get('csrc_hash')}), not used"
+    return t, f"profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE; commit {t.get('commit')})"
 
 
 def host_cores():

@@ -2,12 +2,13 @@
 # tools/install_profiles.sh <tag> : copy what tools/make_profiles.sh <tag> left under gpurun_out/<tag>/ (merged back from the GPU box) into
 # profiles/ under the judged names (gpurun_out/ is scratch, profiles/ is tracked).
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 src=gpurun_out/$tag
-for f in bench_bf16.json bench_f32.json kernel_shapes_bf16.tsv kernel_shapes_f32.tsv kernel_stats_bf16.csv steady_state_bf16.txt small_grids_bf16.txt \
+for f in bench_bf16.json bench_f32.json bench_fp8.json fp8_error.txt kernel_shapes_bf16.tsv kernel_shapes_f32.tsv kernel_shapes_fp8.tsv kernel_stats_bf16.csv steady_state_bf16.txt small_grids_bf16.txt \
          tsgemm.txt gemm_bench.txt pmc_traffic.txt; do
   cp $src/$f profiles/${tag}_$f
 done
-cp $src/pmc_traffic.json profiles/r02_pmc_traffic.json
+cp $src/pmc_traffic.json profiles/pmc_traffic.json
+cp $src/pmc_traffic.json profiles/${tag}_pmc_traffic.json
 grep -v "amdgpu.ids\|UserWarning\|Consider using\|res\[prec\]" $src/bf16_parity.txt > profiles/${tag}_bf16_parity.txt
 ls -la profiles | grep ${tag}_
