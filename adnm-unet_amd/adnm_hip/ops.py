@@ -679,6 +679,18 @@ def k_haar_dwt(x, B, H, W, C, cx=1):
     return y
 
 
+def k_wt_level(x, B, H, W, C, cx, taps, K, flip=False):
+    """One analysis level of WTConv2d in one launch: x (B*H*W, C*cx) fp32 row view -> (sub, tag), both (B*h2*w2, 4C); tag = depthwise KxK conv
+    of sub = DWT(x) (flip: with the flipped taps, the backward form)."""
+    _need_gpu(x)
+    h2, w2 = (H + 1) // 2, (W + 1) // 2
+    sub = torch.empty((B * h2 * w2, 4 * C), dtype=torch.float32, device=x.device)
+    tag = torch.empty_like(sub)
+    px, ldx = _rows(x)
+    lib.call("adnm_wt_level", px, ldx, cx, _f32(taps).data_ptr(), sub.data_ptr(), tag.data_ptr(), B, H, W, C, K, int(flip), _stream())
+    return sub, tag
+
+
 def k_haar_idwt(s, ll_add, B, H, W, C, y_add=()):
     """s: (B*h2*w2, 4C) contiguous (+ ll_add (B*h2*w2, C)) -> (B*H*W, C) [+ up to two contiguous (B*H*W, C) addends]."""
     _need_gpu(s)
@@ -996,12 +1008,17 @@ class WTConvFn(torch.autograd.Function):
         levels = len(level_wt)
         shapes, subs, tags = [], [], []
         cur, cx, h, w = x2, 1, H, W
+        fused = x2.dtype == torch.float32 and K in (3, 5)   # DWT + the level's stencil in one launch (csrc/wtlevel.hip)
         for i in range(levels):
             shapes.append((h, w))
-            sub = k_haar_dwt(cur, B, h, w, C, cx)  # (B*h2*w2, 4C); its LL band (column c*4) feeds the next level
+            if fused:
+                sub, tag = k_wt_level(cur, B, h, w, C, cx, level_wt[i], K)
+            else:
+                sub = k_haar_dwt(cur, B, h, w, C, cx)  # (B*h2*w2, 4C); its LL band (column c*4) feeds the next level
+                tag = k_dwconv_fwd(sub, level_wt[i], None, B, (h + 1) // 2, (w + 1) // 2, 4 * C, K, lib.ACT_NONE)
             h, w = (h + 1) // 2, (w + 1) // 2
             subs.append(sub)
-            tags.append(k_dwconv_fwd(sub, level_wt[i], None, B, h, w, 4 * C, K, lib.ACT_NONE))
+            tags.append(tag)
             cur, cx = sub, 4
         nxt = None
         for i in range(levels - 1, -1, -1):
@@ -1025,23 +1042,33 @@ class WTConvFn(torch.autograd.Function):
         dy2 = dy.reshape(B * H * W, C)
         dy2 = dy2 if dy2.stride(-1) == 1 else dy2.contiguous()
         dxb, dbase, dbb = k_dwconv_bwd(dy2, x2, base_wt, base_bias, B, H, W, C, K, lib.ACT_NONE, want_bias=base_bias is not None, want_dx=need_dx)
-        # the reconstruction's backward walks down: d(merged_i) = DWT(d r_{i-1}); its LL band is d r_i
-        dtags = []
+        # the reconstruction's backward walks down: d(merged_i) = DWT(d r_{i-1}); its LL band is d r_i.  With an input gradient wanted, the
+        # same launch also yields d sub_i = conv^T(d merged_i) (the fused level kernel on the flipped taps)
+        dtags, dsubs = [], []
         cur, cx = dy2, 1
+        fused = need_dx and dy2.dtype == torch.float32 and K in (3, 5)
         for i in range(levels):
             hh, ww = shapes[i]
-            dm = k_haar_dwt(cur, B, hh, ww, C, cx)
+            if fused:
+                dm, dsub = k_wt_level(cur, B, hh, ww, C, cx, level_wt[i], K, flip=True)
+                dsubs.append(dsub)
+            else:
+                dm = k_haar_dwt(cur, B, hh, ww, C, cx)
             dtags.append(dm)
             cur, cx = dm, 4
         # the analysis side's backward walks up: d(ll_{i-1}) = IDWT(d sub_i + [d ll_i on the LL band]); the last step adds the base conv's
         # input gradient and the alias's gradient in the same pass.  An input that needs no gradient (PatchEmbed.conv1: the radar frames)
-        # skips every input-gradient kernel.
+        # skips every input-gradient kernel.  The tap gradients (dtags_i x sub_i) are leaves.
         dll = None
         dlw = [None] * levels
         for i in range(levels - 1, -1, -1):
             hh, ww = shapes[i]
             h2, w2 = (hh + 1) // 2, (ww + 1) // 2
-            dsub, dlw[i], _ = k_dwconv_bwd(dtags[i], subs[i], level_wt[i], None, B, h2, w2, 4 * C, K, lib.ACT_NONE, want_dx=need_dx)
+            if fused:
+                _, dlw[i], _ = k_dwconv_bwd(dtags[i], subs[i], level_wt[i], None, B, h2, w2, 4 * C, K, lib.ACT_NONE, want_dx=False)
+                dsub = dsubs[i]
+            else:
+                dsub, dlw[i], _ = k_dwconv_bwd(dtags[i], subs[i], level_wt[i], None, B, h2, w2, 4 * C, K, lib.ACT_NONE, want_dx=need_dx)
             if need_dx:
                 dll = k_haar_idwt(dsub, dll, B, hh, ww, C, y_add=(dxb, dalias.reshape(B * H * W, C) if dalias is not None else None) if i == 0 else ())
         if not need_dx:

@@ -207,6 +207,12 @@ int adnm_dwconv_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, fl
  * The butterfly is its own transpose, so dwt's backward is idwt and vice versa. */
 int adnm_haar_dwt(const void* x, int64_t ldx, int64_t cx, void* y, int64_t B, int64_t H, int64_t W, int64_t C,
                   int dtype, adnm_stream_t stream);
+/* One ANALYSIS LEVEL of WTConv2d fused (WTConv2d.py:111-124): sub = DWT(x) and tag = depthwise KxK 'same' conv of sub (taps tap-major
+ * (K*K, 4C) fp32, wavelet_scale folded in) in ONE launch (csrc/wtlevel.hip: the sub-band tile + halo lives in LDS).  x: (B,H,W) pixel rows
+ * of stride ldx, channel c at column c*cx (cx = 4: the LL band of the previous level's sub-band tensor); sub, tag: (B,ceil(H/2),ceil(W/2),4C)
+ * contiguous fp32, OVERWRITTEN.  flip != 0: flipped taps — one level of the backward pass (dm = DWT(d r), d sub = conv^T(dm)).  K in {3, 5}. */
+int adnm_wt_level(const float* x, int64_t ldx, int64_t cx, const float* taps, float* sub, float* tag, int64_t B, int64_t H, int64_t W,
+                  int64_t C, int K, int flip, adnm_stream_t stream);
 /* y_add1 / y_add2 (optional, (B,H,W,C) like y): added to the result in the same pass — WTConv2d's backward sums its input-gradient
  * paths (pyramid + base conv + the input's other consumer) there instead of in separate adds. */
 int adnm_haar_idwt(const void* s, const void* ll_add, const void* y_add1, const void* y_add2, void* y, int64_t B, int64_t H,
