@@ -34,31 +34,49 @@ __global__ __launch_bounds__(kBlock) void wt_level_kernel(LvArgs a) {
   const int tile = blockIdx.x, ty0 = (tile / a.tiles_x) * kT, tx0 = (tile % a.tiles_x) * kT;
   const int c0 = blockIdx.y * CB, b = blockIdx.z;
   const int C4all = 4 * a.C;
-  // ---- phase 1: the tile + halo of sub-band pixels; item = (halo pixel, input-channel quad)
-  for (int item = threadIdx.x; item < TP * TP * CB4; item += kBlock) {
+  // the stencil's taps of this thread's channel quad: requested first, so that they arrive under phase 1
+  const int sq = threadIdx.x % CB, pstep = kBlock / CB;
+  float4 wv[K * K];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) wv[t] = *reinterpret_cast<const float4*>(a.taps + (int64_t)(FLIP ? K * K - 1 - t : t) * C4all + 4 * (c0 + sq));
+  // ---- phase 1: the tile + halo of sub-band pixels; item = (halo pixel, input-channel quad).  All of a thread's items are LOADED before
+  // the first is used: one memory round trip per workgroup instead of one per item (the small maps are pure latency)
+  constexpr int kIt = (TP * TP * 8 + kBlock - 1) / kBlock;   // items per thread at the widest channel block (CB = 32)
+  float v[kIt][4][4];   // [item][pixel a, b, c, d of the 2 x 2 block][channel of the quad]
+  const int nitems = TP * TP * CB4;
+#pragma unroll
+  for (int r = 0; r < kIt; ++r) {
+    const int item = threadIdx.x + r * kBlock;
     const int cq = item % CB4, hp = item / CB4, hy = hp / TP, hx = hp - hy * TP;
     const int i = ty0 + hy - R, j = tx0 + hx - R;   // sub-band pixel
-    float v[4][4];   // [pixel a, b, c, d of the 2 x 2 block][channel of the quad]
-    const bool inside = i >= 0 && i < a.h2 && j >= 0 && j < a.w2;
+    const bool inside = item < nitems && i >= 0 && i < a.h2 && j >= 0 && j < a.w2;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int hh = 2 * i + (q >> 1), ww = 2 * j + (q & 1);
       const bool in = inside && hh < a.H && ww < a.W;   // odd sizes: zero-padded bottom / right; outside the map: the conv's zero padding
-      const float* p = a.x + (((int64_t)b * a.H + (in ? hh : 0)) * a.W + (in ? ww : 0)) * a.ldx + (int64_t)(c0 + 4 * cq) * CX;
+      const float* p = a.x + (((int64_t)b * a.H + (in ? hh : 0)) * a.W + (in ? ww : 0)) * a.ldx + (int64_t)(c0 + 4 * (in ? cq : 0)) * CX;
       if (CX == 1) {
         const float4 f = in ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-        v[q][0] = f.x, v[q][1] = f.y, v[q][2] = f.z, v[q][3] = f.w;
+        v[r][q][0] = f.x, v[r][q][1] = f.y, v[r][q][2] = f.z, v[r][q][3] = f.w;
       } else {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) v[q][m] = in ? p[m * CX] : 0.f;
+        for (int m = 0; m < 4; ++m) v[r][q][m] = in ? p[m * CX] : 0.f;
       }
     }
+  }
+#pragma unroll
+  for (int r = 0; r < kIt; ++r) {
+    const int item = threadIdx.x + r * kBlock;
+    if (item >= nitems) break;
+    const int cq = item % CB4, hp = item / CB4, hy = hp / TP, hx = hp - hy * TP;
+    const int i = ty0 + hy - R, j = tx0 + hx - R;
+    const bool inside = i >= 0 && i < a.h2 && j >= 0 && j < a.w2;
     float* dst = sT + hp * S + 16 * cq;
     float* gsub = a.sub + (((int64_t)b * a.h2 + i) * a.w2 + j) * C4all + 4 * (c0 + 4 * cq);
     const bool interior = inside && hy >= R && hy < R + kT && hx >= R && hx < R + kT;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const float p0 = v[0][m], p1 = v[1][m], p2 = v[2][m], p3 = v[3][m];
+      const float p0 = v[r][0][m], p1 = v[r][1][m], p2 = v[r][2][m], p3 = v[r][3][m];
       const float4 o = make_float4(0.5f * (p0 + p1 + p2 + p3), 0.5f * (p0 + p1 - p2 - p3), 0.5f * (p0 - p1 + p2 - p3), 0.5f * (p0 - p1 - p2 + p3));
       *reinterpret_cast<float4*>(dst + 4 * m) = o;
       if (interior) *reinterpret_cast<float4*>(gsub + 4 * m) = o;
@@ -66,10 +84,6 @@ __global__ __launch_bounds__(kBlock) void wt_level_kernel(LvArgs a) {
   }
   __syncthreads();
   // ---- phase 2: the stencil out of LDS; item = (interior pixel, sub-band channel quad = one input channel); a thread keeps its quad
-  const int sq = threadIdx.x % CB, pstep = kBlock / CB;
-  float4 wv[K * K];
-#pragma unroll
-  for (int t = 0; t < K * K; ++t) wv[t] = *reinterpret_cast<const float4*>(a.taps + (int64_t)(FLIP ? K * K - 1 - t : t) * C4all + 4 * (c0 + sq));
   for (int pl = threadIdx.x / CB; pl < kT * kT; pl += pstep) {
     const int py = pl / kT, px = pl - py * kT;
     const int i = ty0 + py, j = tx0 + px;
