@@ -132,16 +132,49 @@ __global__ __launch_bounds__(kBlock) void conv3_kernel(ConvArgs a) {
   const int nchunks = (a.K + CK - 1) / CK;
   const int cbeg = blockIdx.z * a.chunks_per_split;
   const int cend = cbeg + a.chunks_per_split < nchunks ? cbeg + a.chunks_per_split : nchunks;
-  for (int c = cbeg; c < cend; ++c) {
-    __syncthreads();
-    stage_tile<ACT_IN>(a.in, a.ldin, a.in2, a.ldin2, a.vec_in != 0, a.K, a.B, a.H, a.W, a.VR, a.TW, a.TH, sIn, v0, x0, c * CK, q_sa,
-                       rec_a ? &amax_a : nullptr);
-    // weights of this chunk: sW[(tap*NB*16 + nl)*CKP + kq*4 .. +3] = W(n0 + nl, tap, c*16 + 4 kq ..)
-    for (int it = threadIdx.x; it < 9 * NB * 16 * 4; it += kBlock) {
-      const int kq = it & 3, nl = (it >> 2) % (NB * 16), tap = it / (NB * 64);
-      const int n = n0 + nl, k0 = c * CK + 4 * kq;
+  // Register-staged pipeline over the 16-channel chunks: the global loads of chunk c+1 (input tile + halo, the chunk's weights) are
+  // issued right after chunk c went to LDS and fly under its 9-tap MFMA loop — one exposed memory round trip per workgroup instead of one
+  // per chunk (these kernels ran at ~1 TB/s on the 128x128 maps: 2-4 chunks x two barriers with the loads in between).
+  constexpr int kItIn = 4;                                   // input items per thread: (TH+2)(TW+2) pixels x 4 channel quads / 256 <= 3.2
+  constexpr int kItW = (9 * NB * 64 + kBlock - 1) / kBlock;   // weight items per thread
+  const int PT = (a.TH + 2) * TWp;
+  float rin[kItIn][4], rw[kItW][4];
+  auto load_chunk = [&](int c) {
+    const int c0 = c * CK;
+#pragma unroll
+    for (int u = 0; u < kItIn; ++u) {
+      const int it = threadIdx.x + u * kBlock;
+      const int pix = it >> 2, q = it & 3, r = pix / TWp, cc = pix - r * TWp, ch = c0 + 4 * q;
+      const int64_t p = it < PT * 4 ? pixel_of(v0 - 1 + r, x0 - 1 + cc, a.B, a.H, a.W, a.VR) : -1;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (n < a.N && k0 < a.K) {
+      if (p >= 0 && ch < a.K) {
+        if (a.vec_in && ch + 3 < a.K) {
+          const float4 t = *reinterpret_cast<const float4*>(a.in + p * a.ldin + ch);
+          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+          if (ACT_IN != ADNM_ACT_NONE) {
+            const float4 g = *reinterpret_cast<const float4*>(a.in2 + p * a.ldin2 + ch);
+            v[0] *= act_grad<ACT_IN>(g.x); v[1] *= act_grad<ACT_IN>(g.y); v[2] *= act_grad<ACT_IN>(g.z); v[3] *= act_grad<ACT_IN>(g.w);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ch + e < a.K) {
+              v[e] = a.in[p * a.ldin + ch + e];
+              if (ACT_IN != ADNM_ACT_NONE) v[e] *= act_grad<ACT_IN>(a.in2[p * a.ldin2 + ch + e]);
+            }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rin[u][e] = v[e];
+    }
+    // weights of this chunk: sW[(tap*NB*16 + nl)*CKP + kq*4 .. +3] = W(n0 + nl, tap, c*16 + 4 kq ..)
+#pragma unroll
+    for (int u = 0; u < kItW; ++u) {
+      const int it = threadIdx.x + u * kBlock;
+      const int kq = it & 3, nl = (it >> 2) % (NB * 16), tap = it / (NB * 64);
+      const int n = n0 + nl, k0 = c0 + 4 * kq;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (it < 9 * NB * 64 && n < a.N && k0 < a.K) {
         const float* wp = a.w + (int64_t)n * a.sn + (int64_t)(a.flip ? 8 - tap : tap) * a.st + (int64_t)k0 * a.sk;
         if (a.vec_w && k0 + 3 < a.K) {
           const float4 t = *reinterpret_cast<const float4*>(wp);
@@ -152,10 +185,33 @@ __global__ __launch_bounds__(kBlock) void conv3_kernel(ConvArgs a) {
             if (k0 + e < a.K) v[e] = wp[(int64_t)e * a.sk];
         }
       }
-      if (rec_b) amax_b = adnm_amax4(amax_b, v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(sW + (tap * NB * 16 + nl) * CKP + 4 * kq) = make_float4(v[0] * q_sb, v[1] * q_sb, v[2] * q_sb, v[3] * q_sb);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rw[u][e] = v[e];
     }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int u = 0; u < kItIn; ++u) {
+      const int it = threadIdx.x + u * kBlock;
+      if (it >= PT * 4) break;
+      if (rec_a) amax_a = adnm_amax4(amax_a, rin[u][0], rin[u][1], rin[u][2], rin[u][3]);
+      *reinterpret_cast<float4*>(sIn + (it >> 2) * CKP + 4 * (it & 3)) = make_float4(rin[u][0] * q_sa, rin[u][1] * q_sa, rin[u][2] * q_sa, rin[u][3] * q_sa);
+    }
+#pragma unroll
+    for (int u = 0; u < kItW; ++u) {
+      const int it = threadIdx.x + u * kBlock;
+      if (it >= 9 * NB * 64) break;
+      const int kq = it & 3, nl = (it >> 2) % (NB * 16), tap = it / (NB * 64);
+      if (rec_b) amax_b = adnm_amax4(amax_b, rw[u][0], rw[u][1], rw[u][2], rw[u][3]);
+      *reinterpret_cast<float4*>(sW + (tap * NB * 16 + nl) * CKP + 4 * kq) = make_float4(rw[u][0] * q_sb, rw[u][1] * q_sb, rw[u][2] * q_sb, rw[u][3] * q_sb);
+    }
+  };
+  if (cbeg < cend) load_chunk(cbeg);
+  for (int c = cbeg; c < cend; ++c) {
+    __syncthreads();   // every wave has finished reading the previous chunk's LDS images
+    store_chunk();
     __syncthreads();
+    if (c + 1 < cend) load_chunk(c + 1);   // in flight under this chunk's MFMAs
     // one MFMA step = 32 reduction steps = the chunk's 16 channels of TWO taps (tap 8 runs on a zero upper half)
 #pragma unroll
     for (int tp = 0; tp < 9; tp += 2) {
