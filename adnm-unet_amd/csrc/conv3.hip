@@ -334,23 +334,47 @@ __global__ __launch_bounds__(kBlock) void conv3_wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[t][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  // Register-staged pipeline over the pixel tiles (as in conv3_kernel): the loads of the NEXT tile (input tile + halo, dout [* act'(pre)])
+  // fly under the current tile's MFMAs.
+  constexpr int kItIn = 4, kItD = (kTilePix * NB * 4 + kBlock - 1) / kBlock;
+  const int PT = (a.TH + 2) * TWp;
+  float rin[kItIn][4], rd[kItD][4];
+  auto load_tile = [&](int tile) {
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x, x0 = tx * a.TW, v0 = ty * a.TH;
-    __syncthreads();
-    stage_tile<ADNM_ACT_NONE>(a.in, a.ldin, nullptr, 0, a.vec_in != 0, a.K, a.B, a.H, a.W, a.VR, a.TW, a.TH, sIn, v0, x0, c0);
+#pragma unroll
+    for (int u = 0; u < kItIn; ++u) {
+      const int it = threadIdx.x + u * kBlock;
+      const int pix = it >> 2, q = it & 3, r = pix / TWp, cc = pix - r * TWp, ch = c0 + 4 * q;
+      const int64_t p = it < PT * 4 ? pixel_of(v0 - 1 + r, x0 - 1 + cc, a.B, a.H, a.W, a.VR) : -1;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p >= 0 && ch < a.K) {
+        if (a.vec_in && ch + 3 < a.K) {
+          const float4 t = *reinterpret_cast<const float4*>(a.in + p * a.ldin + ch);
+          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ch + e < a.K) v[e] = a.in[p * a.ldin + ch + e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rin[u][e] = v[e];
+    }
     // dpre tile: pixel block pb (0..7), pixel jj of it -> row pb*16 + jj; NB*16 channels from n0
-    for (int it = threadIdx.x; it < kTilePix * NB * 4; it += kBlock) {
+#pragma unroll
+    for (int u = 0; u < kItD; ++u) {
+      const int it = threadIdx.x + u * kBlock;
       const int pxl = it / (NB * 4), q = it - pxl * (NB * 4), n = n0 + 4 * q;
       const int pb = pxl >> 4, jj = pxl & 15, dy_ = jj / a.TW, dx_ = jj - dy_ * a.TW;
-      const int64_t p = pixel_of(v0 + pb * a.RB + dy_, x0 + dx_, a.B, a.H, a.W, a.VR);
+      const int64_t p = it < kTilePix * NB * 4 ? pixel_of(v0 + pb * a.RB + dy_, x0 + dx_, a.B, a.H, a.W, a.VR) : -1;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (p >= 0 && n < a.N) {
         if (a.vec_do && n + 3 < a.N) {
           const float4 t = *reinterpret_cast<const float4*>(a.dout + p * a.lddo + n);
           v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
           if (ACT != ADNM_ACT_NONE) {
-            const float4 u = *reinterpret_cast<const float4*>(a.pre + p * a.ldpre + n);
-            v[0] *= act_grad<ACT>(u.x); v[1] *= act_grad<ACT>(u.y); v[2] *= act_grad<ACT>(u.z); v[3] *= act_grad<ACT>(u.w);
+            const float4 g = *reinterpret_cast<const float4*>(a.pre + p * a.ldpre + n);
+            v[0] *= act_grad<ACT>(g.x); v[1] *= act_grad<ACT>(g.y); v[2] *= act_grad<ACT>(g.z); v[3] *= act_grad<ACT>(g.w);
           }
         } else {
 #pragma unroll
@@ -361,9 +385,31 @@ __global__ __launch_bounds__(kBlock) void conv3_wgrad_kernel(WgArgs a) {
             }
         }
       }
-      *reinterpret_cast<float4*>(sD + pxl * DP + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rd[u][e] = v[e];
     }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int u = 0; u < kItIn; ++u) {
+      const int it = threadIdx.x + u * kBlock;
+      if (it >= PT * 4) break;
+      *reinterpret_cast<float4*>(sIn + (it >> 2) * CKP + 4 * (it & 3)) = make_float4(rin[u][0], rin[u][1], rin[u][2], rin[u][3]);
+    }
+#pragma unroll
+    for (int u = 0; u < kItD; ++u) {
+      const int it = threadIdx.x + u * kBlock;
+      if (it >= kTilePix * NB * 4) break;
+      const int pxl = it / (NB * 4), q = it - pxl * (NB * 4);
+      *reinterpret_cast<float4*>(sD + pxl * DP + 4 * q) = make_float4(rd[u][0], rd[u][1], rd[u][2], rd[u][3]);
+    }
+  };
+  if ((int)blockIdx.x < a.ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    __syncthreads();   // every wave has finished reading the previous tile's LDS images
+    store_tile();
     __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) load_tile(tile + gridDim.x);   // in flight under this tile's MFMAs
     // reduction = the pixels of the wave's MB = 2 pixel blocks: lane (., kk) takes pixels 4 kk .. 4 kk + 3 of each (step e) — 8 per lane =
     // one 32-step MFMA group
     static_assert(MB == 2, "the weight-gradient step pairs the wave's two pixel blocks");

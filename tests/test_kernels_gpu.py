@@ -263,6 +263,34 @@ def test_gate():
     assert_close(hg.grad, ho.grad, GRAD_TOL, "dgate")
 
 
+@pytest.mark.parametrize("B,H,W,d,bias", [(2, 16, 16, 32, True), (1, 9, 13, 16, False), (2, 32, 32, 64, True)])
+def test_feedforward_chain(B, H, W, d, bias):
+    """FeedForward (reference model_untils.py:179-198): 1x1 d->4d, depthwise 3x3, gelu(x1)*sigmoid(x2), 1x1 2d->d as ONE autograd node (FeedForwardFn);
+    against the float64 statement of the same chain."""
+    x = T("ffg.x", (B, H * W, d))
+    w_in, w_out, dw = T("ffg.wi", (4 * d, d), 0.3), T("ffg.wo", (d, 2 * d), 0.3), T("ffg.dw", (4 * d, 1, 3, 3), 0.5)
+    bs = [T("ffg.bi", (4 * d,), 0.2), T("ffg.bd", (4 * d,), 0.2), T("ffg.bo", (d,), 0.2)] if bias else [None, None, None]
+    cot = T("ffg.c", (B, H * W, d))
+
+    def ref(x, w_in, dw, w_out, b_in, b_dw, b_out):
+        h = F.linear(x, w_in, b_in).view(B, H, W, 4 * d).permute(0, 3, 1, 2)
+        h = F.conv2d(h, dw, b_dw, padding=1, groups=4 * d)
+        x1, x2 = h.chunk(2, dim=1)
+        g = (O.gelu(x1) * torch.sigmoid(x2)).permute(0, 2, 3, 1).reshape(B, H * W, 2 * d)
+        return F.linear(g, w_out, b_out)
+
+    po = [leaf(t.double()) for t in (x, w_in, dw, w_out)] + [leaf(t.double()) if t is not None else None for t in bs]
+    yo = ref(*po)
+    (yo * cot.double()).sum().backward()
+    pg = [leaf(t, DEV) for t in (x, w_in, dw, w_out)] + [leaf(t, DEV) if t is not None else None for t in bs]
+    yg = ops.feedforward(pg[0], pg[1], pg[4], pg[2], pg[5], pg[3], pg[6], H, W)
+    (yg * cot.to(DEV)).sum().backward()
+    assert_close(yg, yo, OUT_TOL, "ffn y")
+    for name, g, o in zip(("dx", "dw_in", "ddw", "dw_out", "db_in", "db_dw", "db_out"), pg, po):
+        if g is not None:
+            assert_close(g.grad, o.grad, GRAD_TOL, name, atol=1e-5)
+
+
 # ------------------------------------------------------------------------------------------- bf16 storage
 def test_bf16_storage_paths():
     B, L, H, P, N, G = 2, 512, 16, 4, 16, 2
