@@ -1319,6 +1319,86 @@ def lincomb(xs, scalars, gamma=None):
     return LinCombFn.apply(gamma, *xs, *scalars)
 
 
+class MixNormFn(torch.autograd.Function):
+    """(xn, x) with x = gamma * (s0*x0 + s1*x1) and xn = scale * norm(x) + shift: a residual mix and the NEXT sub-block's pre-norm
+    (ADNMUNet.py:149-158) in one launch each way (csrc/mixnorm.hip).  x comes back as the second output, so the gradient the later
+    residual mix sends to it is added inside this node's backward kernel — d x never exists as a tensor."""
+
+    @staticmethod
+    def forward(ctx, gamma, w, b, scale, shift, eps, mean, x0, x1, s0, s1):
+        shp = x0.shape
+        d = shp[-1]
+        rows = lambda t: t.reshape(-1, d) if t.reshape(-1, d).stride(-1) == 1 else t.reshape(-1, d).contiguous()
+        a2, b2 = rows(x0), rows(x1)
+        _need_gpu(a2)
+        M, dev = a2.shape[0], a2.device
+        x = torch.empty((M, d), dtype=torch.float32, device=dev)
+        xn = torch.empty((M, d), dtype=torch.float32, device=dev)
+        mu = torch.empty(M, dtype=torch.float32, device=dev) if mean else None
+        rstd = torch.empty(M, dtype=torch.float32, device=dev)
+        (pa, lda), (pb, ldb) = _rows(a2), _rows(b2)
+        lib.call("adnm_mixnorm_fwd", pa, lda, pb, ldb, _p(s0), _p(s1), _p(gamma), w.data_ptr(), _p(b), _p(scale), _p(shift), x.data_ptr(), d,
+                 xn.data_ptr(), d, _p(mu), rstd.data_ptr(), M, d, float(eps), int(mean), _stream())
+        ctx.save_for_backward(gamma, w, b, scale, a2, b2, s0, s1, mu, rstd)
+        ctx.meta = (shp, mean, shift)
+        ctx.set_materialize_grads(False)
+        return xn.view(shp), x.view(shp)
+
+    @staticmethod
+    def backward(ctx, dxn, dres):
+        gamma, w, b, scale, a2, b2, s0, s1, mu, rstd = ctx.saved_tensors
+        shp, mean, shift = ctx.meta
+        M, d = a2.shape
+        dev = a2.device
+        rows = lambda t: t.reshape(M, d) if t.reshape(M, d).stride(-1) == 1 else t.reshape(M, d).contiguous()
+        if dxn is None:   # the normed output fed nothing that needs a gradient: a plain mix
+            dxn = torch.zeros((M, d), dtype=torch.float32, device=dev)
+        dxn = rows(dxn)
+        dres = rows(dres) if dres is not None else None
+        need = ctx.needs_input_grad
+        dx0 = torch.empty((M, d), dtype=torch.float32, device=dev) if need[7] else None
+        dx1 = torch.empty((M, d), dtype=torch.float32, device=dev) if need[8] else None
+        dss, accmask = [], 0
+        for i, sk in enumerate((s0, s1)):   # Block's beta1 / beta2 feed two mixes (see LinCombFn.backward)
+            if sk is None:
+                dss.append(None)
+                continue
+            t, acc = GRADS.take_accumulating(sk.data_ptr(), sk.shape, dev)
+            dss.append(t)
+            accmask |= (1 << (1 + i)) if acc else 0
+        dgamma = grad_dst(gamma.data_ptr(), gamma.shape, dev) if gamma is not None else None
+        dw = grad_dst(w.data_ptr(), (d,), dev)
+        db = grad_dst(b.data_ptr(), (d,), dev) if b is not None else None
+        affine = scale is not None or shift is not None
+        dsc = grad_dst(scale.data_ptr() if scale is not None else 0, (), dev) if affine else None
+        dsh = grad_dst(shift.data_ptr() if shift is not None else 0, (), dev) if affine else None
+        nb = lib.query("adnm_mixnorm_bwd_ws_bytes", M, d)
+        ws = _ws(nb, dev)
+        (pg, ldg), (pa, lda), (pb, ldb) = _rows(dxn), _rows(a2), _rows(b2)
+        pr, ldr = _rows(dres) if dres is not None else (None, 0)
+        with FOLDS.defer(dev, ws) as deferred:
+            if accmask:
+                assert deferred, "an accumulating gradient claim needs the deferred fold queue"
+                lib.load().adnm_foldq_accumulate_next(accmask)
+            lib.call("adnm_mixnorm_bwd", pg, ldg, pr, ldr, pa, lda, pb, ldb, _p(s0), _p(s1), _p(gamma), w.data_ptr(), _p(b), _p(scale), _p(mu),
+                     rstd.data_ptr(), _p(dx0), d, _p(dx1), d, _p(dss[0]), _p(dss[1]), _p(dgamma), dw.data_ptr(), _p(db), _p(dsc), _p(dsh),
+                     ws.data_ptr(), nb, M, d, int(mean), _stream())
+        ds = [None if (accmask >> (1 + i)) & 1 else t for i, t in enumerate(dss)]
+        return (dgamma, dw, db, dsc if scale is not None else None, dsh if shift is not None else None, None, None,
+                dx0.view(shp) if dx0 is not None else None, dx1.view(shp) if dx1 is not None else None, ds[0], ds[1])
+
+
+def mixnorm(xs, scalars, gamma, w, b=None, scale=None, shift=None, eps=1e-5, mean=True):
+    """-> (scale * norm(x) + shift, x) with x = gamma * (s0*xs[0] + s1*xs[1]); see MixNormFn."""
+    _need_gpu(xs[0])
+    d = xs[0].shape[-1]
+    if (len(xs) != 2 or xs[0].shape != xs[1].shape or any(x.dtype != torch.float32 for x in xs) or d % 4 or d > 1024
+            or any(sk is not None and sk.numel() != 1 for sk in scalars)):
+        _unsupported("mixnorm", f"mixes two same-shape fp32 token tensors with 4 | d <= 1024 channels and 1-element scalars, got "
+                                f"{[tuple(x.shape) for x in xs]} {[x.dtype for x in xs]}")
+    return MixNormFn.apply(gamma, w, b, scale, shift, eps, mean, xs[0], xs[1], scalars[0], scalars[1])
+
+
 class AdnPrepFn(torch.autograd.Function):
     """Reference-layout ADN-SSD parameters -> the kernel-layout tensors ADNMixerFn consumes (one HIP launch each way;
     see csrc/paramprep.hip).  Argument order = the `params[15]` table of include/adnm_hip.h.

@@ -36,6 +36,13 @@ def _merge(mod, x, residual, features):
     return x
 
 
+def _mix_normed(norm, xs, scalars, scale, shift):
+    """-> (scale*norm(x)+shift, x) for x = s0*xs[0] + s1*xs[1]: the residual mix and the pre-norm that follows it as one HIP launch"""
+    if isinstance(norm, (RMSNorm, BiasFree_LayerNorm)):
+        return norm.mix_tap(xs, scalars, scale, shift)
+    return _normed(norm, ops.lincomb(xs, scalars), scale, shift)
+
+
 def _normed(norm, x, scale, shift):
     """-> (scale*norm(x)+shift, x).  With the HIP row-norms the second value is an autograd alias of x whose gradient is
     added inside the norm's backward kernel (the residual path of the pre-norm block)."""
@@ -77,14 +84,19 @@ class Block(nn.Module):
         x = _merge(self, hidden_states, residual, features)
         b, l, d = x.shape
         h, w = _hw(l)
-        for i in range(self.num_layers):
+        n = self.num_layers
+        xn, x = _normed(self.norm1_layers[0], x, self.scale1[0], self.shift1[0])
+        for i in range(n):
             # beta3/beta4 alias beta1/beta2 in the reference (:145-146)
-            beta1, beta2 = (self.beta1, self.beta2) if self.num_layers == 1 else (self.beta1[i:i + 1], self.beta2[i:i + 1])
-            xn, x = _normed(self.norm1_layers[i], x, self.scale1[i], self.shift1[i])
-            x = ops.lincomb([x, self.drop_path_layers[i](self.mixer_layers[i](xn, h, w))], [beta1, beta2])
-            xn, x = _normed(self.norm2_layers[i], x, self.scale2[i], self.shift2[i])
-            # the block's closing per-channel gamma (:161) rides on the last residual mix: one launch instead of two
-            x = ops.lincomb([x, self.ffns[i].forward_tokens(xn, h, w)], [beta1, beta2], self.gamma if i == self.num_layers - 1 else None)
+            beta1, beta2 = (self.beta1, self.beta2) if n == 1 else (self.beta1[i:i + 1], self.beta2[i:i + 1])
+            # every residual mix (:152, :158) that is followed by a pre-norm (:155, the next layer's :149) shares that norm's launch
+            xn, x = _mix_normed(self.norm2_layers[i], [x, self.drop_path_layers[i](self.mixer_layers[i](xn, h, w))], [beta1, beta2],
+                                self.scale2[i], self.shift2[i])
+            f = self.ffns[i].forward_tokens(xn, h, w)
+            if i + 1 < n:
+                xn, x = _mix_normed(self.norm1_layers[i + 1], [x, f], [beta1, beta2], self.scale1[i + 1], self.shift1[i + 1])
+            else:   # the block's closing per-channel gamma (:161) rides on the last residual mix: one launch instead of two
+                x = ops.lincomb([x, f], [beta1, beta2], self.gamma)
         if self.dim != self.out_dim:
             x = ops.linear(x, self.out_proj.weight, self.out_proj.bias)
         return x
@@ -114,8 +126,7 @@ class Attention(nn.Module):
         b, l, d = x.shape
         h, w = _hw(l)
         xn, x = self.attn_norm1.tap(x, self.attn_scale1, self.attn_shift1)
-        x = ops.lincomb([x, self.attn_layer(xn, h, w)], [self.beta1, self.beta2])
-        xn, x = self.attn_norm2.tap(x, self.attn_scale2, self.attn_shift2)
+        xn, x = self.attn_norm2.mix_tap([x, self.attn_layer(xn, h, w)], [self.beta1, self.beta2], self.attn_scale2, self.attn_shift2)
         x = ops.lincomb([x, self.attn_mlp(xn)], [self.beta3, self.beta4], self.gamma)
         if self.dim != self.out_dim:
             x = ops.linear(x, self.out_proj.weight, self.out_proj.bias)

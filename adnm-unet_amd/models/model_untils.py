@@ -82,6 +82,10 @@ class BiasFree_LayerNorm(nn.Module):
     def tap(self, x, scale=None, shift=None):
         return ops.rownorm_tap(x, self.weight, None, scale, shift, 1e-5, True)
 
+    def mix_tap(self, xs, scalars, scale=None, shift=None):
+        """(scale * norm(x) + shift, x) for x = s0*xs[0] + s1*xs[1]: the residual mix that precedes this norm rides in its kernel"""
+        return ops.mixnorm(xs, scalars, None, self.weight, None, scale, shift, 1e-5, True)
+
 
 class RMSNorm(nn.Module):
     """Stands in for mamba_ssm.ops.triton.layer_norm.RMSNorm (bound at ADNMUNet.py:278 of the reference):
@@ -98,6 +102,9 @@ class RMSNorm(nn.Module):
 
     def tap(self, x, scale=None, shift=None):
         return ops.rownorm_tap(x, self.weight, None, scale, shift, self.eps, False)
+
+    def mix_tap(self, xs, scalars, scale=None, shift=None):
+        return ops.mixnorm(xs, scalars, None, self.weight, None, scale, shift, self.eps, False)
 
 
 class Mlp(nn.Module):

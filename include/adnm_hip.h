@@ -395,6 +395,22 @@ int adnm_lincomb_bwd(const void* dy, int64_t lddy, const void* x0, int64_t ld0, 
                      float* ds0, float* ds1, float* ds2, float* dgamma, void* ws, int64_t ws_bytes, int64_t M, int64_t C,
                      int dtype, adnm_stream_t stream);
 
+/* ---------------------------------------------------------------- residual mix + the next pre-norm, one pass each way
+ * mix = gamma * (s0*x0 + s1*x1)  (adnm_lincomb_fwd, bitwise)   and   xn = scale * ((mix - mu) * rstd * w + b) + shift  (adnm_rownorm_fwd)
+ * — Block.forward's `x = beta1*x + beta2*mixer(..); xn = scale2*norm2(x) + shift2` and the pair around the FFN (ADNMUNet.py:149-158), the
+ * same pairs in Attention.forward (:226-232).  fp32 rows, d % 4 == 0, d <= 1024.  bwd: dyn = d xn, dres = the gradient arriving on mix through
+ * the residual path (NULL: none); writes dx0 / dx1 (NULL skips) and OVERWRITES ds0, ds1, dgamma, dw, db, dscale, dshift (NULL skips); an
+ * accumulate mask announced with adnm_foldq_accumulate_next applies to {dgamma, ds0, ds1} as for adnm_lincomb_bwd. */
+int adnm_mixnorm_fwd(const float* x0, int64_t ld0, const float* x1, int64_t ld1, const float* s0, const float* s1, const float* gamma,
+                     const float* w, const float* b, const float* scale, const float* shift, float* ymix, int64_t ldm, float* yn,
+                     int64_t ldn, float* mu, float* rstd, int64_t M, int64_t d, float eps, int subtract_mean, adnm_stream_t stream);
+int64_t adnm_mixnorm_bwd_ws_bytes(int64_t M, int64_t d);
+int adnm_mixnorm_bwd(const float* dyn, int64_t lddyn, const float* dres, int64_t lddres, const float* x0, int64_t ld0, const float* x1,
+                     int64_t ld1, const float* s0, const float* s1, const float* gamma, const float* w, const float* b, const float* scale,
+                     const float* mu, const float* rstd, float* dx0, int64_t lddx0, float* dx1, int64_t lddx1, float* ds0, float* ds1,
+                     float* dgamma, float* dw, float* db, float* dscale, float* dshift, void* ws, int64_t ws_bytes, int64_t M, int64_t d,
+                     int subtract_mean, adnm_stream_t stream);
+
 /* ---------------------------------------------------------------- fused step glue on flat fp32 buffers (§8f rank 1)
  * clip_grad_norm_(max_norm) (train.py:140) + AdamW (train_untils.py:35-42) over n parameters laid out flat:
  *   state[1] = sum g^2;  coef = min(1, max_norm / (sqrt(state[1]) + 1e-6))  (max_norm <= 0: no clipping)

@@ -69,6 +69,44 @@ def test_rownorm(M, d, mean, bias, affine):
         assert_close(shg.grad, sho.grad, GRAD_TOL, "dshift", atol=1e-4)
 
 
+@pytest.mark.parametrize("M,d,mean,gamma,affine,res", [(1000, 32, True, False, True, True), (777, 64, False, True, True, True),
+                                                      (4096, 256, True, True, False, True), (50, 512, False, False, True, False),
+                                                      (131, 1024, True, True, True, True), (65536, 32, True, False, True, True)])
+def test_mixnorm(M, d, mean, gamma, affine, res):
+    """x = gamma * (s0*x0 + s1*x1); xn = scale * norm(x) + shift (ADNMUNet.py:149-158 of the reference) as one launch each way; `res`:
+    x is also read downstream (the residual path), i.e. a gradient arrives on both outputs.  Forward must equal the two-kernel chain
+    bit for bit (the mix is stored by both with the same operation order)."""
+    eps = 1e-5
+    x0, x1 = T(f"mn.a{M}{d}", (M, d), 2.0), T(f"mn.b{M}{d}", (M, d), 1.5)
+    w, g = 1 + 0.2 * T(f"mn.w{d}", (d,)), (1 + 0.3 * T(f"mn.g{d}", (d,))) if gamma else None
+    s0, s1 = torch.tensor([0.9]), torch.tensor([1.2])
+    sc, sh = (torch.tensor(1.3), torch.tensor(-0.2)) if affine else (None, None)
+    c1, c2 = T(f"mn.c{M}{d}", (M, d)), T(f"mn.e{M}{d}", (M, d))
+    dbl = lambda t: leaf(t.double()) if t is not None else None
+    po = [dbl(t) for t in (x0, x1, w, g, s0, s1, sc, sh)]
+    xo = po[4] * po[0] + po[5] * po[1]
+    if gamma:
+        xo = xo * po[3]
+    no = O.layernorm(xo, po[2], 0.0, eps) if mean else O.rmsnorm(xo, po[2], eps)
+    if affine:
+        no = po[6] * no + po[7]
+    ((no * c1.double()).sum() + ((xo * c2.double()).sum() if res else 0)).backward()
+    dev = lambda t: leaf(t, DEV) if t is not None else None
+    pg = [dev(t) for t in (x0, x1, w, g, s0, s1, sc, sh)]
+    ng, xg = ops.mixnorm([pg[0], pg[1]], [pg[4], pg[5]], pg[3], pg[2], None, pg[6], pg[7], eps, mean)
+    ((ng * c1.to(DEV)).sum() + ((xg * c2.to(DEV)).sum() if res else 0)).backward()
+    with torch.no_grad():   # the unfused chain
+        x2 = ops.lincomb([pg[0].detach(), pg[1].detach()], [pg[4].detach(), pg[5].detach()], pg[3].detach() if gamma else None)
+        n2 = ops.rownorm(x2, pg[2].detach(), None, pg[6].detach() if affine else None, pg[7].detach() if affine else None, eps, mean)
+    assert torch.equal(xg, x2), "mix differs from lincomb_fwd"
+    assert_close(ng, n2, 1e-6, "xn vs the two-kernel chain")
+    assert_close(xg, xo, OUT_TOL, "x")
+    assert_close(ng, no, OUT_TOL, "xn")
+    for name, a, o in zip(("dx0", "dx1", "dw", "dgamma", "ds0", "ds1", "dscale", "dshift"), pg, po):
+        if a is not None:
+            assert_close(a.grad, o.grad, GRAD_TOL, name, atol=1e-4)
+
+
 def test_rownorm_rejects_bad_shape():
     x = torch.zeros(4, 6, device=DEV)
     with pytest.raises(RuntimeError, match="multiple of 4"):
