@@ -691,16 +691,31 @@ def k_wt_level(x, B, H, W, C, cx, taps, K, flip=False):
     return sub, tag
 
 
-def k_haar_idwt(s, ll_add, B, H, W, C, y_add=()):
-    """s: (B*h2*w2, 4C) contiguous (+ ll_add (B*h2*w2, C)) -> (B*H*W, C) [+ up to two contiguous (B*H*W, C) addends]."""
+def k_haar_idwt(s, ll_add, B, H, W, C, y_add=(), up=()):
+    """s: (B*h2*w2, 4C) contiguous (+ ll_add (B*h2*w2, C)) -> (B*H*W, C) [+ up to two contiguous (B*H*W, C) addends].
+    up: the sub-band tensors of the next one / two coarser levels — the cascade in one launch; ll_add then belongs to the coarsest."""
     _need_gpu(s)
-    assert s.is_contiguous() and (ll_add is None or ll_add.is_contiguous())
+    assert s.is_contiguous() and (ll_add is None or ll_add.is_contiguous()) and len(up) <= 2 and all(u.is_contiguous() and u.dtype == s.dtype for u in up)
     adds = [a if a.is_contiguous() else a.contiguous() for a in y_add if a is not None]
     assert len(adds) <= 2
     adds += [None] * (2 - len(adds))
+    ups = list(up) + [None] * (2 - len(up))
     y = torch.empty((B * H * W, C), dtype=s.dtype, device=s.device)
-    lib.call("adnm_haar_idwt", s.data_ptr(), _p(ll_add), _p(adds[0]), _p(adds[1]), y.data_ptr(), B, H, W, C, _dt(s), _stream())
+    lib.call("adnm_haar_idwt", s.data_ptr(), _p(ups[0]), _p(ups[1]), _p(ll_add), _p(adds[0]), _p(adds[1]), y.data_ptr(), B, H, W, C, _dt(s), _stream())
     return y
+
+
+def k_haar_synthesis(bands, shapes, B, C, y_add=()):
+    """The synthesis cascade of WTConv2d (WTConv2d.py:128-141): bands[i] = level i's (B*h*w, 4C) sub-band tensor, shapes[i] = the (H, W) level
+    i reconstructs.  Three levels per launch (the finest launch takes y_add); deeper pyramids chain launches from the coarsest end."""
+    n = len(bands)
+    nxt, top = None, n   # levels [top, n) are already folded into nxt, which sits on level top - 1's LL band
+    while top > 0:
+        lo = max(top - 3, 0)
+        hh, ww = shapes[lo]
+        nxt = k_haar_idwt(bands[lo], nxt, B, hh, ww, C, y_add=y_add if lo == 0 else (), up=tuple(bands[lo + 1:top]))
+        top = lo
+    return nxt
 
 
 def k_instnorm_fwd(x, scale, shift, B, HW, C, eps, act):
@@ -1020,10 +1035,7 @@ class WTConvFn(torch.autograd.Function):
             subs.append(sub)
             tags.append(tag)
             cur, cx = sub, 4
-        nxt = None
-        for i in range(levels - 1, -1, -1):
-            hh, ww = shapes[i]
-            nxt = k_haar_idwt(tags[i], nxt, B, hh, ww, C)
+        nxt = k_haar_synthesis(tags, shapes, B, C) if levels else None
         y = k_dwconv_fwd(x2, base_wt, base_bias, B, H, W, C, K, lib.ACT_NONE, addend=nxt)
         ctx.save_for_backward(x2, base_wt, base_bias, *level_wt, *subs)
         ctx.dims = (B, H, W, C, K, levels, shapes)
@@ -1059,24 +1071,21 @@ class WTConvFn(torch.autograd.Function):
         # the analysis side's backward walks up: d(ll_{i-1}) = IDWT(d sub_i + [d ll_i on the LL band]); the last step adds the base conv's
         # input gradient and the alias's gradient in the same pass.  An input that needs no gradient (PatchEmbed.conv1: the radar frames)
         # skips every input-gradient kernel.  The tap gradients (dtags_i x sub_i) are leaves.
-        dll = None
         dlw = [None] * levels
         for i in range(levels - 1, -1, -1):
             hh, ww = shapes[i]
             h2, w2 = (hh + 1) // 2, (ww + 1) // 2
             if fused:
                 _, dlw[i], _ = k_dwconv_bwd(dtags[i], subs[i], level_wt[i], None, B, h2, w2, 4 * C, K, lib.ACT_NONE, want_dx=False)
-                dsub = dsubs[i]
             else:
                 dsub, dlw[i], _ = k_dwconv_bwd(dtags[i], subs[i], level_wt[i], None, B, h2, w2, 4 * C, K, lib.ACT_NONE, want_dx=need_dx)
-            if need_dx:
-                dll = k_haar_idwt(dsub, dll, B, hh, ww, C, y_add=(dxb, dalias.reshape(B * H * W, C) if dalias is not None else None) if i == 0 else ())
+                dsubs.insert(0, dsub)
         if not need_dx:
             dx = None
         elif levels == 0:
             dx = dxb if dalias is None else dxb + dalias.reshape(B * H * W, C)
-        else:
-            dx = dll
+        else:   # the cascade, three levels per launch; the finest launch adds the base conv's and the alias's gradients
+            dx = k_haar_synthesis(dsubs, shapes, B, C, y_add=(dxb, dalias.reshape(B * H * W, C) if dalias is not None else None))
         return (dx.view(B, H * W, C) if dx is not None else None, None, None, None, dbase, dbb, *dlw)
 
 
@@ -2308,43 +2317,49 @@ def rainloss(pred, target, omega_t, alpha, gamma):
     return RainLossFn.apply(pred, target, omega_t, alpha, gamma)
 
 
-class TokMeanTapFn(torch.autograd.Function):
-    """(x, mean over tokens): Channel_Att_Bridge's global average pool.  x comes back as an autograd alias so that the
-    gradient of its later consumers and the pool's broadcast gradient are summed in ONE pass (tokmean_bwd)."""
+class BridgePoolFn(torch.autograd.Function):
+    """Channel_Att_Bridge's pooling of all skips in one launch each way (csrc/bridge.hip): (*aliases of the skips, att (B, sum C)).  The
+    skips come back as autograd aliases: the gradient of a skip's later consumers and the pool's broadcast gradient are summed in the
+    one backward launch."""
 
     @staticmethod
-    def forward(ctx, x):
-        _need_gpu(x)
-        B, L, C = x.shape
-        xc = x if x.is_contiguous() else x.contiguous()
-        mean = torch.empty((B, C), dtype=torch.float32, device=x.device)
-        nb = lib.query("adnm_tokmean_ws_bytes", B, L, C)
-        ws = _ws(nb, x.device)
-        lib.call("adnm_tokmean_fwd", xc.data_ptr(), mean.data_ptr(), ws.data_ptr(), nb, B, L, C, _stream())
-        ctx.shp = (B, L, C)
+    def forward(ctx, *xs):
+        _need_gpu(xs[0])
+        B, dev = xs[0].shape[0], xs[0].device
+        xc = [x if x.is_contiguous() else x.contiguous() for x in xs]
+        Ls, Cs = [x.shape[1] for x in xs], [x.shape[2] for x in xs]
+        S = sum(Cs)
+        att = torch.empty((B, S), dtype=torch.float32, device=dev)
+        nb = lib.query("adnm_bridge_pool_ws_bytes", B, S)
+        ws = _ws(nb, dev)
+        lib.call("adnm_bridge_pool_fwd", len(xs), lib.ptr_table(xc), lib.i64_table(Ls), lib.i64_table(Cs), att.data_ptr(), ws.data_ptr(), nb, B, _stream())
+        ctx.meta = (B, Ls, Cs)
         ctx.set_materialize_grads(False)   # an unused output arrives as None, not as a full-size zeros tensor
-        return x, mean
+        return (*xs, att)
 
     @staticmethod
-    def backward(ctx, dxa, dmean):
-        B, L, C = ctx.shp
-        if dmean is None:
-            return dxa
-        if dxa is not None and not dxa.is_contiguous():
-            dxa = dxa.contiguous()
-        if dmean.stride(-1) != 1 or dmean.stride(0) % 4 or dmean.data_ptr() % 16:   # usually a column slice of the (B, sum C) concat gradient
-            dmean = dmean.contiguous()
-        dx = torch.empty((B, L, C), dtype=torch.float32, device=dmean.device)
-        lib.call("adnm_tokmean_bwd", _p(dxa), dmean.data_ptr(), dmean.stride(0), dx.data_ptr(), B, L, C, _stream())
-        return dx
+    def backward(ctx, *grads):
+        B, Ls, Cs = ctx.meta
+        dxa, datt = list(grads[:-1]), grads[-1]
+        if datt is None:
+            return tuple(dxa)
+        dev = datt.device
+        datt = datt if datt.is_contiguous() else datt.contiguous()
+        dxa = [g if g is None or g.is_contiguous() else g.contiguous() for g in dxa]
+        need = ctx.needs_input_grad
+        dx = [torch.empty((B, Ls[k], Cs[k]), dtype=torch.float32, device=dev) if need[k] else None for k in range(len(Ls))]
+        lib.call("adnm_bridge_pool_bwd", len(Ls), lib.ptr_table(dxa), datt.data_ptr(), lib.i64_table(Ls), lib.i64_table(Cs), lib.ptr_table(dx), B, _stream())
+        return tuple(dx)
 
 
-def tokmean_tap(x):
-    """-> (alias of x, (B, C) mean over tokens).  Callers should hand the alias to x's later consumers."""
-    _need_gpu(x)
-    if x.dtype != torch.float32 or x.dim() != 3 or x.shape[-1] % 4:
-        _unsupported("tokmean_tap", f"needs fp32 (B, L, C) tokens with 4 | C, got {x.dtype} {tuple(x.shape)}")
-    return TokMeanTapFn.apply(x)
+def bridge_pool(xs):
+    """-> ([aliases of the skips], att (B, sum C)): the token mean of every skip, concatenated.  Callers hand the aliases to the skips'
+    later consumers."""
+    _need_gpu(xs[0])
+    if not 1 <= len(xs) <= 8 or any(x.dtype != torch.float32 or x.dim() != 3 or x.shape[-1] % 4 or x.shape[0] != xs[0].shape[0] for x in xs):
+        _unsupported("bridge_pool", f"pools 1-8 fp32 (B, L, C) token tensors with 4 | C, got {[(x.dtype, tuple(x.shape)) for x in xs]}")
+    out = BridgePoolFn.apply(*xs)
+    return list(out[:-1]), out[-1]
 
 
 class BridgeHeadsFn(torch.autograd.Function):

@@ -117,6 +117,7 @@ struct Io<float> {
   static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
   static __device__ __forceinline__ float ld(const float* p) { return *p; }
   static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float rt(float v) { return v; }   // the value a store + load round trip would give back
 };
 template <>
 struct Io<uint16_t> {  // bf16 storage
@@ -133,6 +134,7 @@ struct Io<uint16_t> {  // bf16 storage
   }
   static __device__ __forceinline__ float ld(const uint16_t* p) { return bf16_to_f32(*p); }
   static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16(v); }
+  static __device__ __forceinline__ float rt(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 };
 
 // ---- MFMA precision ladder of the GEMM-shaped kernels (tsgemm, skgemm / lgemm, conv3) — all on gfx950's own instructions:

@@ -231,3 +231,158 @@ extern "C" int adnm_bridge_heads_bwd(const float* att, const float* const* W, co
   ADNM_CHECK_LAUNCH("bridge_heads_bwd");
   return ADNM_OK;
 }
+
+// ---- the bridge's global average pools, grouped (Channel_Att_Bridge.forward, model_untils.py:570-590 of the reference: avgpool of each of
+// the 7 skips, concatenated along the channel axis).  Before: one pool launch + one fold per skip + a torch.cat — 11 launches of a few
+// microseconds for ~20 MB of reads.  Here: ONE launch over all skips writes per-slice partial rows straight into the concatenated layout
+// (part[slice][b][off_k + c], already scaled by 1 / L_k), one fold sums the slices into att (B, S).  Backward likewise one launch:
+// dx_k[b,l,c] = dxa_k[b,l,c] + datt[b, off_k + c] / L_k (dxa_k: the gradient of the skip's other consumers, or NULL).
+namespace {
+constexpr int kMaxPool = 8, kPoolSlices = 64, kPoolThreads = 256;
+struct PoolDesc {
+  const float* x;     // fwd: (B, L, C) contiguous;  bwd: dxa or NULL
+  float* dx;          // bwd only
+  int L, C, off, ql;  // ql: channel-quad lanes of a workgroup (8 or 16); 256 / ql row lanes
+};
+struct MultiPool {
+  int count, B, S;
+  int blk_end[kMaxPool];
+  PoolDesc d[kMaxPool];
+};
+
+// workgroup = ql channel quads x (256 / ql) row lanes of ONE (skip, sample, slice); 4 rows in flight per lane
+__global__ __launch_bounds__(kPoolThreads) void bridge_pool_fwd_kernel(MultiPool mp_by_value, float* __restrict__ part) {
+  __shared__ float4 sm[kPoolThreads];
+  (void)mp_by_value;
+  const __attribute__((address_space(4))) MultiPool& mp = *(const __attribute__((address_space(4))) MultiPool*)__builtin_amdgcn_kernarg_segment_ptr();
+  int k = 0;
+  while (k + 1 < mp.count && (int)blockIdx.x >= mp.blk_end[k]) ++k;
+  const int local = (int)blockIdx.x - (k ? mp.blk_end[k - 1] : 0);
+  const int L = mp.d[k].L, C = mp.d[k].C, ql = mp.d[k].ql, C4 = C >> 2;
+  const int qblocks = (C4 + ql - 1) / ql;
+  const int qb = local % qblocks, s = (local / qblocks) % kPoolSlices, b = local / (qblocks * kPoolSlices);
+  const int lq = threadIdx.x % ql, rl = threadIdx.x / ql, rls = kPoolThreads / ql;
+  const int q = qb * ql + lq;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (q < C4) {
+    const float* xb = mp.d[k].x + (int64_t)b * L * C + q * 4;
+    const int step = rls * kPoolSlices;
+    int r = s * rls + rl;
+    for (; r + 3 * step < L; r += 4 * step) {
+      const float4 v0 = *reinterpret_cast<const float4*>(xb + (int64_t)r * C), v1 = *reinterpret_cast<const float4*>(xb + (int64_t)(r + step) * C);
+      const float4 v2 = *reinterpret_cast<const float4*>(xb + (int64_t)(r + 2 * step) * C), v3 = *reinterpret_cast<const float4*>(xb + (int64_t)(r + 3 * step) * C);
+      acc.x += (v0.x + v1.x) + (v2.x + v3.x), acc.y += (v0.y + v1.y) + (v2.y + v3.y), acc.z += (v0.z + v1.z) + (v2.z + v3.z), acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; r < L; r += step) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)r * C);
+      acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+    }
+  }
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  if (rl == 0 && q < C4) {
+    for (int j = 1; j < rls; ++j) {   // fixed order
+      const float4 v = sm[j * ql + lq];
+      acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+    }
+    const float inv_l = 1.0f / (float)L;
+    *reinterpret_cast<float4*>(part + ((int64_t)s * mp.B + b) * mp.S + mp.d[k].off + q * 4) = make_float4(acc.x * inv_l, acc.y * inv_l, acc.z * inv_l, acc.w * inv_l);
+  }
+}
+
+__global__ __launch_bounds__(kPoolThreads) void bridge_pool_bwd_kernel(MultiPool mp_by_value, const float* __restrict__ datt) {
+  (void)mp_by_value;
+  const __attribute__((address_space(4))) MultiPool& mp = *(const __attribute__((address_space(4))) MultiPool*)__builtin_amdgcn_kernarg_segment_ptr();
+  int k = 0;
+  while (k + 1 < mp.count && (int)blockIdx.x >= mp.blk_end[k]) ++k;
+  const int first = k ? mp.blk_end[k - 1] : 0, nblk = mp.blk_end[k] - first;
+  const int L = mp.d[k].L, C4 = mp.d[k].C >> 2;
+  const float* __restrict__ dxa = mp.d[k].x;
+  float* __restrict__ dx = mp.d[k].dx;
+  const float* dm = datt + mp.d[k].off;
+  const float inv_l = 1.0f / (float)L;
+  const int64_t total4 = (int64_t)mp.B * L * C4;
+  for (int64_t i = (int64_t)((int)blockIdx.x - first) * kPoolThreads + threadIdx.x; i < total4; i += (int64_t)nblk * kPoolThreads) {
+    const int q = (int)(i % C4);
+    const int64_t b = i / ((int64_t)C4 * L);
+    const float4 m = *reinterpret_cast<const float4*>(dm + b * mp.S + q * 4);
+    float4 v = dxa ? *reinterpret_cast<const float4*>(dxa + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v.x = fmaf(m.x, inv_l, v.x), v.y = fmaf(m.y, inv_l, v.y), v.z = fmaf(m.z, inv_l, v.z), v.w = fmaf(m.w, inv_l, v.w);
+    *reinterpret_cast<float4*>(dx + i * 4) = v;
+  }
+}
+
+int load_pools(const char* who, int n, const int64_t* L, const int64_t* C, int64_t B, MultiPool* mp) {
+  ADNM_REQUIRE(n >= 1 && n <= kMaxPool && L && C, "%s: 1 .. %d skips", who, kMaxPool);
+  ADNM_REQUIRE(B >= 1 && B <= 65535, "%s: bad B=%lld", who, (long long)B);
+  int off = 0;
+  for (int k = 0; k < n; ++k) {
+    ADNM_REQUIRE(L[k] > 0 && C[k] >= 4 && C[k] % 4 == 0 && B * L[k] * C[k] < (1ll << 31), "%s: skip %d: bad shape L=%lld C=%lld (4 | C)", who, k,
+                 (long long)L[k], (long long)C[k]);
+    mp->d[k].L = (int)L[k], mp->d[k].C = (int)C[k], mp->d[k].off = off, mp->d[k].ql = C[k] >= 64 ? 16 : 8;
+    off += (int)C[k];
+  }
+  mp->count = n, mp->B = (int)B, mp->S = off;
+  return ADNM_OK;
+}
+}  // namespace
+
+extern "C" int64_t adnm_bridge_pool_ws_bytes(int64_t B, int64_t S) { return B < 1 || S < 4 ? -1 : (int64_t)kPoolSlices * B * S * (int64_t)sizeof(float); }
+
+// x[k]: (B, L[k], C[k]) contiguous fp32; att: (B, S = sum C) OVERWRITTEN with the token means, skip k at columns [off_k, off_k + C[k]).
+extern "C" int adnm_bridge_pool_fwd(int64_t n, const float* const* x, const int64_t* L, const int64_t* C, float* att, void* ws, int64_t ws_bytes, int64_t B,
+                                    adnm_stream_t stream) {
+  ADNM_REQUIRE(x && att, "bridge_pool_fwd: null pointer");
+  MultiPool mp;
+  if (int rc = load_pools("bridge_pool_fwd", (int)n, L, C, B, &mp)) return rc;
+  if (!ws || ws_bytes < adnm_bridge_pool_ws_bytes(B, mp.S)) {
+    adnm_set_error("bridge_pool_fwd: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_bridge_pool_ws_bytes(B, mp.S));
+    return ADNM_EWORKSPACE;
+  }
+  int blocks = 0;
+  double bytes = 0;
+  for (int k = 0; k < (int)n; ++k) {
+    ADNM_REQUIRE(x[k], "bridge_pool_fwd: skip %d is NULL", k);
+    mp.d[k].x = x[k], mp.d[k].dx = nullptr;
+    blocks += (int)adnm_cdiv(mp.d[k].C / 4, mp.d[k].ql) * kPoolSlices * (int)B;
+    mp.blk_end[k] = blocks;
+    bytes += 4.0 * B * ((double)mp.d[k].L + kPoolSlices) * mp.d[k].C;
+  }
+  for (int k = (int)n; k < kMaxPool; ++k) mp.blk_end[k] = blocks;
+  hipStream_t st = (hipStream_t)stream;
+  {
+    ADNM_PROF("bridge_pool_fwd", st, bytes);
+    bridge_pool_fwd_kernel<<<(unsigned)blocks, kPoolThreads, 0, st>>>(mp, (float*)ws);
+  }
+  ADNM_CHECK_LAUNCH("bridge_pool_fwd");
+  // the conv over the pooled channels reads att right away: the caller binds no fold queue around this call
+  adnm_launch_fold("bridge_pool_fold", (const float*)ws, kPoolSlices, (int)(B * mp.S), {att, (int)(B * mp.S)}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
+  ADNM_CHECK_LAUNCH("bridge_pool_fold");
+  return ADNM_OK;
+}
+
+// dx[k] (B, L[k], C[k]) = dxa[k] (same shape, or NULL) + datt[:, off_k : off_k + C[k]] / L[k] broadcast over the tokens; dx[k] NULL skips a skip
+extern "C" int adnm_bridge_pool_bwd(int64_t n, const float* const* dxa, const float* datt, const int64_t* L, const int64_t* C, float* const* dx, int64_t B,
+                                    adnm_stream_t stream) {
+  ADNM_REQUIRE(dxa && datt && dx && (reinterpret_cast<uintptr_t>(datt) & 15) == 0, "bridge_pool_bwd: null / misaligned pointer");
+  MultiPool mp;
+  if (int rc = load_pools("bridge_pool_bwd", (int)n, L, C, B, &mp)) return rc;
+  int blocks = 0;
+  double bytes = 0;
+  for (int k = 0; k < (int)n; ++k) {
+    mp.d[k].x = dxa[k], mp.d[k].dx = dx[k];
+    if (dx[k]) {
+      const int64_t need = adnm_cdiv(B * mp.d[k].L * (mp.d[k].C / 4), kPoolThreads);
+      blocks += (int)(need < 1024 ? need : 1024);
+      bytes += 4.0 * B * mp.d[k].L * mp.d[k].C * (dxa[k] ? 2 : 1);
+    }
+    mp.blk_end[k] = blocks;
+  }
+  for (int k = (int)n; k < kMaxPool; ++k) mp.blk_end[k] = blocks;
+  if (!blocks) return ADNM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  ADNM_PROF("bridge_pool_bwd", st, bytes);
+  bridge_pool_bwd_kernel<<<(unsigned)blocks, kPoolThreads, 0, st>>>(mp, datt);
+  ADNM_CHECK_LAUNCH("bridge_pool_bwd");
+  return ADNM_OK;
+}

@@ -173,47 +173,6 @@ __global__ __launch_bounds__(kBlock) void rainloss_kernel(const float* __restric
   if (threadIdx.x == 0) part[blockIdx.x] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) * inv_n;
 }
 
-// Global average pool over the tokens of (B, L, C) (Channel_Att_Bridge, model_untils.py:570-590 of the reference).
-// block = 16 channel quads x 16 row lanes; grid (C4/16, S, B); part[s][b][c] already scaled by 1/L.
-__global__ __launch_bounds__(kBlock) void tokmean_kernel(const float* __restrict__ x, float* __restrict__ part, int L, int C, int S, float inv_l) {
-  __shared__ float4 sm[16][16];
-  const int ql = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int q = blockIdx.x * 16 + ql, s = blockIdx.y, b = blockIdx.z;
-  const int C4 = C >> 2;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (q < C4) {
-    const float* xb = x + (int64_t)b * L * C + q * 4;
-    for (int r = s * 16 + rl; r < L; r += 16 * S) {
-      const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)r * C);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-  }
-  sm[rl][ql] = acc;
-  __syncthreads();
-  if (rl == 0 && q < C4) {
-#pragma unroll
-    for (int k = 1; k < 16; ++k) {
-      const float4 v = sm[k][ql];
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    *reinterpret_cast<float4*>(part + ((int64_t)s * gridDim.z + b) * C + q * 4) = make_float4(acc.x * inv_l, acc.y * inv_l, acc.z * inv_l, acc.w * inv_l);
-  }
-}
-
-// dx[b,l,c] = dxa[b,l,c] + dmean[b,c] / L   (dxa may be NULL): the pool's broadcast gradient and the gradient of the other
-// consumers of the same tensor in one pass (autograd would expand, divide and add in three)
-__global__ __launch_bounds__(kBlock) void tokmean_bwd_kernel(const float* __restrict__ dxa, const float* __restrict__ dmean, int64_t ldm,
-                                                             float* __restrict__ dx, int64_t L, int C4, int64_t total4, float inv_l) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (int64_t)gridDim.x * kBlock) {
-    const int q = (int)(i % C4);
-    const int64_t b = i / ((int64_t)C4 * L);
-    const float4 m = *reinterpret_cast<const float4*>(dmean + b * ldm + q * 4);
-    float4 v = dxa ? *reinterpret_cast<const float4*>(dxa + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    v.x = fmaf(m.x, inv_l, v.x); v.y = fmaf(m.y, inv_l, v.y); v.z = fmaf(m.z, inv_l, v.z); v.w = fmaf(m.w, inv_l, v.w);
-    *reinterpret_cast<float4*>(dx + i * 4) = v;
-  }
-}
-
 // nn.Conv1d(1, 1, 3, padding=1) over the channel axis of (B, n) (get_all_att, model_untils.py:548,592): one workgroup.
 // fwd: y = w0 x[i-1] + w1 x[i] + w2 x[i+1] + b.  bwd: dx, dw[3], db in the same pass (block reduction, no partials).
 // One workgroup of 1024 lanes, four elements in flight per lane: this is ~8.5 K elements behind a chain of dependent loads (as a
@@ -601,46 +560,6 @@ extern "C" int adnm_rainloss(const float* pred, const float* target, float* loss
   }
   adnm_launch_fold("rainloss_fold", (const float*)ws, (int)grid, 1, {loss, 1}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
   ADNM_CHECK_LAUNCH("rainloss");
-  return ADNM_OK;
-}
-
-namespace {
-int tokmean_slices(int64_t L) {
-  int64_t s = L / (16 * 32);
-  return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
-}
-}  // namespace
-extern "C" int64_t adnm_tokmean_ws_bytes(int64_t B, int64_t L, int64_t C) { return (int64_t)tokmean_slices(L) * B * C * (int64_t)sizeof(float); }
-
-extern "C" int adnm_tokmean_fwd(const float* x, float* mean, void* ws, int64_t ws_bytes, int64_t B, int64_t L, int64_t C, adnm_stream_t stream) {
-  ADNM_REQUIRE(x && mean, "tokmean_fwd: null pointer");
-  ADNM_REQUIRE(B > 0 && B <= 65535 && L > 0 && C > 0 && C % 4 == 0 && L * C < (1ll << 31), "tokmean_fwd: bad shape B=%lld L=%lld C=%lld", (long long)B,
-               (long long)L, (long long)C);
-  const int S = tokmean_slices(L);
-  if (S > 1 && (!ws || ws_bytes < adnm_tokmean_ws_bytes(B, L, C))) {
-    adnm_set_error("tokmean_fwd: workspace too small");
-    return ADNM_EWORKSPACE;
-  }
-  hipStream_t st = (hipStream_t)stream;
-  float* part = S > 1 ? (float*)ws : mean;
-  {
-    ADNM_PROF("tokmean", st, 4.0 * B * (L + 1) * C);
-    tokmean_kernel<<<dim3((unsigned)adnm_cdiv(C / 4, 16), (unsigned)S, (unsigned)B), kBlock, 0, st>>>(x, part, (int)L, (int)C, S, 1.0f / (float)L);
-  }
-  if (S > 1) adnm_launch_fold("tokmean_fold", part, S, (int)(B * C), {mean, (int)(B * C)}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
-  ADNM_CHECK_LAUNCH("tokmean_fwd");
-  return ADNM_OK;
-}
-
-extern "C" int adnm_tokmean_bwd(const float* dxa, const float* dmean, int64_t ldm, float* dx, int64_t B, int64_t L, int64_t C, adnm_stream_t stream) {
-  ADNM_REQUIRE(dmean && dx, "tokmean_bwd: null pointer");
-  ADNM_REQUIRE(B > 0 && L > 0 && C > 0 && C % 4 == 0, "tokmean_bwd: bad shape");
-  ADNM_REQUIRE(ldm >= C && ldm % 4 == 0 && (reinterpret_cast<uintptr_t>(dmean) & 15) == 0, "tokmean_bwd: dmean rows must be 16-byte aligned (ldm %% 4 == 0)");
-  hipStream_t st = (hipStream_t)stream;
-  const int64_t total4 = B * L * (C / 4);
-  ADNM_PROF("tokmean_bwd", st, 4.0 * B * L * C * (dxa ? 2 : 1));
-  tokmean_bwd_kernel<<<grid_for(total4), kBlock, 0, st>>>(dxa, dmean, ldm, dx, L, (int)(C / 4), total4, 1.0f / (float)L);
-  ADNM_CHECK_LAUNCH("tokmean_bwd");
   return ADNM_OK;
 }
 

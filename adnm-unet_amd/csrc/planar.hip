@@ -52,9 +52,20 @@ __global__ __launch_bounds__(kBlock) void haar_dwt_kernel(const T* __restrict__ 
 // s:(B,h,w,4C) (+ ll_add:(B,h,w,C) on the LL band) -> y:(B,H,W,C), cropped to H,W.  ya / yb (optional, (B,H,W,C)): added to the result —
 // the last synthesis step of WTConv2d's backward sums its three input-gradient paths (wavelet pyramid, base conv, the tensor's other
 // consumer) in this one pass instead of two separate adds.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void haar_idwt_kernel(const T* __restrict__ s, const T* __restrict__ ll_add, const T* __restrict__ ya,
-                                                           const T* __restrict__ yb, T* __restrict__ y, int B, int H, int W, int C) {
+// UP > 0: the whole synthesis CASCADE (WTConv2d.py:128-141) in one launch.  Haar synthesis is local — output pixel (y, x) of a level
+// depends on ONE sub-band pixel of that level and on one value of the level above — so instead of materialising the intermediate
+// reconstructions (one 5 us launch each), a thread derives its LL addend from the coarser levels' sub-band tensors up1 (and up2 above
+// it): one 64-byte read per coarser level, served by L2 (a coarser level is 1/4 the size and shared by 4 / 16 threads).  ll_add then
+// belongs to the COARSEST level of the call.  Same operations in the same order as the chain of single-level launches: bitwise equal.
+__device__ __forceinline__ float idwt_pick(const float4 f, const float ll, const int q) {   // output (q >> 1, q & 1) of the 2 x 2 block
+  const float sy = (q & 2) ? -1.f : 1.f, sz = (q & 1) ? -1.f : 1.f, sw = (q == 1 || q == 2) ? -1.f : 1.f;
+  return 0.5f * (ll + sy * f.y + sz * f.z + sw * f.w);
+}
+
+template <typename T, int UP>
+__global__ __launch_bounds__(kBlock) void haar_idwt_kernel(const T* __restrict__ s, const T* __restrict__ up1, const T* __restrict__ up2,
+                                                           const T* __restrict__ ll_add, const T* __restrict__ ya, const T* __restrict__ yb,
+                                                           T* __restrict__ y, int B, int H, int W, int C) {
   const int C4 = C >> 2, h2 = (H + 1) >> 1, w2 = (W + 1) >> 1;
   const int64_t total = (int64_t)B * h2 * w2 * C4;
   const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -67,9 +78,43 @@ __global__ __launch_bounds__(kBlock) void haar_idwt_kernel(const T* __restrict__
   const int b = (int)(t / h2);
   const int64_t pix = ((int64_t)b * h2 + i) * w2 + j;
   const T* p = s + pix * (4 * (int64_t)C) + (int64_t)cg * 16;
-  float4 add = f4zero();
-  if (ll_add) add = Io<T>::ld4(ll_add + pix * C + cg * 4);
-  const float addv[4] = {add.x, add.y, add.z, add.w};
+  float addv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (UP == 0) {
+    if (ll_add) {
+      const float4 add = Io<T>::ld4(ll_add + pix * C + cg * 4);
+      addv[0] = add.x, addv[1] = add.y, addv[2] = add.z, addv[3] = add.w;
+    }
+  } else {
+    const int h3 = (h2 + 1) >> 1, w3 = (w2 + 1) >> 1;
+    const int64_t pix1 = ((int64_t)b * h3 + (i >> 1)) * w3 + (j >> 1);
+    float add1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (UP == 2) {
+      const int h4 = (h3 + 1) >> 1, w4 = (w3 + 1) >> 1;
+      const int64_t pix2 = ((int64_t)b * h4 + (i >> 2)) * w4 + (j >> 2);
+      float add2[4] = {0.f, 0.f, 0.f, 0.f};
+      if (ll_add) {
+        const float4 add = Io<T>::ld4(ll_add + pix2 * C + cg * 4);
+        add2[0] = add.x, add2[1] = add.y, add2[2] = add.z, add2[3] = add.w;
+      }
+      const T* p2 = up2 + pix2 * (4 * (int64_t)C) + (int64_t)cg * 16;
+      const int q2 = ((i >> 1) & 1) * 2 + ((j >> 1) & 1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float4 f = Io<T>::ld4(p2 + m * 4);
+        add1[m] = Io<T>::rt(idwt_pick(f, f.x + add2[m], q2));
+      }
+    } else if (ll_add) {
+      const float4 add = Io<T>::ld4(ll_add + pix1 * C + cg * 4);
+      add1[0] = add.x, add1[1] = add.y, add1[2] = add.z, add1[3] = add.w;
+    }
+    const T* p1 = up1 + pix1 * (4 * (int64_t)C) + (int64_t)cg * 16;
+    const int q1 = (i & 1) * 2 + (j & 1);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float4 f = Io<T>::ld4(p1 + m * 4);
+      addv[m] = Io<T>::rt(idwt_pick(f, f.x + add1[m], q1));
+    }
+  }
   float o[4][4];  // [pixel][channel]
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -452,19 +497,30 @@ extern "C" int adnm_haar_dwt(const void* x, int64_t ldx, int64_t cx, void* y, in
   return ADNM_OK;
 }
 
-extern "C" int adnm_haar_idwt(const void* s, const void* ll_add, const void* y_add1, const void* y_add2, void* y, int64_t B, int64_t H, int64_t W,
-                              int64_t C, int dtype, adnm_stream_t stream) {
+extern "C" int adnm_haar_idwt(const void* s, const void* up1, const void* up2, const void* ll_add, const void* y_add1, const void* y_add2, void* y,
+                              int64_t B, int64_t H, int64_t W, int64_t C, int dtype, adnm_stream_t stream) {
   ADNM_REQUIRE(s && y, "haar_idwt: null pointer");
+  ADNM_REQUIRE(up1 || !up2, "haar_idwt: the coarser levels must be filled in order (up2 without up1)");
   ADNM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "haar_idwt: bad shape (C=%lld must be a multiple of 4)", (long long)C);
   ADNM_REQUIRE(dtype == ADNM_F32 || dtype == ADNM_BF16, "haar_idwt: bad dtype %d", dtype);
   const int64_t total = B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
   const unsigned grid = (unsigned)adnm_cdiv(total, kBlock);
   hipStream_t st = (hipStream_t)stream;
-  const double units = (ll_add ? 2.25 : 2.0) + (y_add1 ? 1.0 : 0.0) + (y_add2 ? 1.0 : 0.0);
-  if (dtype == ADNM_F32)
-    { ADNM_PROF("haar_idwt", st, 4.0 * B * H * W * C * units); haar_idwt_kernel<float><<<grid, kBlock, 0, st>>>((const float*)s, (const float*)ll_add, (const float*)y_add1, (const float*)y_add2, (float*)y, (int)B, (int)H, (int)W, (int)C); }
-  else
-    { ADNM_PROF("haar_idwt", st, 2.0 * B * H * W * C * units); haar_idwt_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)s, (const uint16_t*)ll_add, (const uint16_t*)y_add1, (const uint16_t*)y_add2, (uint16_t*)y, (int)B, (int)H, (int)W, (int)C); }
+  const double units = 2.0 + (up1 ? 0.25 : 0.0) + (up2 ? 0.0625 : 0.0) + (ll_add ? (up2 ? 0.015625 : (up1 ? 0.0625 : 0.25)) : 0.0) + (y_add1 ? 1.0 : 0.0) + (y_add2 ? 1.0 : 0.0);
+  const int up = up2 ? 2 : (up1 ? 1 : 0);
+#define IDWT(T, UP) haar_idwt_kernel<T, UP><<<grid, kBlock, 0, st>>>((const T*)s, (const T*)up1, (const T*)up2, (const T*)ll_add, (const T*)y_add1, (const T*)y_add2, (T*)y, (int)B, (int)H, (int)W, (int)C)
+  if (dtype == ADNM_F32) {
+    ADNM_PROF("haar_idwt", st, 4.0 * B * H * W * C * units);
+    if (up == 0) IDWT(float, 0);
+    else if (up == 1) IDWT(float, 1);
+    else IDWT(float, 2);
+  } else {
+    ADNM_PROF("haar_idwt", st, 2.0 * B * H * W * C * units);
+    if (up == 0) IDWT(uint16_t, 0);
+    else if (up == 1) IDWT(uint16_t, 1);
+    else IDWT(uint16_t, 2);
+  }
+#undef IDWT
   ADNM_CHECK_LAUNCH("haar_idwt");
   return ADNM_OK;
 }

@@ -488,11 +488,11 @@ class Channel_Att_Bridge(nn.Module):
 
     def forward(self, t, live=None, alias_out=None):
         """alias_out: optional list that receives autograd aliases of the skips — later consumers that read those instead of
-        t[i] get their gradient summed with the pool's in one HIP pass (ops.tokmean_tap)."""
-        taps = [ops.tokmean_tap(t[i]) for i in range(len(t))]
+        t[i] get their gradient summed with the pool's in one HIP pass (ops.bridge_pool)."""
+        aliases, att = ops.bridge_pool([t[i] for i in range(len(t))])   # every skip's avgpool + the concat: one launch (+ one fold)
         if alias_out is not None:
-            alias_out[:] = [a for a, _ in taps]
-        att = torch.cat([m for _, m in taps], dim=-1).unsqueeze(1)  # (B,1,sum C)
+            alias_out[:] = aliases
+        att = att.unsqueeze(1)  # (B,1,sum C)
         att = ops.conv1d3(att, self.get_all_att.weight, self.get_all_att.bias)
         idx = [i for i in range(7) if live is None or i in live]
         lins = [getattr(self, f"att{i + 1}") for i in idx]

@@ -214,9 +214,12 @@ int adnm_haar_dwt(const void* x, int64_t ldx, int64_t cx, void* y, int64_t B, in
 int adnm_wt_level(const float* x, int64_t ldx, int64_t cx, const float* taps, float* sub, float* tag, int64_t B, int64_t H, int64_t W,
                   int64_t C, int K, int flip, adnm_stream_t stream);
 /* y_add1 / y_add2 (optional, (B,H,W,C) like y): added to the result in the same pass — WTConv2d's backward sums its input-gradient
- * paths (pyramid + base conv + the input's other consumer) there instead of in separate adds. */
-int adnm_haar_idwt(const void* s, const void* ll_add, const void* y_add1, const void* y_add2, void* y, int64_t B, int64_t H,
-                   int64_t W, int64_t C, int dtype, adnm_stream_t stream);
+ * paths (pyramid + base conv + the input's other consumer) there instead of in separate adds.
+ * up1 / up2 (optional): the sub-band tensors of the next one / two COARSER levels ((B, ceil(h/2), ceil(w/2), 4C) with h, w the sub-band
+ * size of the level below): the synthesis cascade (WTConv2d.py:128-141) in ONE launch — the LL addend of `s` is derived from them instead of
+ * being read; ll_add then belongs to the coarsest level given.  Bitwise equal to the chain of single-level calls. */
+int adnm_haar_idwt(const void* s, const void* up1, const void* up2, const void* ll_add, const void* y_add1, const void* y_add2, void* y,
+                   int64_t B, int64_t H, int64_t W, int64_t C, int dtype, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- max pooling, NHWC (K11)
  * nn.MaxPool2d on tokens: stride == kernel in [2,4] (DownSample, model_untils.py:472-487; floor mode) or stride 1 with
@@ -302,14 +305,9 @@ int adnm_attn4_fwd(const float* qkv, float* out, float* lse, int64_t B, int64_t 
 int adnm_attn4_bwd(const float* dout, const float* qkv, const float* out, const float* lse, float* dqkv, int64_t B, int64_t L, int64_t heads,
                    float scale, adnm_stream_t stream);
 
-/* ---------------------------------------------------------------- Channel_Att_Bridge pooling (K15)
- * model_untils.py:570-592 of the reference: mean[b,c] = (1/L) sum_l x[b,l,c] for contiguous fp32 (B,L,C) tokens (the
- * reference's AdaptiveAvgPool2d(1) of each skip), C % 4 == 0; bwd: dx = dxa + dmean/L broadcast over l (dmean rows ldm apart; dxa = the gradient of
- * the tensor's other consumers, or NULL), one pass.  conv1d3: nn.Conv1d(1,1,3,padding=1) over the concatenated channel axis
+/* ---------------------------------------------------------------- Channel_Att_Bridge's Conv1d (K15; the pooling itself: adnm_bridge_pool_*)
+ * model_untils.py:592 of the reference.  conv1d3: nn.Conv1d(1,1,3,padding=1) over the concatenated channel axis
  * of (B,n) (get_all_att); bwd writes dx and dwb = [dw0, dw1, dw2, dbias] (OVERWRITTEN). */
-int64_t adnm_tokmean_ws_bytes(int64_t B, int64_t L, int64_t C);
-int adnm_tokmean_fwd(const float* x, float* mean, void* ws, int64_t ws_bytes, int64_t B, int64_t L, int64_t C, adnm_stream_t stream);
-int adnm_tokmean_bwd(const float* dxa, const float* dmean, int64_t ldm, float* dx, int64_t B, int64_t L, int64_t C, adnm_stream_t stream);
 /* Elementwise product y = a * b of two (M, C) fp32 token matrices with row strides lda / ldb (y, da, db contiguous): VSSD's output gate
  * LayerNorm(y) * z (Vssd.py:280-281).  4 | C. */
 int adnm_emul_fwd(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t M, int64_t C, adnm_stream_t stream);
@@ -335,6 +333,16 @@ int adnm_bridge_heads_bwd(const float* att, const float* const* W, const int64_t
                           const float* threshold, const float* const* z, const float* const* dy, float* datt, float* const* dW,
                           float* const* dbias, float* denhance, float* dthreshold, void* ws, int64_t ws_bytes, int64_t B, int64_t S,
                           adnm_stream_t stream);
+
+/* The bridge's global average pools, grouped (Channel_Att_Bridge.forward, model_untils.py:570-590: AdaptiveAvgPool2d(1) of each skip, then
+ * torch.cat along the channels): ONE launch + one fold for all n <= 8 skips.  x[k]: (B, L[k], C[k]) contiguous fp32 tokens, 4 | C[k];
+ * att: (B, S = sum C[k]) OVERWRITTEN, skip k at columns [sum_{j<k} C[j], ...).  bwd: dx[k] = dxa[k] (or 0 when NULL) + datt[:, cols of k] / L[k]
+ * broadcast over the tokens, one launch for all skips (dx[k] NULL skips skip k). */
+int64_t adnm_bridge_pool_ws_bytes(int64_t B, int64_t S);
+int adnm_bridge_pool_fwd(int64_t n, const float* const* x, const int64_t* L, const int64_t* C, float* att, void* ws, int64_t ws_bytes, int64_t B,
+                         adnm_stream_t stream);
+int adnm_bridge_pool_bwd(int64_t n, const float* const* dxa, const float* datt, const int64_t* L, const int64_t* C, float* const* dx, int64_t B,
+                         adnm_stream_t stream);
 
 /* out[c] = sum_r x[r*n + c] for a contiguous (rows, n) fp32 matrix — nn.Linear's bias gradient (autograd's sum over the token
  * rows) when the weight gradient is computed elsewhere (the transposed conv's).  Deterministic (fixed tree), OVERWRITES out; matrices

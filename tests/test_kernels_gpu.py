@@ -267,6 +267,24 @@ def test_haar_roundtrip_full_size():
         assert_close(back, x, 1e-6, "haar round trip")
 
 
+@pytest.mark.parametrize("B,H,W,C,levels,dtype", [(2, 128, 128, 32, 3, torch.float32), (1, 37, 51, 8, 3, torch.float32), (2, 19, 23, 12, 2, torch.float32),
+                                                  (1, 45, 30, 4, 5, torch.float32), (2, 64, 64, 16, 3, torch.bfloat16)])
+def test_haar_synthesis_cascade(B, H, W, C, levels, dtype):
+    """the synthesis cascade (three levels per launch, LL addends derived from the coarser levels' sub-bands) against the chain of
+    single-level launches: bitwise, odd sizes and both storage types included; the two optional output addends ride in the finest launch."""
+    shapes, bands, (h, w) = [], [], (H, W)
+    for i in range(levels):
+        shapes.append((h, w))
+        h, w = (h + 1) // 2, (w + 1) // 2
+        bands.append(T(f"hs.{i}.{H}", (B * h * w, 4 * C)).to(DEV).to(dtype))
+    adds = (T(f"hs.a.{H}", (B * H * W, C)).to(DEV).to(dtype), T(f"hs.b.{H}", (B * H * W, C)).to(DEV).to(dtype))
+    nxt = None
+    for i in range(levels - 1, -1, -1):
+        nxt = ops.k_haar_idwt(bands[i], nxt, B, shapes[i][0], shapes[i][1], C, y_add=adds if i == 0 else ())
+    got = ops.k_haar_synthesis(bands, shapes, B, C, y_add=adds)
+    assert torch.equal(got, nxt)
+
+
 # ------------------------------------------------------------------------------------------- InstanceNorm
 @pytest.mark.parametrize("B,HW,C,act", [(4, 16384, 32, lib.ACT_NONE), (2, 1024, 64, lib.ACT_GELU), (2, 16, 1024, lib.ACT_NONE), (3, 77, 12, lib.ACT_GELU)])
 def test_instnorm(B, HW, C, act):
@@ -625,16 +643,24 @@ def test_skgemm_strided_operands():
     assert float(big_out[:, :16].abs().max()) == 0.0 and float(big_out[:, 16 + N:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("B,L,C", [(4, 4096, 32), (2, 16, 1024), (3, 700, 64)])
-def test_tokmean_tap(B, L, C):
-    x, c1, c2 = T(f"tm.x{L}", (B, L, C)), T(f"tm.c1{L}", (B, L, C)), T(f"tm.c2{L}", (B, C))
-    xo = leaf(x.double())
-    ((xo * c1.double()).sum() + (xo.mean(1) * c2.double()).sum()).backward()
-    xg = leaf(x, DEV)
-    xa, m = ops.tokmean_tap(xg)
-    ((xa * c1.to(DEV)).sum() + (m * c2.to(DEV)).sum()).backward()
-    assert_close(m, x.double().mean(1), OUT_TOL, "mean")
-    assert_close(xg.grad, xo.grad, GRAD_TOL, "dx = consumer gradient + broadcast pool gradient")
+@pytest.mark.parametrize("B,shapes", [(4, [(16384, 32), (4096, 64), (1024, 128), (256, 256), (64, 512), (16, 512), (4, 1024)]),
+                                      (2, [(700, 64)]), (3, [(33, 8), (5, 4), (1, 12)])])
+def test_bridge_pool(B, shapes):
+    """Channel_Att_Bridge's avgpool of every skip + the concat as one launch each way; every skip comes back as an alias whose consumer
+    gradient is summed with the pool's broadcast gradient in the one backward launch (one skip is left without another consumer)."""
+    xs = [T(f"bp.x{i}.{L}", (B, L, C)) for i, (L, C) in enumerate(shapes)]
+    cs = [T(f"bp.c{i}.{L}", (B, L, C)) for i, (L, C) in enumerate(shapes)]
+    S = sum(C for _, C in shapes)
+    c2 = T(f"bp.m{S}", (B, S))
+    xo = [leaf(x.double()) for x in xs]
+    atto = torch.cat([x.mean(1) for x in xo], dim=-1)
+    (sum((x * c.double()).sum() for x, c in list(zip(xo, cs))[1:]) + (atto * c2.double()).sum()).backward()
+    xg = [leaf(x, DEV) for x in xs]
+    al, att = ops.bridge_pool(xg)
+    (sum((a * c.to(DEV)).sum() for a, c in list(zip(al, cs))[1:]) + (att * c2.to(DEV)).sum()).backward()
+    assert_close(att, atto, OUT_TOL, "pooled means")
+    for i, (g, o) in enumerate(zip(xg, xo)):
+        assert_close(g.grad, o.grad, GRAD_TOL, f"dx[{i}] = consumer gradient + broadcast pool gradient")
 
 
 def test_conv1d3():
@@ -681,7 +707,7 @@ def test_unsupported_shapes_raise():
     with pytest.raises(RuntimeError, match="no PyTorch fallback"):
         ops.igate(torch.zeros(3, device=DEV), one, one)
     with pytest.raises(RuntimeError, match="no PyTorch fallback"):
-        ops.tokmean_tap(odd)
+        ops.bridge_pool([odd.view(1, 5, 6)])
     with pytest.raises(RuntimeError, match="no PyTorch fallback"):
         ops.conv1d3(torch.zeros(2, 2, 8, device=DEV), torch.zeros(1, 1, 3, device=DEV), None)
     with pytest.raises(RuntimeError, match="adnm_hip linear"):
