@@ -1800,7 +1800,8 @@ def k_linear_dw(dy2, x2, want_bias, w_ptr=0, b_ptr=0, dw_out=None):
         ws = _ws(nb, dev)
         pdw, pdb = dw.data_ptr(), _p(db)
         dty, dtx = _dt(dy2), _dt(x2)
-        SIDE.submit(dev, (dy2, x2), FOLDS.defer(dev, ws), lambda: lib.call(
+        # (the operands stay referenced until the flush: under the leaf queue the GEMM itself is deferred, not just its fold)
+        SIDE.submit(dev, (dy2, x2), FOLDS.defer(dev, ws, dy2, x2), lambda: lib.call(
             "adnm_tsgemm_tn", dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), pdw, pdb, ws.data_ptr(), nb, M, N, K, dty, dtx, _stream()))
         return dw, db
     dy2, x2 = _sk_operand(dy2, "output gradient"), _sk_operand(x2, "input")

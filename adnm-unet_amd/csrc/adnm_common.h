@@ -49,10 +49,12 @@ struct AdnmLeaf {
   double bytes;
   alignas(16) unsigned char args[200];
 };
-enum { ADNM_LEAF_SKGEMM_TN = 0, ADNM_LEAF_DWCONV_WGRAD_K3 = 1, ADNM_LEAF_DWCONV_WGRAD_K5 = 2, ADNM_LEAF_KINDS = 3 };
+enum { ADNM_LEAF_SKGEMM_TN = 0, ADNM_LEAF_DWCONV_WGRAD_K3 = 1, ADNM_LEAF_DWCONV_WGRAD_K5 = 2, ADNM_LEAF_TSGEMM_TN = 3, ADNM_LEAF_KINDS = 4 };
+bool adnm_leafq_active();                                                    // would a push be queued?
 bool adnm_leafq_push(const AdnmLeaf& leaf);                                  // false: no queue bound on this thread (launch now)
 int adnm_skgemm_tn_launch_multi(const AdnmLeaf* const* items, int n, hipStream_t st);   // skgemm.hip
 int adnm_dwconv_wgrad_launch_multi(const AdnmLeaf* const* items, int n, int K, hipStream_t st);   // dwconv.hip
+int adnm_tsgemm_tn_launch_multi(const AdnmLeaf* const* items, int n, hipStream_t st);   // tsgemm.hip
 
 #define ADNM_REQUIRE(cond, ...)            \
   do {                                     \

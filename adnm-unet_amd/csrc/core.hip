@@ -314,6 +314,7 @@ struct LeafQueue {
 };
 thread_local LeafQueue* tls_leafq = nullptr;
 }  // namespace
+bool adnm_leafq_active() { return tls_leafq && tls_foldq; }
 bool adnm_leafq_push(const AdnmLeaf& leaf) {
   if (!tls_leafq || !tls_foldq) return false;   // (a leaf's partials are folded by a QUEUED fold: without the fold queue the order would break)
   tls_leafq->items.push_back(leaf);
@@ -346,6 +347,7 @@ extern "C" int adnm_leafq_flush(void* q, adnm_stream_t stream) {
       if (l.kind == kind) sel.push_back(&l);
     if (sel.empty()) continue;
     if (kind == ADNM_LEAF_SKGEMM_TN) rc = adnm_skgemm_tn_launch_multi(sel.data(), (int)sel.size(), (hipStream_t)stream);
+    else if (kind == ADNM_LEAF_TSGEMM_TN) rc = adnm_tsgemm_tn_launch_multi(sel.data(), (int)sel.size(), (hipStream_t)stream);
     else rc = adnm_dwconv_wgrad_launch_multi(sel.data(), (int)sel.size(), kind == ADNM_LEAF_DWCONV_WGRAD_K3 ? 3 : 5, (hipStream_t)stream);
   }
   lq->items.clear();

@@ -377,8 +377,18 @@ WGeo wgeo(int64_t B, int64_t H, int64_t W, int64_t C, int K) {
   const int64_t tiles = B * H * adnm_cdiv(W, TW);
   // tiles per lane: 8 on the big maps; on the deep ones fewer (down to 2 = one trip of the two-tiles-in-flight loop), so that the
   // grid still has ~256 workgroups instead of a handful of lanes walking a long dependent chain
+  // (queued for the grouped launch the other problems fill the chip: longer walks per lane = fewer workgroup tails and fewer partial
+  // rows for the fold; ADNM_DW_WG_TPL: measurement aid)
+  static const int grouped_tpl = [] {
+    const char* e = getenv("ADNM_DW_WG_TPL");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 16;
+  }();
+  const bool walker = K == 3 && H * W >= 128 * 128;
+  const int64_t tmax = !walker && adnm_leafq_active() ? grouped_tpl : 8;
   int64_t tpl = (tiles * g.gx) / ((int64_t)slots * 256);
-  tpl = tpl < 2 ? 2 : (tpl > 8 ? 8 : tpl);
+  if (tmax > 8 && tpl >= 8) tpl = tmax;
+  tpl = tpl < 2 ? 2 : (tpl > tmax ? tmax : tpl);
   int64_t npb = adnm_cdiv(tiles, (int64_t)slots * tpl);
   int64_t cap = (4 << 20) / ((int64_t)(K * K + 1) * C * 4);     // keep the partials under ~4 MB
   if (cap > 1024) cap = 1024;
@@ -388,7 +398,7 @@ WGeo wgeo(int64_t B, int64_t H, int64_t W, int64_t C, int K) {
   g.npb = (int)npb;
   g.rows = g.npb;
   g.seg = g.nseg = 0;
-  if (K == 3 && H * W >= 128 * 128) {   // column walker — measured: 37.6 -> 29.7 us on the 128x128x128 stencil, slower than the tap-row
+  if (walker) {   // column walker — measured: 37.6 -> 29.7 us on the 128x128x128 stencil, slower than the tap-row
                                          // kernel on 64x64 and smaller maps (short strips: halo rows and the block reduction dominate)
     const int64_t WT = adnm_cdiv(W, TW);
     int64_t seg = (H * B * WT * C4) / 65536;

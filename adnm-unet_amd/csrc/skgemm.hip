@@ -464,7 +464,14 @@ Plan plan_deferred(int64_t I, int64_t J, int64_t R, bool direct, bool bf16) {
     }
     while (pl.wpt > 1 && pl.wpt > pl.nchunks) pl.wpt >>= 1;
   } else {
-    int want = (int)adnm_cdiv(2048, pl.ntiles);
+    // waves per problem: alone, a weight gradient needs every CU (2048 waves); queued for the grouped launch the other problems fill
+    // the chip, and fewer reduction slices mean fewer partial slabs to write and fold (ADNM_SK_TN_WAVES: measurement aid)
+    static const int grouped_waves = [] {
+      const char* e = getenv("ADNM_SK_TN_WAVES");
+      const int v = e ? atoi(e) : 0;
+      return v > 0 ? v : 256;
+    }();
+    int want = (int)adnm_cdiv(adnm_leafq_active() ? grouped_waves : 2048, pl.ntiles);
     if (want > pl.nchunks) want = pl.nchunks;
     if (want < 1) want = 1;
     pl.wpt = 1;

@@ -211,14 +211,15 @@ __global__ __launch_bounds__(kBlock) void tsgemm_nt_kernel(const AT* __restrict_
 
 // ---------------------------------------------------------------------------------------------- tn: dW = dY^T . X
 // part[blockIdx.x][n][k]; A = dY^T (16 n x 4 m), B = X (4 m x 16 k)
+// (bx, by, nbx): this workgroup's row-band index, its N-tile and the number of row bands of ITS problem — the grid of the single-problem
+// launch, a block range of the grouped launch (tsgemm_tn_multi_kernel)
 template <int NBN, int NBK, typename YT, typename XT>
-__global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const YT* __restrict__ dy, int64_t lddy, const XT* __restrict__ x,
-                                                           int64_t ldx, float* __restrict__ part, float* __restrict__ bpart, int64_t M,
-                                                           int N, int K) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // 4 x (NBN*NBK*256 + NBN*16)
+__device__ __forceinline__ void tsgemm_tn_body(const YT* __restrict__ dy, int64_t lddy, const XT* __restrict__ x, int64_t ldx, float* __restrict__ part,
+                                               float* __restrict__ bpart, int64_t M, int N, int K, const int bx, const int by, const int nbx,
+                                               float* __restrict__ sm) {   // sm: 4 x (NBN*NBK*256 + NBN*16) floats
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
-  const int nb0 = blockIdx.y * NBN * 16;  // first output row (n) of this block's tile
+  const int nb0 = by * NBN * 16;  // first output row (n) of this block's tile
   f32x4 acc[NBN][NBK];
   float bsum[NBN];
 #pragma unroll
@@ -228,36 +229,45 @@ __global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const YT* __restrict_
     for (int b = 0; b < NBK; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int64_t nmb = (M + 3) >> 2;
-  const int64_t stride = (int64_t)gridDim.x * kWaves;
-  float av[NBN], bv[NBK], an[NBN], bn[NBK];
-  auto fetch = [&](int64_t mb, float (&a_)[NBN], float (&b_)[NBK]) {
-    const int64_t m = mb * 4 + kk;
-    const bool mv = mb < nmb && m < M;
+  const int64_t stride = (int64_t)nbx * kWaves;
+  // D rounds of operand loads in flight per wave: one round is (NBN + NBK) x 256 B — with one round ahead a CU had ~30 KB outstanding,
+  // i.e. the kernel ran at latency x bytes-in-flight (2.3 TB/s at the 65 536-token level) instead of at the HBM rate
+  constexpr int D = NBN + NBK <= 6 ? 4 : (NBN + NBK <= 10 ? 3 : (NBN * NBK <= 16 ? 2 : 1));   // (the 26-block tile has no registers to spare)
+  float ra[D + 1][NBN], rb[D + 1][NBK];
+  // UNCONDITIONAL loads from clamped (valid) addresses: a predicated load becomes a branch around it, and across branches the compiler
+  // gives up counting outstanding loads — every round then waited for ALL loads in flight (s_waitcnt vmcnt(0)) and the ring was worth
+  // nothing.  A row past M is clamped to the last row and its dY values are zeroed when the round is CONSUMED (0 x finite = 0; the bias
+  // sum takes the zeroed value too); a column past N / K is clamped to the last column and lands in accumulator rows / columns that are
+  // never stored.  Addresses are uniform base + 32-bit lane offset (host-checked: M * ld < 2^31): one register per load in flight.
+  const uint32_t cn = (uint32_t)(nb0 + i), ck = (uint32_t)i, nmax = (uint32_t)(N - 1), kmax = (uint32_t)(K - 1);
+  const uint32_t lddy32 = (uint32_t)lddy, ldx32 = (uint32_t)ldx, mlast = (uint32_t)(M - 1);
+  auto fetch = [&](int64_t mb_, float (&a_)[NBN], float (&b_)[NBK]) {
+    const int64_t m64 = mb_ * 4 + kk;
+    const uint32_t m = m64 < M ? (uint32_t)m64 : mlast;
+    const uint32_t oa = m * lddy32, ob = m * ldx32;
 #pragma unroll
-    for (int a = 0; a < NBN; ++a) {
-      const int n = nb0 + a * 16 + i;
-      a_[a] = (mv && n < N) ? Io<YT>::ld(dy + m * lddy + n) : 0.f;
-    }
+    for (int a = 0; a < NBN; ++a) a_[a] = Io<YT>::ld(dy + (oa + min(cn + 16u * a, nmax)));
 #pragma unroll
-    for (int b = 0; b < NBK; ++b) {
-      const int k = b * 16 + i;
-      b_[b] = (mv && k < K) ? Io<XT>::ld(x + m * ldx + k) : 0.f;
-    }
+    for (int b = 0; b < NBK; ++b) b_[b] = Io<XT>::ld(x + (ob + min(ck + 16u * b, kmax)));
   };
-  int64_t mb = (int64_t)blockIdx.x * kWaves + wave;
-  fetch(mb, av, bv);
-  for (; mb < nmb; mb += stride) {
-    fetch(mb + stride, an, bn);   // next round's loads fly under this round's MFMAs
+  int64_t mb = (int64_t)bx * kWaves + wave;
 #pragma unroll
-    for (int a = 0; a < NBN; ++a) bsum[a] += av[a];
+  for (int s = 0; s < D; ++s) fetch(mb + s * stride, ra[s], rb[s]);
+  for (; mb < nmb; mb += (D + 1) * stride) {
 #pragma unroll
-    for (int a = 0; a < NBN; ++a)
+    for (int s = 0; s <= D; ++s) {   // slot s holds round mb + s * stride
+      fetch(mb + (s + D) * stride, ra[(s + D) % (D + 1)], rb[(s + D) % (D + 1)]);
+      const bool mv = (mb + s * stride) * 4 + kk < M;
+      float av[NBN];
 #pragma unroll
-      for (int b = 0; b < NBK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+      for (int a = 0; a < NBN; ++a) av[a] = mv ? ra[s][a] : 0.f;
 #pragma unroll
-    for (int a = 0; a < NBN; ++a) av[a] = an[a];
+      for (int a = 0; a < NBN; ++a) bsum[a] += av[a];
 #pragma unroll
-    for (int b = 0; b < NBK; ++b) bv[b] = bn[b];
+      for (int a = 0; a < NBN; ++a)
+#pragma unroll
+        for (int b = 0; b < NBK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], rb[s][b], acc[a][b], 0, 0, 0);
+    }
   }
   // bias gradient: lanes with the same i (n) but different kk hold different m's
 #pragma unroll
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const YT* __restrict_
   }
   if (wave == 0) {
     const int64_t rowlen = (int64_t)N * K + (bpart ? N : 0);   // one partial row = [dW tile rows | bias sums]: ONE fold for both
-    float* dst = part + (int64_t)blockIdx.x * rowlen;
+    float* dst = part + (int64_t)bx * rowlen;
 #pragma unroll
     for (int a = 0; a < NBN; ++a) {
 #pragma unroll
@@ -311,6 +321,55 @@ __global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const YT* __restrict_
   }
 }
 
+template <int NBN, int NBK, typename YT, typename XT>
+__global__ __launch_bounds__(kBlock) void tsgemm_tn_kernel(const YT* __restrict__ dy, int64_t lddy, const XT* __restrict__ x, int64_t ldx,
+                                                           float* __restrict__ part, float* __restrict__ bpart, int64_t M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  tsgemm_tn_body<NBN, NBK, YT, XT>(dy, lddy, x, ldx, part, bpart, M, N, K, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, sm);
+}
+
+// The weight-gradient GEMMs of a backward stage in ONE launch.  Each of them is a leaf (nothing reads dW before the optimiser) and, at
+// the 65 536-token level, a SHORT kernel: 25 - 60 MB streamed in ~8 us between a launch ramp and a tail (LDS tree over the 8 waves, one
+// wave's stores) of comparable length — 20 launches per step at config 2 ran at 2.3 TB/s.  Queued (core.hip: adnm_leafq_*) and launched
+// together, one problem's tail overlaps the next one's stream.  fp32 storage only; the descriptor table lives in the kernarg segment.
+constexpr int kMaxTn = 24;
+struct TnArgs {
+  const float* dy;
+  const float* x;
+  float* part;
+  float* bpart;
+  int64_t lddy, ldx, M;
+  int N, K, a, b, nblk, ntiles;
+};
+struct MultiTn {
+  int count;
+  int blk_end[kMaxTn];
+  TnArgs p[kMaxTn];
+};
+__global__ __launch_bounds__(kBlock) void tsgemm_tn_multi_kernel(MultiTn m_by_value) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  (void)m_by_value;
+  const __attribute__((address_space(4))) MultiTn& m = *(const __attribute__((address_space(4))) MultiTn*)__builtin_amdgcn_kernarg_segment_ptr();
+  int k = 0;
+  while (k + 1 < m.count && (int)blockIdx.x >= m.blk_end[k]) ++k;
+  const int local = (int)blockIdx.x - (k ? m.blk_end[k - 1] : 0);
+  const float* dy = m.p[k].dy;
+  const float* x = m.p[k].x;
+  float* part = m.p[k].part;
+  float* bpart = m.p[k].bpart;
+  const int64_t lddy = m.p[k].lddy, ldx = m.p[k].ldx, M = m.p[k].M;
+  const int N = m.p[k].N, K = m.p[k].K, nblk = m.p[k].nblk;
+  const int bx = local % nblk, by = local / nblk;
+  const int variant = m.p[k].a * 32 + m.p[k].b;   // workgroup-uniform
+#define TN(A, B) case A * 32 + B: tsgemm_tn_body<A, B, float, float>(dy, lddy, x, ldx, part, bpart, M, N, K, bx, by, nblk, sm); break
+  switch (variant) {
+    TN(1, 1); TN(1, 2); TN(1, 4); TN(1, 8); TN(1, 13); TN(1, 16); TN(2, 1); TN(2, 2); TN(2, 4); TN(2, 8); TN(2, 13);
+    TN(4, 1); TN(4, 2); TN(4, 4); TN(8, 1); TN(8, 2); TN(13, 1); TN(13, 2); TN(16, 1);
+    default: break;
+  }
+#undef TN
+}
+
 int rows_per_wave(const char* name, int dflt) {   // measurement aid: ADNM_TS_NT_RPW / ADNM_TS_TN_RPW override the row blocks per wave
   const char* e = getenv(name);
   const int v = e ? atoi(e) : 0;
@@ -325,9 +384,14 @@ int nt_blocks(int64_t M, bool bf16) {
   if (b > 1024) b = 1024;
   return (int)(b < 1 ? 1 : b);
 }
-int tn_blocks(int64_t M) {
+// row bands (= partial rows for the fold) of one problem.  Launched alone a problem needs one band per CU; inside the grouped launch the
+// other problems fill the chip, and fewer, longer bands amortise a band's tail (LDS tree + store) and halve the fold's reads: measured
+// in one session at config 2, 20 problems: 256 bands 328 us, 128 bands 266 us, 64 bands 248 us (ADNM_TS_TN_BLOCKS overrides the grouped figure)
+int tn_blocks(int64_t M, bool grouped = false) {
+  static const int gcap = rows_per_wave("ADNM_TS_TN_BLOCKS", 64);
+  const int cap = grouped ? gcap : 256;
   int64_t b = adnm_cdiv(adnm_cdiv(M, 4), kWaves * 8);  // >= 8 MFMA rounds per wave
-  if (b > 256) b = 256;
+  if (b > cap) b = cap;
   return (int)(b < 1 ? 1 : b);
 }
 
@@ -375,7 +439,8 @@ int launch_tn(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* p
 }
 
 // tile the N axis so that one block keeps at most 32 accumulator blocks: returns NBN (blocks of 16 rows per tile)
-// (<= 16 blocks = 64 accumulator VGPRs, 26 for the 13-wide in_proj case: the 32-block variants spill to scratch)
+// (<= 16 blocks = 64 accumulator VGPRs, 26 for the 13-wide in_proj case — tiling that one to 2 x (8, 2) re-reads X and measured 9 %
+// slower; the 32-block variants spill to scratch)
 inline int tn_tile(int nbn_total, int nbk) {
   int t = nbk == 13 ? 2 : 16 / nbk;
   if (t > 16) t = 16;
@@ -433,6 +498,42 @@ extern "C" int adnm_tsgemm_nt(const void* x, int64_t ldx, const float* w, int64_
   return ADNM_OK;
 }
 
+namespace {
+bool tn_variant(int a, int b) {   // the (N/16, K/16) tiles the grouped kernel's switch holds (= every variant of the single-problem dispatch)
+  static const int v[][2] = {{1, 1}, {1, 2}, {1, 4}, {1, 8}, {1, 13}, {1, 16}, {2, 1}, {2, 2}, {2, 4}, {2, 8}, {2, 13}, {4, 1}, {4, 2}, {4, 4}, {8, 1}, {8, 2}, {13, 1}, {13, 2}, {16, 1}};
+  for (const auto& e : v)
+    if (e[0] == a && e[1] == b) return true;
+  return false;
+}
+}  // namespace
+
+// the queued weight-gradient problems, kMaxTn per launch
+int adnm_tsgemm_tn_launch_multi(const AdnmLeaf* const* items, int n, hipStream_t st) {
+  int i = 0;
+  while (i < n) {
+    MultiTn m;
+    m.count = 0;
+    int blocks = 0;
+    double bytes = 0;
+    size_t smem = 0;
+    for (; i < n && m.count < kMaxTn; ++i) {
+      memcpy(&m.p[m.count], items[i]->args, sizeof(TnArgs));
+      const TnArgs& t = m.p[m.count];
+      const size_t need = (size_t)(kWaves / 2) * (t.a * t.b * 256 + t.a * 16) * sizeof(float);
+      smem = need > smem ? need : smem;
+      blocks += items[i]->grid;
+      m.blk_end[m.count++] = blocks;
+      bytes += items[i]->bytes;
+    }
+    for (int k = m.count; k < kMaxTn; ++k) m.blk_end[k] = blocks;
+    ADNM_PROF("tsgemm_tn", st, bytes);
+    ADNM_ALLOW_LDS(tsgemm_tn_multi_kernel, smem, "tsgemm_tn (grouped)");
+    tsgemm_tn_multi_kernel<<<(unsigned)blocks, kBlock, smem, st>>>(m);
+  }
+  ADNM_CHECK_LAUNCH("tsgemm_tn (grouped)");
+  return ADNM_OK;
+}
+
 extern "C" int adnm_tsgemm_tn_supported(int64_t M, int64_t N, int64_t K) {
   if (M < 1 || N < 1 || K < 1 || N > 1024 || K > 256) return 0;
   const int b = pick((int)adnm_cdiv(K, 16), kNB, 6);
@@ -459,12 +560,25 @@ extern "C" int adnm_tsgemm_tn(const void* dy, int64_t lddy, const void* x, int64
     if (a < 0) a = 1;
     ntiles = (int)adnm_cdiv(nbn_total, a);
   }
-  const int nblk = tn_blocks(M);
+  ADNM_REQUIRE(M * lddy < (1ll << 31) && M * ldx < (1ll << 31), "tsgemm_tn: operands beyond 2^31 elements (32-bit lane offsets)");
+  const bool leafy = dy_dtype == ADNM_F32 && x_dtype == ADNM_F32 && tn_variant(a, b) && adnm_leafq_active();
+  const int nblk = tn_blocks(M, leafy);
   float* part = (float*)ws;
   float* bpart = dbias ? part : nullptr;   // non-null = "emit the bias sums at the end of every partial row"
   hipStream_t st = (hipStream_t)stream;
   int rc = ADNM_EINVAL;
-#define TN(A, B) if (a == A && b == B) rc = launch_tn<A, B>(dy, lddy, x, ldx, part, bpart, M, (int)N, (int)K, nblk, ntiles, dy_dtype == ADNM_BF16, x_dtype == ADNM_BF16, st)
+  if (leafy) {   // a leaf: waits for the grouped launch
+    static_assert(sizeof(TnArgs) <= sizeof(AdnmLeaf::args), "TnArgs must fit a leaf record");
+    TnArgs t;
+    t.dy = (const float*)dy, t.x = (const float*)x, t.part = part, t.bpart = bpart, t.lddy = lddy, t.ldx = ldx, t.M = M;
+    t.N = (int)N, t.K = (int)K, t.a = a, t.b = b, t.nblk = nblk, t.ntiles = ntiles;
+    AdnmLeaf leaf;
+    leaf.kind = ADNM_LEAF_TSGEMM_TN, leaf.grid = nblk * ntiles, leaf.prec = ADNM_MFMA_F32, leaf.prof = "tsgemm_tn";
+    leaf.bytes = 4.0 * ((double)M * (K + N) + (double)N * K);
+    memcpy(leaf.args, &t, sizeof(TnArgs));
+    if (adnm_leafq_push(leaf)) rc = ADNM_OK;
+  }
+#define TN(A, B) if (rc != ADNM_OK) if (a == A && b == B) rc = launch_tn<A, B>(dy, lddy, x, ldx, part, bpart, M, (int)N, (int)K, nblk, ntiles, dy_dtype == ADNM_BF16, x_dtype == ADNM_BF16, st)
   TN(1, 1); TN(1, 2); TN(1, 4); TN(1, 8); TN(1, 13); TN(1, 16); TN(2, 1); TN(2, 2); TN(2, 4); TN(2, 8); TN(2, 13);
   TN(4, 1); TN(4, 2); TN(4, 4); TN(8, 1); TN(8, 2); TN(13, 1); TN(13, 2); TN(16, 1);
 #undef TN

@@ -707,7 +707,7 @@ def test_unsupported_shapes_raise():
     with pytest.raises(RuntimeError, match="no PyTorch fallback"):
         ops.igate(torch.zeros(3, device=DEV), one, one)
     with pytest.raises(RuntimeError, match="no PyTorch fallback"):
-        ops.bridge_pool([odd.view(1, 5, 6)])
+        ops.bridge_pool([odd])
     with pytest.raises(RuntimeError, match="no PyTorch fallback"):
         ops.conv1d3(torch.zeros(2, 2, 8, device=DEV), torch.zeros(1, 1, 3, device=DEV), None)
     with pytest.raises(RuntimeError, match="adnm_hip linear"):
