@@ -156,12 +156,24 @@ __global__ __launch_bounds__(kBlock) void skip_pool_bwd_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------ gated branches, forward
+template <int T>
+__device__ __forceinline__ void load_group_weights(const float* __restrict__ src, float (&wg)[16 * T]) {
+#pragma unroll
+  for (int e = 0; e < 16 * T; e += 4) {
+    const float4 v = ld4(src + e);
+    wg[e] = v.x, wg[e + 1] = v.y, wg[e + 2] = v.z, wg[e + 3] = v.w;
+  }
+}
+
 template <int K>
 __device__ __forceinline__ void conv4(const float* __restrict__ p, const float* __restrict__ wk, const float* __restrict__ bk, const Geo& g, int b,
                                       int h, int w, int cg, float c[4]) {
   constexpr int T = Taps<K>::T;
   f4(ld4(bk + cg * 4), c);
-  const float* wg = wk + (int64_t)cg * 16 * T;
+  // the group's 16 T weights: 16-byte loads (lanes are whole groups apart, so every load instruction touches 64 cache lines — as 240
+  // dword loads per lane this was what the kernel's 31 us consisted of)
+  float wg[16 * T];
+  load_group_weights<T>(wk + (int64_t)cg * 16 * T, wg);
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const int hh = h + Taps<K>::di(t), ww = w + Taps<K>::dj(t);
@@ -296,7 +308,8 @@ __device__ __forceinline__ void dgrad4(const float* __restrict__ dc, const float
                                        float o[4]) {
   constexpr int T = Taps<K>::T;
   o[0] = o[1] = o[2] = o[3] = 0.f;
-  const float* wg = wk + (int64_t)cg * 16 * T;
+  float wg[16 * T];
+  load_group_weights<T>(wk + (int64_t)cg * 16 * T, wg);
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const int hh = h - Taps<K>::di(t), ww = w - Taps<K>::dj(t);   // the output pixel that read us through tap t
@@ -400,7 +413,14 @@ int load_params(const char* who, const float* const* params, Params* P) {
   P->gamma = params[17];
   return ADNM_OK;
 }
-int slices_pointwise(const Geo& g) { return (int)(g.npix < 4 ? 1 : (g.npix / 4 > 512 ? 512 : g.npix / 4)); }
+int slices_pointwise(const Geo& g) {   // pixels per lane of the pointwise backward = npix / slices (ADNM_SKIP_PPL: measurement aid)
+  static const int ppl = [] {
+    const char* e = getenv("ADNM_SKIP_PPL");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 1;   // measured in one session (3 gates per step): 4 pixels per lane 73 us, 2: 48, 1: 37
+  }();
+  return (int)(g.npix < ppl ? 1 : (g.npix / ppl > 1024 ? 1024 : g.npix / ppl));
+}
 int64_t scal_rows(const Geo& g, int S) { return adnm_cdiv((int64_t)S * g.C4, kBlock) * (kBlock / 64); }   // one per launched wave
 int slices_wgrad(const Geo& g) { return (int)(g.npix / 64 < 1 ? 1 : (g.npix / 64 > 16 ? 16 : g.npix / 64)); }   // x 16 in-wave sub-slices
 struct WsLayout {
