@@ -5,6 +5,7 @@ torch's caching allocator only, so a whole training step is hipGraph-capturable.
 Layout convention: token tensors are (B, L, C) / (M, C) channels-last; a "row view" is a 2-D
 tensor with stride (ld, 1) — kernels take the row stride, so column slices of wide buffers are
 passed without copies."""
+import math
 import os
 import threading
 
@@ -280,10 +281,15 @@ class GradRegistry:
             if ent is not None:
                 owner, g = ent
                 fits = tuple(g.shape) == tuple(shape) and g.dtype == dtype and (strides is None or tuple(g.stride()) == tuple(strides))
-                if ptr not in self._claimed[owner] and fits:
+                # the same dense memory under another shape — a (4d, d, 1, 1) conv weight whose gradient a GEMM writes as (4d, d), a
+                # (C, 1, 3, 3) depthwise weight written as (C, 9): the caller gets the slice viewed its way (25 M of config 2's 72 M
+                # gradient elements used to be refused here and copied by the trainer's gather)
+                dense = (not fits and g.dtype == dtype and g.is_contiguous() and g.numel() == math.prod(shape)
+                         and (strides is None or tuple(strides) == tuple(torch.empty(tuple(shape), device="meta").stride())))
+                if ptr not in self._claimed[owner] and (fits or dense):
                     self._claimed[owner].add(ptr)
                     # a fresh tensor object on the same memory: AccumulateGrad only keeps ("steals") a gradient nobody else references
-                    return g.detach()
+                    return g.detach() if fits else g.detach().view(tuple(shape))
                 second = ptr in self._claimed[owner]
                 if second:
                     self._multi[owner].add(ptr)

@@ -81,6 +81,25 @@ def test_grad_registry_drop_is_lock_free_and_reentrant():
     assert got.data_ptr() == w.data_ptr() and w.data_ptr() in reg.born_in_place(2)
 
 
+def test_grad_registry_hands_out_dense_slices_under_another_shape():
+    """A (4d, d, 1, 1) conv weight whose gradient a GEMM writes as (4d, d): the same dense memory, so the claim succeeds with the slice
+    viewed the caller's way (and is recorded: the trainer's gather then skips the copy); a non-dense layout is still refused."""
+    from adnm_hip.ops import GradRegistry
+    reg = GradRegistry()
+    g = torch.zeros(8, 4, 1, 1)
+    reg.register(7, {g.data_ptr(): g})
+    t = reg.take(g.data_ptr(), (8, 4), g.device)
+    assert t.shape == (8, 4) and t.data_ptr() == g.data_ptr() and g.data_ptr() in reg.born_in_place(7)
+    h = torch.zeros(6, 5)[:, :4]   # not dense
+    reg.register(8, {h.data_ptr(): h})
+    u = reg.take(h.data_ptr(), (24,), h.device)
+    assert u.data_ptr() != h.data_ptr() and h.data_ptr() not in reg.born_in_place(8)
+    k = torch.zeros(8, 4)
+    reg.register(9, {k.data_ptr(): k})
+    v = reg.take(k.data_ptr(), (4, 8), k.device, strides=(1, 4))   # the caller would write a transposed layout: refused
+    assert v.data_ptr() != k.data_ptr() and k.data_ptr() not in reg.born_in_place(9)
+
+
 def test_bench_multi_rank_launcher_reports_a_dead_rank():
     """`python bench.py --gpus 2` on a box without GPUs: both ranks exit at once ("needs a GPU"); the parent must notice, stop the
     job and exit non-zero within seconds instead of waiting for a rendezvous that never happens."""
