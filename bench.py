@@ -46,18 +46,20 @@ FAMILIES = [
     ("K4 depthwise 3x3 stencil", ("dwconv_k3",)),
     ("K3 depthwise 5x5 stencil (WTConv)", ("dwconv_k5",)),
     ("K3/K4 depthwise weight gradient", ("dwconv_wgrad_k3", "dwconv_wgrad_k5")),
-    ("K3 Haar DWT/IDWT", ("haar_dwt", "haar_idwt", "wt_level_fwd", "wt_level_bwd")),
-    ("K2/K7 row norms", ("rownorm_fwd", "rownorm_bwd")),
+    ("K3 Haar DWT/IDWT (+ the fused WTConv level: DWT + 5x5 stencil)", ("haar_dwt", "haar_idwt", "wt_level")),
+    ("K2/K7 row norms (+ the fused residual mix + norm)", ("rownorm_fwd", "rownorm_bwd", "mixnorm_fwd", "mixnorm_bwd")),
     ("K8 instance norm", ("instnorm_stats", "instnorm_apply", "instnorm_bwd_stats", "instnorm_bwd_apply", "instnorm_bwd_scalar")),
     ("K6 tall-skinny MFMA GEMM", ("tsgemm_nt", "tsgemm_tn")),
     ("K6b short MFMA GEMM", ("skgemm_nt", "skgemm_nn", "skgemm_tn")),
     ("K5 dense 3x3 conv (MFMA implicit GEMM)", ("conv3_fwd", "conv3_dgrad", "conv3_wgrad", "conv3_join")),
     ("K9 transposed conv gathers (its GEMMs are in K6b)", ("convt_col2im", "convt_im2col")),
     ("second-stage folds (batched + critical-path)", ("fold_batch", "skgemm_fold", "ssd_fold", "ssd_bc_fold", "ssd_head_fold", "lincomb_bwd_fold",
-                                                      "igate_bwd_fold", "tokmean_fold", "rainloss_fold", "grad_sumsq_fold", "dwconv_wgrad_fold",
+                                                      "mixnorm_bwd_fold", "igate_bwd_fold", "bridge_heads_fold", "bridge_pool_fold", "rainloss_fold", "grad_sumsq_fold", "dwconv_wgrad_fold",
                                                       "rownorm_bwd_fold", "tsgemm_tn_fold", "conv3_wgrad_fold", "catmix_bwd_fold", "colsum",
                                                       "adn_prep_bwd_fold", "skip_vec_fold", "skip_scal_fold", "skip_wgrad_fold")),
-    ("scalar/gamma mixes + gates", ("lincomb_fwd", "lincomb_bwd", "catmix_fwd", "catmix_bwd", "gate_fwd", "gate_bwd", "igate_fwd", "igate_bwd")),
+    ("scalar/gamma mixes + gates", ("lincomb_fwd", "lincomb_bwd", "catmix_fwd", "catmix_bwd", "gate_fwd", "gate_bwd", "igate_fwd", "igate_bwd", "emul_fwd", "emul_bwd")),
+    ("skip-connection gating (EncoderToDecoder core, bridge pools / heads)", ("skip_pool_fwd", "skip_branch_fwd", "skip_branch_bwd", "skip_conv_bwd", "skip_pool_bwd",
+                                                                            "bridge_pool_fwd", "bridge_pool_bwd", "bridge_heads_fwd", "bridge_heads_bwd")),
     ("K12 optimiser (sumsq + AdamW)", ("grad_sumsq", "adamw_update")),
 ]
 

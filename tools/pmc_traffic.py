@@ -27,17 +27,21 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # every scope whose launch is the shared fold_rows_kernel: one PMC row for the group ("a|b|c" keys = the kernel symbol serves all of them)
-FOLDS = "|".join(["fold_batch", "skgemm_fold", "ssd_head_fold", "lincomb_bwd_fold", "igate_bwd_fold", "tokmean_fold", "rainloss_fold", "grad_sumsq_fold",
+FOLDS = "|".join(["fold_batch", "skgemm_fold", "ssd_head_fold", "lincomb_bwd_fold", "mixnorm_bwd_fold", "igate_bwd_fold", "rainloss_fold", "grad_sumsq_fold",
                   "dwconv_wgrad_fold", "rownorm_bwd_fold", "tsgemm_tn_fold", "conv3_wgrad_fold", "catmix_bwd_fold", "colsum", "adn_prep_bwd_fold",
-                  "skip_vec_fold", "skip_scal_fold", "skip_wgrad_fold"])
+                  "skip_vec_fold", "skip_scal_fold", "skip_wgrad_fold", "bridge_heads_fold", "bridge_pool_fold", "instnorm_bwd_scalar", "swish_bwd_fold"])
 # (regex on the demangled kernel symbol, profiler scope); first match wins
 SCOPES = [
-    (r"^skgemm_kernel<true, true", "skgemm_nt"), (r"^skgemm_kernel<true, false", "skgemm_nn"), (r"^skgemm_kernel<false, false", "skgemm_tn"),
+    (r"^skgemm_kernel<true, true", "skgemm_nt"), (r"^skgemm_kernel<true, false", "skgemm_nn"), (r"^skgemm_kernel<false, false|^skgemm_tn_multi_kernel", "skgemm_tn"),
     (r"^lgemm_kernel<false", "skgemm_nt"), (r"^lgemm_kernel<true", "skgemm_nn"),   # the LDS-tiled half of adnm_skgemm (B_OC = op NN)
     (r"^colsum_partial_kernel", "colsum_partial"),
-    (r"^tsgemm_nt_kernel", "tsgemm_nt"), (r"^tsgemm_tn_kernel", "tsgemm_tn"),
+    (r"^tsgemm_nt_kernel", "tsgemm_nt"), (r"^tsgemm_tn_kernel|^tsgemm_tn_multi_kernel", "tsgemm_tn"),
     (r"^dwconv_kernel<float, 3", "dwconv_k3"), (r"^dwconv_kernel<float, 5", "dwconv_k5"),
-    (r"^dwconv_wgrad3_roll_kernel|^dwconv_wgrad_kernel<float, 3", "dwconv_wgrad_k3"), (r"^dwconv_wgrad_kernel<float, 5", "dwconv_wgrad_k5"),
+    (r"^dwconv_wgrad3_roll_kernel|^dwconv_wgrad_kernel<float, 3|^dwconv_wgrad_multi_kernel<3", "dwconv_wgrad_k3"),
+    (r"^dwconv_wgrad_kernel<float, 5|^dwconv_wgrad_multi_kernel<5", "dwconv_wgrad_k5"),
+    (r"^adn_prep_fwd_multi_kernel", "adn_prep_fwd"), (r"^adn_prep_bwd_multi_kernel", "adn_prep_bwd"),
+    (r"^wt_prep_fwd_multi_kernel", "wt_prep_fwd"), (r"^wt_prep_bwd_multi_kernel", "wt_prep_bwd"),
+    (r"^igate_res_fwd_kernel", "igate_fwd"), (r"^igate_res_bwd_kernel", "igate_bwd"), (r"^conv1d3_kernel", "conv1d3|conv1d3_bwd"),
     (r"^ssd_kv_kernel<.*true>$", "ssd_kv"), (r"^ssd_kv_kernel<.*false>$", "ssd_dkv"),
     (r"^ssd_apply_kernel<.*true>$", "ssd_apply_ln"), (r"^ssd_apply_kernel<.*false>$", "ssd_apply"),
     (r"^ssd_bwd_kernel", "ssd_bwd"), (r"^ssd_fold_kernel", "ssd_fold"), (r"^ssd_bc_fold_kernel", "ssd_bc_fold"),
@@ -45,7 +49,6 @@ SCOPES = [
     (r"^conv3_kernel", "conv3_fwd|conv3_dgrad"), (r"^conv3_wgrad_kernel", "conv3_wgrad"), (r"^conv3_join_kernel", "conv3_join"),
     (r"^adamw_kernel", "adamw_update"), (r"^sumsq_partial_kernel", "grad_sumsq"),
     (r"^haar_dwt_kernel", "haar_dwt"), (r"^haar_idwt_kernel", "haar_idwt"),
-    (r"^wt_level_fwd_kernel", "wt_level_fwd"), (r"^wt_level_bwd_kernel", "wt_level_bwd"),
     (r"^(\w+?)_kernel", None),   # default: the symbol's stem is the scope (rownorm_fwd, lincomb_bwd, gate_fwd, instnorm_apply, ...)
 ]
 
