@@ -1634,32 +1634,40 @@ def prep_group(*roots):
 
 
 class MaxPoolFn(torch.autograd.Function):
-    """nn.MaxPool2d on (B, H*W, C) tokens: stride == kernel (DownSample) or stride 1 'same' (EncoderToDecoder)."""
+    """nn.MaxPool2d on (B, H*W, C) tokens: stride == kernel (DownSample) or stride 1 'same' (EncoderToDecoder).  tap: also hand back x as
+    an autograd alias for its OTHER consumer (an encoder stage's output is pooled and kept as a skip tensor): that consumer's gradient is
+    added inside the pool's backward kernel instead of by a separate autograd add."""
 
     @staticmethod
-    def forward(ctx, x, H, W, kh, kw, stride):
+    def forward(ctx, x, H, W, kh, kw, stride, tap):
         B, L, C = x.shape
-        x = x.contiguous()
-        _need_gpu(x)
+        xc = x.contiguous()
+        _need_gpu(xc)
         Ho, Wo = (H, W) if stride == 1 else (H // stride, W // stride)
         y = torch.empty((B, Ho * Wo, C), dtype=x.dtype, device=x.device)
-        lib.call("adnm_maxpool_fwd", x.data_ptr(), y.data_ptr(), B, H, W, C, kh, kw, stride, _dt(x), _stream())
-        ctx.save_for_backward(x)
+        lib.call("adnm_maxpool_fwd", xc.data_ptr(), y.data_ptr(), B, H, W, C, kh, kw, stride, _dt(xc), _stream())
+        ctx.save_for_backward(xc)
         ctx.dims = (B, H, W, C, kh, kw, stride)
-        return y
+        ctx.set_materialize_grads(False)
+        return (y, x) if tap else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dalias=None):
         (x,) = ctx.saved_tensors
         B, H, W, C, kh, kw, stride = ctx.dims
+        if dy is None:
+            return dalias, None, None, None, None, None, None
         dy = dy.contiguous()
+        if dalias is not None:
+            dalias = dalias.reshape(x.shape).contiguous()
         dx = torch.empty_like(x)
-        lib.call("adnm_maxpool_bwd", dy.data_ptr(), x.data_ptr(), dx.data_ptr(), B, H, W, C, kh, kw, stride, _dt(x), _stream())
-        return dx, None, None, None, None, None
+        lib.call("adnm_maxpool_bwd", dy.data_ptr(), x.data_ptr(), _p(dalias), dx.data_ptr(), B, H, W, C, kh, kw, stride, _dt(x), _stream())
+        return dx, None, None, None, None, None, None
 
 
-def maxpool(x, H, W, kh, kw, stride):
-    return MaxPoolFn.apply(x, H, W, kh, kw, stride)
+def maxpool(x, H, W, kh, kw, stride, tap=False):
+    """tap=True: -> (pooled, alias of x) — hand the alias to x's other consumer (see MaxPoolFn)."""
+    return MaxPoolFn.apply(x, H, W, kh, kw, stride, tap)
 
 
 # ------------------------------------------------------------------------------------------- Linear / 1x1 GEMMs (K6, K6b)

@@ -174,8 +174,8 @@ __global__ __launch_bounds__(kBlock) void maxpool_fwd_kernel(const T* __restrict
 }
 
 template <typename T>
-__global__ __launch_bounds__(kBlock) void maxpool_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx, int B, int H,
-                                                             int W, int C, PoolGeo g) {
+__global__ __launch_bounds__(kBlock) void maxpool_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ dxa,
+                                                             T* __restrict__ dx, int B, int H, int W, int C, PoolGeo g) {
   const int C4 = C >> 2;
   const int64_t total = (int64_t)B * H * W * C4;
   const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -217,7 +217,12 @@ __global__ __launch_bounds__(kBlock) void maxpool_bwd_kernel(const T* __restrict
       for (int k = 0; k < 4; ++k)
         if (arg[k] == h * W + w) acc[k] += gv[k];
     }
-  Io<T>::st4(dx + (((int64_t)b * H + h) * W + w) * C + cg * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+  const int64_t at = (((int64_t)b * H + h) * W + w) * C + cg * 4;
+  if (dxa) {   // the gradient of x's other consumer (the encoder stage's output is also a skip tensor): summed here, not by an autograd add
+    const float4 e = Io<T>::ld4(dxa + at);
+    acc[0] += e.x, acc[1] += e.y, acc[2] += e.z, acc[3] += e.w;
+  }
+  Io<T>::st4(dx + at, make_float4(acc[0], acc[1], acc[2], acc[3]));
 }
 
 // ---------------------------------------------------------------------------------------------- InstanceNorm
@@ -555,7 +560,7 @@ extern "C" int adnm_maxpool_fwd(const void* x, void* y, int64_t B, int64_t H, in
   return ADNM_OK;
 }
 
-extern "C" int adnm_maxpool_bwd(const void* dy, const void* x, void* dx, int64_t B, int64_t H, int64_t W, int64_t C, int kh, int kw, int stride,
+extern "C" int adnm_maxpool_bwd(const void* dy, const void* x, const void* dx_add, void* dx, int64_t B, int64_t H, int64_t W, int64_t C, int kh, int kw, int stride,
                                 int dtype, adnm_stream_t stream) {
   ADNM_REQUIRE(dy && x && dx, "maxpool_bwd: null pointer");
   PoolGeo g;
@@ -564,11 +569,11 @@ extern "C" int adnm_maxpool_bwd(const void* dy, const void* x, void* dx, int64_t
   const unsigned grid = (unsigned)adnm_cdiv(total, kBlock);
   hipStream_t st = (hipStream_t)stream;
   const double es = dtype == ADNM_F32 ? 4.0 : 2.0;
-  ADNM_PROF("maxpool_bwd", st, es * C * B * (2.0 * H * W + (double)g.Ho * g.Wo));
+  ADNM_PROF("maxpool_bwd", st, es * C * B * ((dx_add ? 3.0 : 2.0) * H * W + (double)g.Ho * g.Wo));
   if (dtype == ADNM_F32)
-    maxpool_bwd_kernel<float><<<grid, kBlock, 0, st>>>((const float*)dy, (const float*)x, (float*)dx, (int)B, (int)H, (int)W, (int)C, g);
+    maxpool_bwd_kernel<float><<<grid, kBlock, 0, st>>>((const float*)dy, (const float*)x, (const float*)dx_add, (float*)dx, (int)B, (int)H, (int)W, (int)C, g);
   else
-    maxpool_bwd_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)dy, (const uint16_t*)x, (uint16_t*)dx, (int)B, (int)H, (int)W, (int)C, g);
+    maxpool_bwd_kernel<uint16_t><<<grid, kBlock, 0, st>>>((const uint16_t*)dy, (const uint16_t*)x, (const uint16_t*)dx_add, (uint16_t*)dx, (int)B, (int)H, (int)W, (int)C, g);
   ADNM_CHECK_LAUNCH("maxpool_bwd");
   return ADNM_OK;
 }

@@ -208,23 +208,29 @@ class Encoder(nn.Module):
     def forward_lo(self, x):
         x = x.flatten(2).transpose(1, 2)
         skips = []
+        # a stage's output is pooled AND kept as a skip: the skip list gets the pool's alias of it (one gradient sum inside maxpool_bwd)
         x, res = self.encoder1(x)
+        d, x = self.down_sample1.tap(x)
         skips.append(x)
-        x = self.encoder2(self.down_sample1(x))
+        x = self.encoder2(d)
+        d, x = self.down_sample2.tap(x)
         skips.append(x)
-        x = self.encoder3(self.down_sample2(x))
+        x = self.encoder3(d)
+        d, x = self.down_sample3.tap(x)
         skips.append(x)
-        x = self.attn(self.down_sample3(x))
+        x = self.attn(d)
         skips.append(x)
         return x, skips, res
 
     def forward_hi(self, x):
         skips = []
         x = self.encoder4(x)
+        d, x = self.down_sample4.tap(x)
         skips.append(x)
-        x = self.encoder5(self.down_sample4(x))
+        x = self.encoder5(d)
+        d, x = self.down_sample5.tap(x)
         skips.append(x)
-        x = self.encoder6(self.down_sample5(x))
+        x = self.encoder6(d)
         skips.append(x)
         x = self.attn2(x)
         return x, skips

@@ -431,12 +431,17 @@ class DownSample(nn.Module):
         self.dim = dim
         self.max_pool = nn.MaxPool2d(kernel_size=ratio, stride=ratio, padding=0)
 
-    def forward(self, x):
+    def forward(self, x, tap=False):
         b, l, d = x.shape
         h, w = _hw(l)
         if d % 4 or not 2 <= self.ratio <= 4:
             raise RuntimeError(f"DownSample: the HIP max-pool takes 4 | channels and ratio 2..4, got dim {d}, ratio {self.ratio}")
-        return ops.maxpool(x, h, w, self.ratio, self.ratio, self.ratio)
+        return ops.maxpool(x, h, w, self.ratio, self.ratio, self.ratio, tap=tap)
+
+    def tap(self, x):
+        """-> (pooled, alias of x): the alias goes to x's other consumer (the skip connection); its gradient is then summed with the
+        pool's inside the pool's backward kernel"""
+        return self.forward(x, tap=True)
 
 
 class UpSample(nn.Module):

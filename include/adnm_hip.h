@@ -224,11 +224,12 @@ int adnm_haar_idwt(const void* s, const void* up1, const void* up2, const void* 
 /* ---------------------------------------------------------------- max pooling, NHWC (K11)
  * nn.MaxPool2d on tokens: stride == kernel in [2,4] (DownSample, model_untils.py:472-487; floor mode) or stride 1 with
  * kernel 1x3 / 3x1 / 3x3 and -inf 'same' padding (EncoderToDecoder, model_untils.py:690-719).  x:(B,H,W,C),
- * y:(B,Ho,Wo,C) contiguous.  bwd recomputes the first arg-max of every window (ATen's tie rule): no index tensor. */
+ * y:(B,Ho,Wo,C) contiguous.  bwd recomputes the first arg-max of every window (ATen's tie rule): no index tensor; dx_add (optional, like
+ * x): the gradient of x's other consumer, added in the same pass (an encoder stage's output is pooled AND kept as a skip tensor). */
 int adnm_maxpool_fwd(const void* x, void* y, int64_t B, int64_t H, int64_t W, int64_t C, int kh, int kw, int stride,
                      int dtype, adnm_stream_t stream);
-int adnm_maxpool_bwd(const void* dy, const void* x, void* dx, int64_t B, int64_t H, int64_t W, int64_t C, int kh, int kw,
-                     int stride, int dtype, adnm_stream_t stream);
+int adnm_maxpool_bwd(const void* dy, const void* x, const void* dx_add, void* dx, int64_t B, int64_t H, int64_t W, int64_t C, int kh,
+                     int kw, int stride, int dtype, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- InstanceNorm2d, NHWC (K8)
  * y = act( scale * (x - mean_{hw}) * rsqrt(var_{hw} + eps) + shift ), per (b,c) plane, no affine,

@@ -406,6 +406,25 @@ def test_maxpool(B, H, W, C, kh, kw, stride):
     assert_close(xg.grad, xo.grad, 1e-6, "dx")
 
 
+def test_maxpool_tap():
+    """DownSample's pool with the input handed back as an alias for the skip connection: the skip's gradient is added inside the pool's
+    backward kernel; a pooled output that needs no gradient leaves the alias gradient untouched."""
+    B, H, W, C = 2, 16, 12, 32
+    x, c1, c2 = T("mpt.x", (B, H * W, C)), T("mpt.c1", (B, (H // 2) * (W // 2), C)), T("mpt.c2", (B, H * W, C))
+    xo = leaf(x.double())
+    yo = O.seq(F.max_pool2d(O.img(xo, H, W), 2, 2))
+    ((yo * c1.double()).sum() + (xo * c2.double()).sum()).backward()
+    xg = leaf(x, DEV)
+    yg, xa = ops.maxpool(xg, H, W, 2, 2, 2, tap=True)
+    ((yg * c1.to(DEV)).sum() + (xa * c2.to(DEV)).sum()).backward()
+    assert torch.equal(yg.cpu().double(), yo.detach())
+    assert_close(xg.grad, xo.grad, 1e-6, "dx = pool gradient + skip gradient")
+    xh = leaf(x, DEV)
+    _, xb = ops.maxpool(xh, H, W, 2, 2, 2, tap=True)
+    (xb * c2.to(DEV)).sum().backward()
+    assert_close(xh.grad, c2, 1e-7, "alias-only gradient")
+
+
 # ------------------------------------------------------------------------------------------- tall-skinny MFMA GEMMs (K6)
 @pytest.mark.parametrize("M,K,N,bias", [
     (4 * 16384, 32, 208, False),   # refiner in_proj
