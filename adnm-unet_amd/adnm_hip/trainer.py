@@ -217,7 +217,7 @@ class FlatTrainer:
         pairs = [(gv, p.grad) for gv, p in zip(self.g_views[lo:hi], self.used[lo:hi])
                  if p.grad is not None and p.grad.data_ptr() != gv.data_ptr() and p.data_ptr() not in born]
         self.gathered = [i for i, (gv, p) in enumerate(zip(self.g_views[lo:hi], self.used[lo:hi]), lo)
-                         if p.grad is not None and p.grad.data_ptr() != gv.data_ptr() and p.data_ptr() not in born]   # (tools/dbg_unclaimed.py)
+                         if p.grad is not None and p.grad.data_ptr() != gv.data_ptr() and p.data_ptr() not in born]   # (tools/gather_report.py)
         if pairs:
             torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
 
