@@ -363,6 +363,130 @@ __global__ __launch_bounds__(kBlock) void dwconv_wgrad3_roll_kernel(const T* __r
   }
 }
 
+// (c'') 5x5 weight / bias gradients, the same column walker (fp32 tokens).  The tap-row kernel above moves 7.5x its algorithmic bytes
+// through L1 at 5x5 (every tap-row wave re-reads the d pre tile, every x row is fetched by five of them): 0.22 ms per step at config 2.
+// Here a lane owns one channel quad and one TWR-pixel-wide strip of SEG rows, keeps a rolling window of FIVE x rows (TWR + 4 wide) in
+// registers and all 25 tap accumulators: per row it loads TWR + 4 + TWR float4 for 25 TWR fma4 — ~4 units of L1 traffic per pixel
+// instead of 15.  ~230 VGPRs: two waves per SIMD, which is what a workgroup of the grouped launch gets anyway.
+constexpr int kWalkTW = 1;
+template <int K, int TWR>
+__device__ __forceinline__ void dwconv_wgrad_walk_body(const float* __restrict__ dpre, int64_t ldd, const float* __restrict__ x, int64_t ldx,
+                                                       float* __restrict__ part, int B, int H, int W, int C, int cgb, int SEG, int nseg, int wcm,
+                                                       const int bx, const int by) {
+  constexpr int R = K / 2, NT = K * K, XW = TWR + K - 1;
+  __shared__ __attribute__((aligned(16))) float red[kBlock / 64 - 1][64][4];
+  const int C4 = C >> 2;
+  const int WT = (W + TWR - 1) / TWR;
+  const int cgl = threadIdx.x & (cgb - 1), sp = threadIdx.x / cgb, spb = kBlock / cgb;
+  const int cg = bx * cgb + cgl;
+  const int64_t S = (int64_t)B * nseg * WT, sidx = (int64_t)by * spb + sp;
+  const bool cv = cg < C4, live = cv && sidx < S;
+  const int c = cv ? cg * 4 : 0;
+  float4 aw[NT], ab = f4zero();
+#pragma unroll
+  for (int k = 0; k < NT; ++k) aw[k] = f4zero();
+  if (live) {
+    const int wt = (int)(sidx % WT), seg = (int)((sidx / WT) % nseg), b = (int)(sidx / ((int64_t)WT * nseg));
+    const int h0 = seg * SEG, h1 = h0 + SEG < H ? h0 + SEG : H, w0 = wt * TWR;
+    float4 win[K][XW];
+    auto load_x = [&](int hh, float4 (&r)[XW]) {
+      const bool ok = hh >= 0 && hh < H;
+      const float* xr = x + ((int64_t)b * H + (ok ? hh : 0)) * W * ldx + c;
+#pragma unroll
+      for (int j = 0; j < XW; ++j) {
+        const int ww = w0 + j - R;
+        r[j] = (ok && ww >= 0 && ww < W) ? *reinterpret_cast<const float4*>(xr + (int64_t)ww * ldx) : f4zero();
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < K - 1; ++i) load_x(h0 - R + i, win[i]);
+    // one row: tap row 0 (the window's oldest row) first, so that the NEXT row's loads — into that slot — can be issued under the other
+    // four tap rows' 80 fma4
+    auto step = [&](int hr, int j) {
+      float4 g[TWR];
+#pragma unroll
+      for (int p = 0; p < TWR; ++p) {
+        const int ww = w0 + p;
+        g[p] = ww < W ? *reinterpret_cast<const float4*>(dpre + (((int64_t)b * H + hr) * W + ww) * ldd + c) : f4zero();
+        ab.x += g[p].x, ab.y += g[p].y, ab.z += g[p].z, ab.w += g[p].w;
+      }
+#pragma unroll
+      for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int t = 0; t < K; ++t)
+#pragma unroll
+          for (int p = 0; p < TWR; ++p) fma4(aw[i * K + t], g[p], win[(j + i) % K][p + t]);
+    };
+    // (a branch-free copy of the full trips lets the compiler hoist every load of a trip: 384 VGPRs = one wave per SIMD, measured 1.5x slower)
+    for (int h = h0; h < h1; h += K) {   // K rows per trip so the window rotates by renaming, not by copying
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        if (h + j < h1) {
+          load_x(h + j + R, win[(j + K - 1) % K]);
+          step(h + j, j);
+        }
+      }
+    }
+  }
+  // strips that share a wave (lanes differing in bits >= log2 cgb), then the waves through LDS — one tap at a time (26 float4 per lane
+  // at once would be 80 KB of LDS), then the workgroup's partial row
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* dst = part + (int64_t)by * (NT + 1) * C;
+#pragma unroll
+  for (int k = 0; k <= NT; ++k) {
+    float4 v = k < NT ? aw[k] : ab;
+    v.x = wave_sum_from(v.x, cgb), v.y = wave_sum_from(v.y, cgb), v.z = wave_sum_from(v.z, cgb), v.w = wave_sum_from(v.w, cgb);
+    if (wave > 0) *reinterpret_cast<float4*>(&red[wave - 1][lane][0]) = v;
+    __syncthreads();
+    if (wave == 0 && lane < cgb) {
+#pragma unroll
+      for (int wv = 0; wv < kBlock / 64 - 1; ++wv) {
+        const float4 o = *reinterpret_cast<const float4*>(&red[wv][lane][0]);   // lane l of every wave holds quad l & (cgb - 1)'s wave total
+        v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+      }
+      if (cv) {
+        if (wcm && k < NT) {
+          float* q = dst + (int64_t)c * NT + k;
+          q[0] = v.x, q[NT] = v.y, q[2 * NT] = v.z, q[3 * NT] = v.w;
+        } else {
+          *reinterpret_cast<float4*>(dst + (int64_t)k * C + c) = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void dwconv_wgrad5_walk_kernel(const float* __restrict__ dpre, int64_t ldd, const float* __restrict__ x, int64_t ldx,
+                                                                    float* __restrict__ part, int B, int H, int W, int C, int cgb, int SEG, int nseg,
+                                                                    int wcm) {
+  dwconv_wgrad_walk_body<5, kWalkTW>(dpre, ldd, x, ldx, part, B, H, W, C, cgb, SEG, nseg, wcm, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// grouped form of the 5x5 walker
+struct WalkLeaf {
+  const float* dpre;
+  int64_t ldd;
+  const float* x;
+  int64_t ldx;
+  float* part;
+  int B, H, W, C, cgb, wcm, gx, npb, seg, nseg;
+};
+struct MultiWalk {
+  int count, blk_end[kMaxWg];
+  WalkLeaf p[kMaxWg];
+};
+__global__ __launch_bounds__(kBlock) void dwconv_wgrad5_walk_multi_kernel(MultiWalk by_value) {
+  (void)by_value;
+  const auto& m = *(const __attribute__((address_space(4))) MultiWalk*)__builtin_amdgcn_kernarg_segment_ptr();
+  int k = 0;
+  while (k + 1 < m.count && (int)blockIdx.x >= m.blk_end[k]) ++k;
+  const int lin = (int)blockIdx.x - (k ? m.blk_end[k - 1] : 0);
+  const int gx = m.p[k].gx;
+  dwconv_wgrad_walk_body<5, kWalkTW>(m.p[k].dpre, m.p[k].ldd, m.p[k].x, m.p[k].ldx, m.p[k].part, m.p[k].B, m.p[k].H, m.p[k].W, m.p[k].C, m.p[k].cgb,
+                                     m.p[k].seg, m.p[k].nseg, m.p[k].wcm, lin % gx, lin / gx);
+}
+
 struct WGeo {
   int cgb, gx, npb, rows;
   int seg, nseg;   // 3x3 column walker: rows per strip, strips per image column (0 = tap-row kernel)
@@ -413,6 +537,30 @@ WGeo wgeo(int64_t B, int64_t H, int64_t W, int64_t C, int K) {
   return g;
 }
 
+// geometry of the 5x5 column walker (fp32 tokens): strips of SEG rows; a strip that starts inside an image re-reads 4 halo rows, so
+// strips are at least 16 rows long, and as long as ~64 K lanes' worth of strips allow
+WGeo wgeo_walk5(int64_t B, int64_t H, int64_t W, int64_t C) {
+  WGeo g;
+  const int64_t C4 = C / 4;
+  g.cgb = 1;
+  while (g.cgb < 64 && g.cgb < C4) g.cgb <<= 1;
+  g.gx = (int)adnm_cdiv(C4, g.cgb);
+  const int64_t WT = adnm_cdiv(W, kWalkTW);
+  static const int seg_min = [] {   // measurement aid
+    const char* e = getenv("ADNM_DW_WALK_SEG");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 16;
+  }();
+  int64_t seg = (H * B * WT * C4) / 65536;
+  seg = seg < seg_min ? seg_min : (seg > 64 ? 64 : seg);
+  if (seg > H) seg = H;
+  g.seg = (int)seg;
+  g.nseg = (int)adnm_cdiv(H, seg);
+  g.npb = (int)adnm_cdiv(B * g.nseg * WT, kBlock / g.cgb);
+  g.rows = g.npb;
+  return g;
+}
+
 int check(const char* who, const void* x, int64_t B, int64_t H, int64_t W, int64_t C, int KH, int KW, int act, int dtype) {
   ADNM_REQUIRE(x, "%s: null pointer", who);
   ADNM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "%s: shape B=%lld H=%lld W=%lld C=%lld (C must be a multiple of 4)", who,
@@ -446,6 +594,21 @@ void launch_conv(const void* x, int64_t ldx, const float* wgt, const float* bias
 template <typename T>
 void launch_wgrad(const void* dpre, int64_t ldd, const void* x, int64_t ldx, float* part, float* dwgt, float* dbias, int64_t B, int64_t H,
                   int64_t W, int64_t C, int K, int wcm, hipStream_t st) {
+  if (K == 5 && sizeof(T) == 4) {   // the 5x5 column walker (fp32 tokens); a leaf of the backward pass: may wait for the grouped launch
+    const WGeo g = wgeo_walk5(B, H, W, C);
+    static_assert(sizeof(WalkLeaf) <= sizeof(AdnmLeaf::args), "WalkLeaf must fit a leaf record");
+    WalkLeaf w{(const float*)dpre, ldd, (const float*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb, wcm, g.gx, g.npb, g.seg, g.nseg};
+    AdnmLeaf leaf;
+    leaf.kind = ADNM_LEAF_DWCONV_WGRAD_K5, leaf.grid = g.gx * g.npb, leaf.prec = 0, leaf.prof = "dwconv_wgrad_k5", leaf.bytes = 4.0 * B * H * W * C * 2;
+    memcpy(leaf.args, &w, sizeof(w));
+    if (!adnm_leafq_push(leaf)) {
+      ADNM_PROF("dwconv_wgrad_k5", st, 4.0 * B * H * W * C * 2);
+      dwconv_wgrad5_walk_kernel<<<dim3(g.gx, g.npb), kBlock, 0, st>>>((const float*)dpre, ldd, (const float*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb,
+                                                                     g.seg, g.nseg, wcm);
+    }
+    adnm_launch_fold("dwconv_wgrad_fold", part, g.rows, 26 * (int)C, {dwgt, 25 * (int)C}, {dbias, (int)C}, {nullptr, 0}, {nullptr, 0}, st);
+    return;
+  }
   const WGeo g = wgeo(B, H, W, C, K);
   const dim3 grid(g.gx, g.npb);
   if (K == 3 && g.seg > 0)
@@ -490,8 +653,12 @@ extern "C" int adnm_dwconv_fwd(const void* x, int64_t ldx, const float* wgt, con
 
 extern "C" int64_t adnm_dwconv_bwd_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t C, int KH, int KW) {
   if (B <= 0 || H <= 0 || W <= 0 || C < 4) return 0;
-  const WGeo g = wgeo(B, H, W, C, KH);
-  return (int64_t)g.rows * (KH * KW + 1) * C * (int64_t)sizeof(float);
+  int64_t rows = wgeo(B, H, W, C, KH).rows;
+  if (KH == 5) {   // (the query does not know the storage type: fp32 tokens take the column walker's geometry)
+    const int64_t r5 = wgeo_walk5(B, H, W, C).rows;
+    rows = r5 > rows ? r5 : rows;
+  }
+  return rows * (KH * KW + 1) * C * (int64_t)sizeof(float);
 }
 
 extern "C" int adnm_dwconv_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* wgt, const float* bias,
@@ -551,6 +718,25 @@ extern "C" int adnm_dwconv_wgrad(const void* g, int64_t ldg, const void* x, int6
 
 // the queued depthwise tap-gradient problems of one kernel size, kMaxWg per launch
 int adnm_dwconv_wgrad_launch_multi(const AdnmLeaf* const* items, int n, int K, hipStream_t st) {
+  if (K == 5) {   // every queued 5x5 problem is a column-walker problem (launch_wgrad)
+    for (int i = 0; i < n;) {
+      MultiWalk m;
+      m.count = 0;
+      int blocks = 0;
+      double bytes = 0;
+      for (; i < n && m.count < kMaxWg; ++i) {
+        memcpy(&m.p[m.count], items[i]->args, sizeof(WalkLeaf));
+        blocks += items[i]->grid;
+        m.blk_end[m.count++] = blocks;
+        bytes += items[i]->bytes;
+      }
+      for (int k = m.count; k < kMaxWg; ++k) m.blk_end[k] = blocks;
+      ADNM_PROF("dwconv_wgrad_k5", st, bytes);
+      dwconv_wgrad5_walk_multi_kernel<<<(unsigned)blocks, kBlock, 0, st>>>(m);
+    }
+    ADNM_CHECK_LAUNCH("dwconv_wgrad (grouped)");
+    return ADNM_OK;
+  }
   for (int i = 0; i < n;) {
     MultiWg m;
     m.count = 0;
@@ -563,9 +749,8 @@ int adnm_dwconv_wgrad_launch_multi(const AdnmLeaf* const* items, int n, int K, h
       bytes += items[i]->bytes;
     }
     for (int k = m.count; k < kMaxWg; ++k) m.blk_end[k] = blocks;
-    ADNM_PROF(K == 3 ? "dwconv_wgrad_k3" : "dwconv_wgrad_k5", st, bytes);
-    if (K == 3) dwconv_wgrad_multi_kernel<3><<<(unsigned)blocks, 64 * 3 * kWgSlices, 0, st>>>(m);
-    else dwconv_wgrad_multi_kernel<5><<<(unsigned)blocks, 64 * 5 * kWgSlices, 0, st>>>(m);
+    ADNM_PROF("dwconv_wgrad_k3", st, bytes);
+    dwconv_wgrad_multi_kernel<3><<<(unsigned)blocks, 64 * 3 * kWgSlices, 0, st>>>(m);
   }
   ADNM_CHECK_LAUNCH("dwconv_wgrad (grouped)");
   return ADNM_OK;
