@@ -38,7 +38,7 @@ SCOPES = [
     (r"^tsgemm_nt_kernel", "tsgemm_nt"), (r"^tsgemm_tn_kernel|^tsgemm_tn_multi_kernel", "tsgemm_tn"),
     (r"^dwconv_kernel<float, 3", "dwconv_k3"), (r"^dwconv_kernel<float, 5", "dwconv_k5"),
     (r"^dwconv_wgrad3_roll_kernel|^dwconv_wgrad_kernel<float, 3|^dwconv_wgrad_multi_kernel<3", "dwconv_wgrad_k3"),
-    (r"^dwconv_wgrad_kernel<float, 5|^dwconv_wgrad_multi_kernel<5", "dwconv_wgrad_k5"),
+    (r"^dwconv_wgrad_kernel<float, 5|^dwconv_wgrad_multi_kernel<5|^dwconv_wgrad5_walk", "dwconv_wgrad_k5"),
     (r"^adn_prep_fwd_multi_kernel", "adn_prep_fwd"), (r"^adn_prep_bwd_multi_kernel", "adn_prep_bwd"),
     (r"^wt_prep_fwd_multi_kernel", "wt_prep_fwd"), (r"^wt_prep_bwd_multi_kernel", "wt_prep_bwd"),
     (r"^igate_res_fwd_kernel", "igate_fwd"), (r"^igate_res_bwd_kernel", "igate_bwd"), (r"^conv1d3_kernel", "conv1d3|conv1d3_bwd"),
