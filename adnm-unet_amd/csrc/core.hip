@@ -99,7 +99,7 @@ namespace {
 // few columns (per-channel scalars, bias sums: 1024 x 4, 1024 x 131 ...) would leave one or two workgroups walking hundreds of rows
 // each, so they take 16 x 64 or 4 x 256; sets with few rows take 128 .. 1024 columns.  The geometry is a function of (rows, n) only: a set is summed in the same order whether it
 // is folded at once or from the queue.
-constexpr int kFoldThreads = 1024, kMaxFolds = 16;
+constexpr int kFoldThreads = 1024, kMaxFolds = 48;   // (48 descriptors = 3.7 KB of the 4 KB kernel-argument segment)
 struct FoldSegs {
   float* ptr[4];
   int end[4];
