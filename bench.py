@@ -48,7 +48,7 @@ FAMILIES = [
     ("K3/K4 depthwise weight gradient", ("dwconv_wgrad_k3", "dwconv_wgrad_k5")),
     ("K3 Haar DWT/IDWT (+ the fused WTConv level: DWT + 5x5 stencil)", ("haar_dwt", "haar_idwt", "wt_level")),
     ("K2/K7 row norms (+ the fused residual mix + norm)", ("rownorm_fwd", "rownorm_bwd", "mixnorm_fwd", "mixnorm_bwd")),
-    ("K8 instance norm", ("instnorm_stats", "instnorm_apply", "instnorm_bwd_stats", "instnorm_bwd_apply", "instnorm_bwd_scalar")),
+    ("K8 instance norm", ("instnorm_stats", "instnorm_apply", "instnorm_bwd_stats", "instnorm_bwd_apply")),
     ("K6 tall-skinny MFMA GEMM", ("tsgemm_nt", "tsgemm_tn")),
     ("K6b short MFMA GEMM", ("skgemm_nt", "skgemm_nn", "skgemm_tn")),
     ("K5 dense 3x3 conv (MFMA implicit GEMM)", ("conv3_fwd", "conv3_dgrad", "conv3_wgrad", "conv3_join")),
@@ -56,7 +56,7 @@ FAMILIES = [
     ("second-stage folds (batched + critical-path)", ("fold_batch", "skgemm_fold", "ssd_fold", "ssd_bc_fold", "ssd_head_fold", "lincomb_bwd_fold",
                                                       "mixnorm_bwd_fold", "igate_bwd_fold", "bridge_heads_fold", "bridge_pool_fold", "rainloss_fold", "grad_sumsq_fold", "dwconv_wgrad_fold",
                                                       "rownorm_bwd_fold", "tsgemm_tn_fold", "conv3_wgrad_fold", "catmix_bwd_fold", "colsum",
-                                                      "adn_prep_bwd_fold", "skip_vec_fold", "skip_scal_fold", "skip_wgrad_fold")),
+                                                      "adn_prep_bwd_fold", "skip_vec_fold", "skip_scal_fold", "skip_wgrad_fold", "instnorm_bwd_scalar", "swish_bwd_fold")),
     ("scalar/gamma mixes + gates", ("lincomb_fwd", "lincomb_bwd", "catmix_fwd", "catmix_bwd", "gate_fwd", "gate_bwd", "igate_fwd", "igate_bwd", "emul_fwd", "emul_bwd")),
     ("skip-connection gating (EncoderToDecoder core, bridge pools / heads)", ("skip_pool_fwd", "skip_branch_fwd", "skip_branch_bwd", "skip_conv_bwd", "skip_pool_bwd",
                                                                             "bridge_pool_fwd", "bridge_pool_bwd", "bridge_heads_fwd", "bridge_heads_bwd")),
