@@ -35,6 +35,9 @@ __global__ void optim_tick_kernel(float* __restrict__ state, float beta1, float 
   state[3] = sqrtf(1.0f - powf(beta2, step));
 }
 
+// NT: streaming (non-temporal) accesses for g / m / v — read and written exactly once per step — and U float4 per lane and stream in
+// flight; p keeps normal accesses (the next forward reads it)
+template <bool NT, int U>
 __global__ __launch_bounds__(kBlock) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, int64_t n, const float* __restrict__ state, float lr,
                                                        float beta1, float beta2, float eps, float wd, float max_norm) {
@@ -46,26 +49,46 @@ __global__ __launch_bounds__(kBlock) void adamw_kernel(float* __restrict__ p, co
   const float bc1 = state[2], bc2s = state[3];
   const float decay = 1.0f - lr * wd, step_size = lr / bc1;
   const int64_t n4 = n >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
-    float4 pp = reinterpret_cast<float4*>(p)[i];
-    const float4 gg = reinterpret_cast<const float4*>(g)[i];
-    float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
-    float* P = &pp.x;
-    const float* G = &gg.x;
-    float* M = &mm.x;
-    float* V = &vv.x;
+  using f4 = __attribute__((ext_vector_type(4))) float;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n4; i0 += U * stride) {
+    f4 pp[U], gg[U], mm[U], vv[U];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float gk = G[k] * coef;
-      P[k] *= decay;                                   // p.mul_(1 - lr*wd)
-      M[k] = M[k] + (1.0f - beta1) * (gk - M[k]);      // exp_avg.lerp_(g, 1-beta1)
-      V[k] = V[k] * beta2 + (1.0f - beta2) * gk * gk;  // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
-      const float denom = sqrtf(V[k]) / bc2s + eps;
-      P[k] -= step_size * (M[k] / denom);              // p.addcdiv_(exp_avg, denom, value=-lr/bc1)
+    for (int u = 0; u < U; ++u) {   // every load of the trip first
+      const int64_t i = i0 + u * stride;
+      if (i < n4) {
+        pp[u] = reinterpret_cast<const f4*>(p)[i];
+        if (NT) {
+          gg[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(g) + i);
+          mm[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(m) + i);
+          vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(v) + i);
+        } else {
+          gg[u] = reinterpret_cast<const f4*>(g)[i], mm[u] = reinterpret_cast<const f4*>(m)[i], vv[u] = reinterpret_cast<const f4*>(v)[i];
+        }
+      }
     }
-    reinterpret_cast<float4*>(p)[i] = pp;
-    reinterpret_cast<float4*>(m)[i] = mm;
-    reinterpret_cast<float4*>(v)[i] = vv;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i >= n4) break;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gk = gg[u][k] * coef;
+        float P = pp[u][k] * decay;                               // p.mul_(1 - lr*wd)
+        const float M = mm[u][k] + (1.0f - beta1) * (gk - mm[u][k]);      // exp_avg.lerp_(g, 1-beta1)
+        const float V = vv[u][k] * beta2 + (1.0f - beta2) * gk * gk;      // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
+        const float denom = sqrtf(V) / bc2s + eps;
+        P -= step_size * (M / denom);                             // p.addcdiv_(exp_avg, denom, value=-lr/bc1)
+        pp[u][k] = P, mm[u][k] = M, vv[u][k] = V;
+      }
+      reinterpret_cast<f4*>(p)[i] = pp[u];
+      if (NT) {
+        __builtin_nontemporal_store(mm[u], reinterpret_cast<f4*>(m) + i);
+        __builtin_nontemporal_store(vv[u], reinterpret_cast<f4*>(v) + i);
+      } else {
+        reinterpret_cast<f4*>(m)[i] = mm[u], reinterpret_cast<f4*>(v)[i] = vv[u];
+      }
+    }
   }
 }
 // wire format of the gradient all-reduce (reduce_dtype = bf16): one streaming pass each way, 8 elements per lane
@@ -132,7 +155,10 @@ extern "C" int adnm_adamw_step(float* p, const float* g, float* m, float* v, int
   optim_tick_kernel<<<1, 1, 0, st>>>(state, beta1, beta2);
   int64_t blocks = adnm_cdiv(n / 4, kBlock);
   if (blocks > 4096) blocks = 4096;
-  { ADNM_PROF("adamw_update", st, 4.0 * n * 7); adamw_kernel<<<(unsigned)blocks, kBlock, 0, st>>>(p, g, m, v, n, state, lr, beta1, beta2, eps, weight_decay, max_norm); }
+  {   // measured in one session (two runs each): plain accesses 0.446 ms, non-temporal g / m / v 0.414, + two float4 per lane 0.400 / 0.47 without
+    ADNM_PROF("adamw_update", st, 4.0 * n * 7);
+    adamw_kernel<true, 1><<<(unsigned)blocks, kBlock, 0, st>>>(p, g, m, v, n, state, lr, beta1, beta2, eps, weight_decay, max_norm);
+  }
   ADNM_CHECK_LAUNCH("adamw_step");
   return ADNM_OK;
 }
