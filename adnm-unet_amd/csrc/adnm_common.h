@@ -38,6 +38,10 @@ int64_t adnm_lgemm_ws_bytes(int64_t I, int64_t J, int64_t R, int nbs);
 int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, void* ws,
                       int64_t ws_bytes, int64_t I, int64_t J, int64_t R, int nbs, int prec, float* q, hipStream_t st);
 int* adnm_take_tickets(int n, hipStream_t st);
+// Slab space of the in-launch split-K combine (skgemm.hip): `bytes` of the per-device ring of UNCACHED device memory, or NULL (ring not
+// allocatable: first use under stream capture, allocation failure, request larger than the ring) — the caller then keeps its slabs in the
+// workspace it was given and brackets the ticket with agent-scope fences.
+float* adnm_take_slabs(int64_t bytes, hipStream_t st);
 
 // Deferred LEAF launches (core.hip, include/adnm_hip.h: adnm_leafq_*).  A weight-gradient kernel is a leaf of the backward pass: nothing reads
 // its result before the optimiser.  While the calling thread has bound a leaf queue (AND a fold queue: the fold of a leaf's partials must

@@ -49,6 +49,7 @@ struct LgArgs {
   int64_t ldc;
   float* slab;          // nbs > 1: [tile][slice][64][64]
   int* tickets;
+  int uc;               // the slabs live in uncached memory (adnm_take_slabs): no agent-scope fences around the ticket
   int I, J, R;
   int tiles_j, nbs, kt_per_slice, nkt;
   AdnmQuant* q;         // quantisation record (fp8 scales, amax collection) or NULL
@@ -296,21 +297,26 @@ __global__ __launch_bounds__(kThreads) void lgemm_kernel(LgArgs p) {
   }
   if (!split) return;
 
-  // In-launch combine of the nbs slabs of this tile.  Publish: every wave drains its plain slab stores, the workgroup meets, one lane
-  // releases at agent scope and draws a ticket; the workgroup that draws the last one acquires at agent scope and adds the slabs in
+  // In-launch combine of the nbs slabs of this tile.  Publish: every wave drains its slab stores, the workgroup meets, one lane
+  // (releases at agent scope unless the slabs are in uncached memory, skgemm.hip: adnm_take_slabs, and) draws a ticket; the workgroup that
+  // draws the last one (acquires at agent scope and) adds the slabs in
   // slice order 0 .. nbs-1 (its own included, re-read from memory), so the sum does not depend on which slice arrived last.  The
   // counter goes back to zero for the next launch on the stream.  Correct wherever the slices ran (any CU / XCD).
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int* const flag = reinterpret_cast<int*>(lds);
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!p.uc) {   // slabs in ordinary (L2-cached) memory: write this XCD's L2 back before the ticket, invalidate before reading the others'
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     const int drawn = __hip_atomic_fetch_add(p.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (drawn == p.nbs - 1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      p.tickets[tile] = 0;
+      if (!p.uc) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __hip_atomic_store(p.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     *flag = drawn;
   }
@@ -381,7 +387,7 @@ int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, in
   p.A = a, p.lda = lda, p.B = b, p.ldb = ldb, p.bias = bias, p.C = c, p.ldc = ldc;
   p.I = (int)I, p.J = (int)J, p.R = (int)R;
   p.tiles_j = pl.tiles_j, p.nbs = pl.nbs, p.kt_per_slice = pl.kt_per_slice, p.nkt = pl.nkt;
-  p.slab = nullptr, p.tickets = nullptr;
+  p.slab = nullptr, p.tickets = nullptr, p.uc = 0;
   p.q = reinterpret_cast<AdnmQuant*>(q);
   if (pl.nbs > 1) {
     if (!ws || ws_bytes < adnm_lgemm_ws_bytes(I, J, R, nbs)) {
@@ -389,6 +395,7 @@ int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, in
       return ADNM_EWORKSPACE;
     }
     p.slab = (float*)ws;
+    if (float* slabs = adnm_take_slabs(adnm_lgemm_ws_bytes(I, J, R, nbs), st)) p.slab = slabs, p.uc = 1;
     p.tickets = adnm_take_tickets(pl.ntiles, st);
     ADNM_REQUIRE(p.tickets, "skgemm: no arrival counters (first split launch of a device under stream capture, or hipMalloc failed)");
   }

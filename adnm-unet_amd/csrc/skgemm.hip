@@ -49,6 +49,7 @@ struct SkArgs {
   int I, J, R;
   int tiles_j, ntiles, nbs, wpt, chunks_per_wave, nchunks;   // nbs workgroup-slices x wpt waves per tile; a chunk = 16 KC steps
   int* tickets;         // NT / NN with nbs > 1: one arrival counter per output tile (zero when idle); the result goes to `out`
+  int uc;               // the slabs live in uncached memory (adnm_take_slabs): no agent-scope fences around the ticket
   float* out;
   int64_t ldo;
   AdnmQuant* q;         // quantisation record (fp8 scales, amax collection) or NULL
@@ -315,13 +316,17 @@ __device__ __forceinline__ void skgemm_body(const Args& p, const int bid, const 
   if (wave == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!p.uc) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       const int drawn = __hip_atomic_fetch_add(p.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (drawn == p.nbs - 1) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        p.tickets[tile] = 0;
+        if (!p.uc) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __hip_atomic_store(p.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       *flag = drawn;
     }
@@ -559,6 +564,51 @@ int* adnm_take_tickets(int n, hipStream_t st) {
   return t;
 }
 
+// Slabs of the in-launch combine in UNCACHED device memory.  The per-XCD L2s are not coherent with one another for ordinary (cached) device
+// memory, so publishing a slab written with plain stores needs an agent-scope release = a write-back of the whole L2 of the publishing
+// XCD (buffer_wbl2), and reading it an acquire = an invalidate (buffer_inv) — per WORKGROUP of a split launch: measured, the launch time grew in
+// proportion to the slice count (profiles/r03_splitk_slices.txt).  Memory allocated uncached (MTYPE UC: hipDeviceMallocUncached) is not
+// held in L2 at all: a slab store is at the device-wide coherence point when it has completed (s_waitcnt vmcnt(0)), a load reads it from there,
+// and the ticket needs no fence.  One ring per device (128 MB, taken in launch order like the counters; launches on one stream are ordered,
+// so a region is idle again long before the ring comes round; a captured launch keeps its region for every replay).
+namespace {
+constexpr int64_t kSlabRingBytes = 128ll << 20;
+struct SlabRing {
+  char* base = nullptr;
+  int64_t next = 0;
+  bool failed = false;
+};
+SlabRing slab_rings[kMaxDevices];
+bool slabs_uncached() {   // ADNM_SK_UC_SLABS=0: measurement aid / the fenced protocol of round 2 (tests/test_kernels_gpu.py runs both)
+  const char* e = getenv("ADNM_SK_UC_SLABS");
+  return !(e && e[0] == '0');
+}
+}  // namespace
+
+float* adnm_take_slabs(int64_t bytes, hipStream_t st) {
+  int dev = 0;
+  if (!slabs_uncached() || bytes <= 0 || bytes > kSlabRingBytes || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  std::lock_guard<std::mutex> lock(ticket_mutex);
+  SlabRing& r = slab_rings[dev];
+  if (r.failed) return nullptr;
+  if (!r.base) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    void* ptr = nullptr;
+    if (hipExtMallocWithFlags(&ptr, (size_t)kSlabRingBytes, hipDeviceMallocUncached) != hipSuccess || !ptr) {
+      (void)hipGetLastError();
+      r.failed = true;
+      return nullptr;
+    }
+    r.base = (char*)ptr;
+  }
+  const int64_t need = (bytes + 255) & ~255ll;
+  if (r.next + need > kSlabRingBytes) r.next = 0;
+  float* out = reinterpret_cast<float*>(r.base + r.next);
+  r.next += need;
+  return out;
+}
+
 namespace {
 int shape_ok(int op, int64_t M, int64_t N, int64_t K) {
   if (M < 1 || N < 4 || K < 4 || M > 65536 || N > 16384 || K > 16384) return 0;
@@ -651,9 +701,12 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   p.slice_stride = split ? rowlen : 0;
   p.bsum = dbias ? (split ? part + I * J : dbias) : nullptr;
   p.bsum_stride = split ? rowlen : 0;
-  p.tickets = nullptr, p.out = c, p.ldo = ldc;
+  p.tickets = nullptr, p.out = c, p.ldo = ldc, p.uc = 0;
   p.q = reinterpret_cast<AdnmQuant*>(q);
   if (pl.combine) {
+    if (float* slabs = adnm_take_slabs(ws_need(pl, I, J, R), st)) {   // (the bias-gradient rows of a partial row exist for op TN only)
+      p.C = slabs, p.uc = 1;
+    }
     p.tickets = adnm_take_tickets(pl.ntiles, st);
     ADNM_REQUIRE(p.tickets, "skgemm: no arrival counters (first split launch of a device under stream capture, or hipMalloc failed)");
   }

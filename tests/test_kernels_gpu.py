@@ -651,6 +651,24 @@ def test_skgemm_linear(M, K, N, bias):
         assert_close(bg.grad, bo.grad, GRAD_TOL, "db")
 
 
+@pytest.mark.parametrize("M,K,N", [(64, 4096, 1024), (256, 4096, 1024), (64, 1024, 4672), (1024, 2048, 512), (4, 2144, 256)])
+def test_skgemm_split_slab_protocols_agree(M, K, N, monkeypatch):
+    """The in-launch split-K combine publishes its slabs either through the library's ring of UNCACHED device memory (no fences around
+    the arrival ticket) or, as a fallback, through the caller's workspace bracketed by agent-scope release / acquire fences: same
+    slabs, same summation order — forward and input gradient must agree bit for bit, run to run and between the two protocols."""
+    x, w, cot = T(f"sp.x{M}{K}", (M, K)).to(DEV), T(f"sp.w{N}{K}", (N, K), 0.05).to(DEV), T(f"sp.c{M}{N}", (M, N)).to(DEV)
+    outs = []
+    for mode in ("1", "0", "1"):
+        monkeypatch.setenv("ADNM_SK_UC_SLABS", mode)
+        ys = [ops.k_linear(x, w, None) for _ in range(3)]
+        dxs = [ops.k_linear_dx(cot, w) for _ in range(3)]
+        assert all(torch.equal(ys[0], y) for y in ys) and all(torch.equal(dxs[0], d) for d in dxs)
+        outs.append((ys[0], dxs[0]))
+    for y, dx in outs[1:]:
+        assert torch.equal(outs[0][0], y) and torch.equal(outs[0][1], dx)
+    assert_close(outs[0][0], x.double() @ w.double().t(), OUT_TOL, "y")
+
+
 def test_skgemm_strided_operands():
     """column slices of wider buffers as input and output (how the mixer calls it): no partials for the strided output."""
     M, K, N = 256, 512, 128
