@@ -36,11 +36,11 @@ def _merge(mod, x, residual, features):
     return x
 
 
-def _mix_normed(norm, xs, scalars, scale, shift):
-    """-> (scale*norm(x)+shift, x) for x = s0*xs[0] + s1*xs[1]: the residual mix and the pre-norm that follows it as one HIP launch"""
+def _mix_normed(norm, xs, scalars, scale, shift, gamma=None):
+    """-> (scale*norm(x)+shift, x) for x = gamma*(s0*xs[0] + s1*xs[1]): the residual mix and the pre-norm that follows it as one HIP launch"""
     if isinstance(norm, (RMSNorm, BiasFree_LayerNorm)):
-        return norm.mix_tap(xs, scalars, scale, shift)
-    return _normed(norm, ops.lincomb(xs, scalars), scale, shift)
+        return norm.mix_tap(xs, scalars, scale, shift, gamma)
+    return _normed(norm, ops.lincomb(xs, scalars, gamma), scale, shift)
 
 
 def _normed(norm, x, scale, shift):
@@ -80,12 +80,21 @@ class Block(nn.Module):
             self.out_proj = nn.Linear(dim, out_dim)
         self.gamma = nn.Parameter(1 * torch.ones(dim))
 
-    def forward(self, hidden_states, residual=None, features=None, inference_params=None, use_checkpoint=False):
-        x = _merge(self, hidden_states, residual, features)
+    def forward(self, hidden_states, residual=None, features=None, inference_params=None, use_checkpoint=False, then=None):
+        """then: the Block that consumes this one's output directly (a chain like Refiner's refiner1 -> .. -> refiner4): this block's closing
+        mix (:158, :161) and THAT block's opening norm (:149) then run as one launch, and the pair (normed, x) is handed over — the next
+        block takes it as `hidden_states`."""
+        if isinstance(hidden_states, tuple):   # (normed by MY norm1[0], x): handed over by the block before (see `then`)
+            assert residual is None and features is None
+            xn, x = hidden_states
+        else:
+            x = _merge(self, hidden_states, residual, features)
+            xn = None
         b, l, d = x.shape
         h, w = _hw(l)
         n = self.num_layers
-        xn, x = _normed(self.norm1_layers[0], x, self.scale1[0], self.shift1[0])
+        if xn is None:
+            xn, x = _normed(self.norm1_layers[0], x, self.scale1[0], self.shift1[0])
         for i in range(n):
             # beta3/beta4 alias beta1/beta2 in the reference (:145-146)
             beta1, beta2 = (self.beta1, self.beta2) if n == 1 else (self.beta1[i:i + 1], self.beta2[i:i + 1])
@@ -95,6 +104,8 @@ class Block(nn.Module):
             f = self.ffns[i].forward_tokens(xn, h, w)
             if i + 1 < n:
                 xn, x = _mix_normed(self.norm1_layers[i + 1], [x, f], [beta1, beta2], self.scale1[i + 1], self.shift1[i + 1])
+            elif then is not None and self.dim == self.out_dim:   # ... and the next block's opening norm rides along too
+                return _mix_normed(then.norm1_layers[0], [x, f], [beta1, beta2], then.scale1[0], then.shift1[0], self.gamma)
             else:   # the block's closing per-channel gamma (:161) rides on the last residual mix: one launch instead of two
                 x = ops.lincomb([x, f], [beta1, beta2], self.gamma)
         if self.dim != self.out_dim:
@@ -320,8 +331,11 @@ class Refiner(nn.Module):
                                 wt_levels=wt_levels[0], out_expand=out_expand, InstanceNorm=InstanceNorm)
 
     def forward(self, x, res):
-        x = self.refiner4(self.refiner3(self.refiner2(self.refiner1(x))))
-        return self.out_proj(x, res)
+        # the four blocks are a chain: each block's closing mix shares a launch with the next block's opening norm (Block.forward: `then`)
+        x = self.refiner1(x, then=self.refiner2)
+        x = self.refiner2(x, then=self.refiner3)
+        x = self.refiner3(x, then=self.refiner4)
+        return self.out_proj(self.refiner4(x), res)
 
 
 class VisionMamba(nn.Module):

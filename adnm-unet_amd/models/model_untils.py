@@ -82,9 +82,9 @@ class BiasFree_LayerNorm(nn.Module):
     def tap(self, x, scale=None, shift=None):
         return ops.rownorm_tap(x, self.weight, None, scale, shift, 1e-5, True)
 
-    def mix_tap(self, xs, scalars, scale=None, shift=None):
-        """(scale * norm(x) + shift, x) for x = s0*xs[0] + s1*xs[1]: the residual mix that precedes this norm rides in its kernel"""
-        return ops.mixnorm(xs, scalars, None, self.weight, None, scale, shift, 1e-5, True)
+    def mix_tap(self, xs, scalars, scale=None, shift=None, gamma=None):
+        """(scale * norm(x) + shift, x) for x = gamma * (s0*xs[0] + s1*xs[1]): the residual mix that precedes this norm rides in its kernel"""
+        return ops.mixnorm(xs, scalars, gamma, self.weight, None, scale, shift, 1e-5, True)
 
 
 class RMSNorm(nn.Module):
@@ -103,8 +103,8 @@ class RMSNorm(nn.Module):
     def tap(self, x, scale=None, shift=None):
         return ops.rownorm_tap(x, self.weight, None, scale, shift, self.eps, False)
 
-    def mix_tap(self, xs, scalars, scale=None, shift=None):
-        return ops.mixnorm(xs, scalars, None, self.weight, None, scale, shift, self.eps, False)
+    def mix_tap(self, xs, scalars, scale=None, shift=None, gamma=None):
+        return ops.mixnorm(xs, scalars, gamma, self.weight, None, scale, shift, self.eps, False)
 
 
 class Mlp(nn.Module):
