@@ -156,24 +156,32 @@ __global__ __launch_bounds__(kBlock) void skip_pool_bwd_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------ gated branches, forward
-template <int T>
-__device__ __forceinline__ void load_group_weights(const float* __restrict__ src, float (&wg)[16 * T]) {
-#pragma unroll
-  for (int e = 0; e < 16 * T; e += 4) {
-    const float4 v = ld4(src + e);
-    wg[e] = v.x, wg[e + 1] = v.y, wg[e + 2] = v.z, wg[e + 3] = v.w;
+// The grouped-conv weights of 16 adjacent groups, staged ONCE per workgroup in LDS.  A workgroup = 16 groups x 16 pixels: the 16 groups'
+// 16 T weights of branch K are one contiguous run of memory (coalesced 16-byte loads), every pixel lane of a group then reads the same LDS
+// word (a broadcast) and the 16 group lanes hit 16 different banks (group pitch 241 words).  Before, every (pixel, group) lane fetched its
+// group's 960 bytes itself — as 240 dword loads (31 us per launch), then as 60 16-byte loads (17 us), each touching 64 cache lines.
+constexpr int kGW = 16, kGP = kBlock / kGW;          // groups / pixels per workgroup
+constexpr int kWPitch = 4 * 4 * (3 + 3 + 9) + 1;      // 240 weights per group + 1
+constexpr int kWOff[3] = {0, 48, 96};                // branch K's weights inside a group's LDS row
+template <int K>
+__device__ __forceinline__ void stage_weights(const float* __restrict__ wk, int cg0, int C4, float* __restrict__ wl) {
+  constexpr int T = Taps<K>::T, PER = 16 * T;
+  const int ng = C4 - cg0 < kGW ? C4 - cg0 : kGW;
+  const float* src = wk + (int64_t)cg0 * PER;
+  for (int e4 = threadIdx.x; e4 < ng * PER / 4; e4 += kBlock) {
+    const float4 v = ld4(src + 4 * e4);
+    const int gl = (4 * e4) / PER, e = (4 * e4) % PER;
+    float* d = wl + gl * kWPitch + kWOff[K] + e;
+    d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
   }
 }
 
 template <int K>
-__device__ __forceinline__ void conv4(const float* __restrict__ p, const float* __restrict__ wk, const float* __restrict__ bk, const Geo& g, int b,
+__device__ __forceinline__ void conv4(const float* __restrict__ p, const float* __restrict__ wl, const float* __restrict__ bk, const Geo& g, int b,
                                       int h, int w, int cg, float c[4]) {
   constexpr int T = Taps<K>::T;
   f4(ld4(bk + cg * 4), c);
-  // the group's 16 T weights: 16-byte loads (lanes are whole groups apart, so every load instruction touches 64 cache lines — as 240
-  // dword loads per lane this was what the kernel's 31 us consisted of)
-  float wg[16 * T];
-  load_group_weights<T>(wk + (int64_t)cg * 16 * T, wg);
+  const float* wg = wl + kWOff[K];   // this lane's group row of the staged weights
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const int hh = h + Taps<K>::di(t), ww = w + Taps<K>::dj(t);
@@ -191,14 +199,23 @@ __global__ __launch_bounds__(kBlock) void skip_branch_fwd_kernel(const float* __
                                                                  const float* __restrict__ p1, const float* __restrict__ p2, Params P,
                                                                  float* __restrict__ c0, float* __restrict__ c1, float* __restrict__ c2,
                                                                  float* __restrict__ out, Geo g) {
-  const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (idx >= g.npix * g.C4) return;
-  int b, h, w, cg;
-  decode(idx, g, b, h, w, cg);
+  __shared__ float wlds[kGW * kWPitch];
+  const int nchunk = (g.C4 + kGW - 1) / kGW;
+  const int cg0 = ((int)blockIdx.x % nchunk) * kGW, cg = cg0 + (threadIdx.x & (kGW - 1));
+  const int64_t pix = (int64_t)((int)blockIdx.x / nchunk) * kGP + (threadIdx.x / kGW);
+  stage_weights<0>(P.w[0], cg0, g.C4, wlds);
+  stage_weights<1>(P.w[1], cg0, g.C4, wlds);
+  stage_weights<2>(P.w[2], cg0, g.C4, wlds);
+  __syncthreads();
+  if (cg >= g.C4 || pix >= g.npix) return;
+  const int64_t idx = pix * g.C4 + cg;
+  int b, h, w, cgd;
+  decode(idx, g, b, h, w, cgd);
+  const float* wl = wlds + (threadIdx.x & (kGW - 1)) * kWPitch;
   float c[3][4], xv[4], gam[4], o[4] = {0.f, 0.f, 0.f, 0.f};
-  conv4<0>(p0, P.w[0], P.b[0], g, b, h, w, cg, c[0]);
-  conv4<1>(p1, P.w[1], P.b[1], g, b, h, w, cg, c[1]);
-  conv4<2>(p2, P.w[2], P.b[2], g, b, h, w, cg, c[2]);
+  conv4<0>(p0, wl, P.b[0], g, b, h, w, cg, c[0]);
+  conv4<1>(p1, wl, P.b[1], g, b, h, w, cg, c[1]);
+  conv4<2>(p2, wl, P.b[2], g, b, h, w, cg, c[2]);
   f4(ld4(x + idx * 4), xv);
   f4(ld4(P.gamma + cg * 4), gam);
 #pragma unroll
@@ -304,12 +321,11 @@ __global__ __launch_bounds__(kBlock) void skip_branch_bwd_kernel(const float* __
 // One launch, two roles.  Blocks [0, ndg): data gradient g_k = conv_k^T(d c_k), thread = (pixel, group).
 // Blocks [ndg, ...): weight gradient, thread = one weight element (PyTorch's flat index) x pixel slice.
 template <int K>
-__device__ __forceinline__ void dgrad4(const float* __restrict__ dc, const float* __restrict__ wk, const Geo& g, int b, int h, int w, int cg,
+__device__ __forceinline__ void dgrad4(const float* __restrict__ dc, const float* __restrict__ wl, const Geo& g, int b, int h, int w, int cg,
                                        float o[4]) {
   constexpr int T = Taps<K>::T;
   o[0] = o[1] = o[2] = o[3] = 0.f;
-  float wg[16 * T];
-  load_group_weights<T>(wk + (int64_t)cg * 16 * T, wg);
+  const float* wg = wl + kWOff[K];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const int hh = h - Taps<K>::di(t), ww = w - Taps<K>::dj(t);   // the output pixel that read us through tap t
@@ -368,17 +384,26 @@ __global__ __launch_bounds__(kBlock) void skip_conv_bwd_kernel(const float* __re
                                                                const float* __restrict__ p1, const float* __restrict__ p2, Params P,
                                                                float* __restrict__ g0, float* __restrict__ g1, float* __restrict__ g2,
                                                                float* __restrict__ dw, int ndg, int SW, Geo g) {
-  if ((int)blockIdx.x < ndg) {
-    const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= g.npix * g.C4) return;
-    int b, h, w, cg;
-    decode(idx, g, b, h, w, cg);
+  __shared__ float wlds[kGW * kWPitch];
+  if ((int)blockIdx.x < ndg) {   // workgroup = 16 groups x 16 pixels, the groups' weights staged in LDS (see stage_weights)
+    const int nchunk = (g.C4 + kGW - 1) / kGW;
+    const int cg0 = ((int)blockIdx.x % nchunk) * kGW, cg = cg0 + (threadIdx.x & (kGW - 1));
+    const int64_t pix = (int64_t)((int)blockIdx.x / nchunk) * kGP + (threadIdx.x / kGW);
+    stage_weights<0>(P.w[0], cg0, g.C4, wlds);
+    stage_weights<1>(P.w[1], cg0, g.C4, wlds);
+    stage_weights<2>(P.w[2], cg0, g.C4, wlds);
+    __syncthreads();
+    if (cg >= g.C4 || pix >= g.npix) return;
+    const int64_t idx = pix * g.C4 + cg;
+    int b, h, w, cgd;
+    decode(idx, g, b, h, w, cgd);
+    const float* wl = wlds + (threadIdx.x & (kGW - 1)) * kWPitch;
     float o[4];
-    dgrad4<0>(dc0, P.w[0], g, b, h, w, cg, o);
+    dgrad4<0>(dc0, wl, g, b, h, w, cg, o);
     st4(g0 + idx * 4, o);
-    dgrad4<1>(dc1, P.w[1], g, b, h, w, cg, o);
+    dgrad4<1>(dc1, wl, g, b, h, w, cg, o);
     st4(g1 + idx * 4, o);
-    dgrad4<2>(dc2, P.w[2], g, b, h, w, cg, o);
+    dgrad4<2>(dc2, wl, g, b, h, w, cg, o);
     st4(g2 + idx * 4, o);
     return;
   }
@@ -463,7 +488,8 @@ extern "C" int adnm_skipgate_fwd(const float* x, const float* const* params, flo
   }
   {
     ADNM_PROF("skip_branch_fwd", st, 4.0 * (8 * n + kWeightsPerChannel * C));
-    skip_branch_fwd_kernel<<<grid, kBlock, 0, st>>>(x, pooled, pooled + n, pooled + 2 * n, P, conv, conv + n, conv + 2 * n, out, g);
+    const unsigned gridb = (unsigned)(adnm_cdiv(g.C4, kGW) * adnm_cdiv(g.npix, kGP));
+    skip_branch_fwd_kernel<<<gridb, kBlock, 0, st>>>(x, pooled, pooled + n, pooled + 2 * n, P, conv, conv + n, conv + 2 * n, out, g);
   }
   ADNM_CHECK_LAUNCH("skipgate_fwd");
   return ADNM_OK;
@@ -497,7 +523,7 @@ extern "C" int adnm_skipgate_bwd(const float* dout, const float* x, const float*
   }
   adnm_launch_fold("skip_vec_fold", vpart, S, kVec * g.C, {dvec, kVec * g.C}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
   adnm_launch_fold("skip_scal_fold", spart, (int)scal_rows(g, S), kScal, {dscal, kScal}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, st);
-  const int ndg = (int)adnm_cdiv(g.npix * g.C4, kBlock);
+  const int ndg = (int)(adnm_cdiv(g.C4, kGW) * adnm_cdiv(g.npix, kGP));
   {
     ADNM_PROF("skip_conv_bwd", st, 4.0 * (9 * n + 2.0 * nwt));
     skip_conv_bwd_kernel<<<(unsigned)(ndg + 3 * ((g.C4 + 15) / 16) * SW), kBlock, 0, st>>>(
