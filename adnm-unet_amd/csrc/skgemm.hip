@@ -611,7 +611,7 @@ float* adnm_take_slabs(int64_t bytes, hipStream_t st) {
 
 namespace {
 int shape_ok(int op, int64_t M, int64_t N, int64_t K) {
-  if (M < 1 || N < 4 || K < 4 || M > 65536 || N > 16384 || K > 16384) return 0;
+  if (M < 1 || N < 4 || K < 4 || M > (1 << 20) || N > 16384 || K > 16384 || M * N >= (1ll << 31) || M * K >= (1ll << 31)) return 0;   // (int element offsets)
   if (op == ADNM_SKGEMM_NT) return K % 4 == 0;
   if (op == ADNM_SKGEMM_NN) return N % 4 == 0 && K % 4 == 0;
   if (op == ADNM_SKGEMM_TN) return N % 4 == 0 && K % 4 == 0;

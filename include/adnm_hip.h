@@ -353,7 +353,7 @@ int64_t adnm_colsum_ws_bytes(int64_t rows, int64_t n);
 int adnm_colsum(const float* x, float* out, int64_t rows, int64_t n, void* ws, int64_t ws_bytes, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- short GEMMs of the deep stages (K6b, MFMA)
- * nn.Linear with M <= 65536 token rows and up to 16384 features: Mamba2.in_proj/out_proj (ADNssd.py:309,461),
+ * nn.Linear with M <= 2^20 token rows (M x features < 2^31) and up to 16384 features: Mamba2.in_proj/out_proj (ADNssd.py:309,461),
  * FeedForward.project_in/out (model_untils.py:193,196), Mlp (:64,67), ConvFFD (:217,221), Block.out_proj (ADNMUNet.py:163),
  * StandardAttention.to_qkv/to_out (ADNssd.py:33-34), Channel_Att_Bridge.att* (model_untils.py:744-750).  fp32, row-major:
  *   ADNM_SKGEMM_NT: c[M,N] = a[M,K] . b[N,K]^T (+ bias[N])           forward          K % 4 == 0
