@@ -81,6 +81,8 @@ def parse():
                          "backward, -1 (default) = on whenever N>1")
     ap.add_argument("--stages", type=int, default=0, help="stage cuts of the overlapped backward: 0 = every stage the model offers (5), 2 = encoder | rest")
     ap.add_argument("--reduce-dtype", default="f32", choices=["f32", "bf16"], help="wire dtype of the gradient all-reduce (N>1)")
+    ap.add_argument("--dump-json", default=os.path.join(ROOT, "bench_tables.json"),
+                    help="side file for the full record (the stdout line + the complete per-family / per-kernel tables)")
     ap.add_argument("--dump-prof", default="", help="write the per-(kernel, shape) HIP-event table of the instrumented steps to this file")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): replay fwd+bwd as captured hipGraphs; 0: eager launches")
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16", "fp8"],
@@ -268,6 +270,81 @@ def cpu_baseline(args, steps):
                       f"torch.set_num_threads({cores}); median {t:.2f} s/step"}
 
 
+def summarise(prof, ps, pmc, pmc_src, step_s, prof_step_ms):
+    """Per-kernel / per-family tables and the `roofline` object from the profiler rows of `ps` instrumented steps.
+    Pure host arithmetic (tests/test_host_logic.py drives it with a canned profile)."""
+    agg = by_kernel(prof)
+    total_ms = sum(r["ms"] for r in prof.values()) or 1.0
+
+    def line(names):
+        """aggregate over profiler scopes: per-step launches / ms / algorithmic bytes, achieved GB/s, fraction of the HBM peak,
+        PMC traffic per step and its ratio to the algorithmic bytes (None without a matching PMC pass)"""
+        rs = [agg[n] for n in names if n in agg]
+        if not rs:
+            return None
+        ms, by, ln = sum(r["ms"] for r in rs) / ps, sum(r["bytes"] for r in rs) / ps, sum(r["launches"] for r in rs) / ps
+        ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        tr = None
+        if pmc:
+            # a PMC row is keyed by profiler scope, or by "a|b|c" when one kernel symbol serves several scopes (conv3 fwd/dgrad, the
+            # shared fold kernel): such a row counts only when ALL of its scopes are asked for together
+            left, tr = {n for n in names if n in agg}, 0.0
+            for key, row in pmc["kernels"].items():
+                members = set(key.split("|"))
+                if members & left:
+                    if not members <= set(names):
+                        tr = None
+                        break
+                    tr += row["hbm_bytes_per_step"]
+                    left -= members
+            if left:
+                tr = None
+        return {"launches_per_step": round(ln, 1), "ms_per_step": round(ms, 4), "algorithmic_MB_per_step": round(by / 1e6, 2),
+                "GBps": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "traffic_MB_per_step": None if tr is None else round(tr / 1e6, 2),
+                "traffic_over_algorithmic": None if tr is None or by <= 0 else round(tr / by, 3)}
+
+    kernels = {n: line((n,)) for n, _ in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    families = {fam: line(names) for fam, names in FAMILIES if line(names)}
+    roofline = None
+    if agg:
+        # the dominant kernel = the library kernel with the largest AGGREGATE time per step (all its shapes together)
+        name = max(agg.items(), key=lambda kv: kv[1]["ms"])[0]
+        r, k = agg[name], kernels[name]
+        per_launch_bytes = r["bytes"] / r["launches"]
+        avg_us = 1e3 * r["ms"] / r["launches"]
+        roofline = {"kernel": name, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["frac"],
+                    "traffic": None if k["traffic_MB_per_step"] is None else round(1e6 * k["traffic_MB_per_step"] / k["launches_per_step"]),
+                    "traffic_source": pmc_src, "launches_per_step": k["launches_per_step"], "avg_launch_us": round(avg_us, 2),
+                    "algorithmic_bytes_per_launch": round(per_launch_bytes),
+                    "definition": "achieved = algorithmic bytes of this kernel's launches in a step / their HIP-event durations",
+                    "hip_kernels_ms_per_step": round(total_ms / ps, 3), "instrumented_step_ms": round(prof_step_ms, 3),
+                    "whole_step_frac": round(sum(r_["bytes"] for r_ in agg.values()) / ps / step_s / 1e9 / HBM_PEAK_GBS, 4)}
+    return kernels, families, roofline
+
+
+MAX_LINE = 4000   # the driver parses ONE stdout line; round 3's 20 kB line came back unparsed
+
+
+def stdout_line(res, families, tables_path):
+    """The one JSON line for stdout: the contract's keys, `roofline`, `cpu_baseline` and the 8 families with the most time, held under
+    MAX_LINE bytes (families are dropped from the tail if a long path or message would push it over).  The full per-kernel and
+    per-family tables go to `tables_path` and stderr."""
+    top = sorted(families.items(), key=lambda kv: -kv[1]["ms_per_step"])[:8]
+    short = [{"family": f.split(" (")[0], "launches": r["launches_per_step"], "ms": r["ms_per_step"], "frac": r["frac"],
+              "traffic_x": r["traffic_over_algorithmic"]} for f, r in top]
+    out = dict(res)
+    out["tables"] = tables_path
+    while True:
+        out["families_top"] = short
+        s = json.dumps(out, separators=(",", ":"))
+        if len(s) < MAX_LINE or not short:
+            break
+        short = short[:-1]
+    if len(s) >= MAX_LINE:
+        raise RuntimeError(f"bench.py: the result line is {len(s)} bytes, over the {MAX_LINE}-byte limit")
+    return s
+
+
 # ------------------------------------------------------------------------------------------------ one rank
 def main():
     args = parse()
@@ -377,73 +454,24 @@ def main():
 
     if rank == 0:
         ps = max(args.prof_steps, 1)
-        total_ms = sum(r["ms"] for r in prof.values()) or 1.0
         if args.dump_prof:
             with open(args.dump_prof, "w") as f:
                 f.write("kernel@bytes_per_launch\tlaunches_per_step\tavg_us\tms_per_step\tGB/s\n")
                 for key, r in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
                     f.write(f"{key}\t{r['launches'] / ps:.1f}\t{1e3 * r['ms'] / r['launches']:.2f}\t{r['ms'] / ps:.4f}\t"
                             f"{r['bytes'] / max(r['ms'], 1e-9) / 1e6:.1f}\n")
-        agg = by_kernel(prof)
         pmc, pmc_src = pmc_table()
-
-        def line(names):
-            """aggregate over profiler scopes: per-step launches / ms / algorithmic bytes, achieved GB/s, fraction of the HBM peak,
-            PMC traffic per step and its ratio to the algorithmic bytes (None without a matching PMC pass)"""
-            rs = [agg[n] for n in names if n in agg]
-            if not rs:
-                return None
-            ms, by, ln = sum(r["ms"] for r in rs) / ps, sum(r["bytes"] for r in rs) / ps, sum(r["launches"] for r in rs) / ps
-            ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            tr = None
-            if pmc:
-                # a PMC row is keyed by profiler scope, or by "a|b|c" when one kernel symbol serves several scopes (conv3 fwd/dgrad, the
-                # shared fold kernel): such a row counts only when ALL of its scopes are asked for together
-                left, tr = {n for n in names if n in agg}, 0.0
-                for key, row in pmc["kernels"].items():
-                    members = set(key.split("|"))
-                    if members & left:
-                        if not members <= set(names):
-                            tr = None
-                            break
-                        tr += row["hbm_bytes_per_step"]
-                        left -= members
-                if left:
-                    tr = None
-            return {"launches_per_step": round(ln, 1), "ms_per_step": round(ms, 4), "algorithmic_MB_per_step": round(by / 1e6, 2),
-                    "GBps": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "traffic_MB_per_step": None if tr is None else round(tr / 1e6, 2),
-                    "traffic_over_algorithmic": None if tr is None or by <= 0 else round(tr / by, 3)}
-
-        kernels = {n: line((n,)) for n, _ in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
-        families = {fam: line(names) for fam, names in FAMILIES if line(names)}
-        roofline = None
-        if agg:
-            # the dominant kernel = the library kernel with the largest AGGREGATE time per step (all its shapes together)
-            name = max(agg.items(), key=lambda kv: kv[1]["ms"])[0]
-            r, k = agg[name], kernels[name]
-            per_launch_bytes = r["bytes"] / r["launches"]
-            avg_us = 1e3 * r["ms"] / r["launches"]
-            roofline = {"kernel": name, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["frac"],
-                        "traffic": None if k["traffic_MB_per_step"] is None else round(1e6 * k["traffic_MB_per_step"] / k["launches_per_step"]),
-                        "traffic_source": pmc_src, "launches_per_step": k["launches_per_step"], "avg_launch_us": round(avg_us, 2),
-                        "algorithmic_bytes_per_launch": round(per_launch_bytes),
-                        "definition": "achieved = sum of algorithmic bytes of this kernel's launches in a step / sum of their HIP-event durations "
-                                      "(per-launch averages over all its shapes); per-shape rows: --dump-prof / profiles/",
-                        "hip_kernels_ms_per_step": round(total_ms / ps, 3), "instrumented_step_ms": round(prof_step_ms, 3),
-                        "whole_step_frac": round(sum(r_["bytes"] for r_ in agg.values()) / ps / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+        kernels, families, roofline = summarise(prof, ps, pmc, pmc_src, dt / args.steps, prof_step_ms if prof else 0.0)
         res = {
             "metric": f"sequences/sec training ADNM-UNet {args.in_frames}->{args.out_frames}x{args.size}x{args.size}", "value": round(world * args.batch * args.steps / dt, 3),
             "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype,
             "dtype_detail": {"f32": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32) everywhere: the bit-level parity path",
-                             "bf16": "bf16 x bf16 -> fp32 on v_mfma_f32_16x16x32_bf16 in every GEMM-shaped kernel (K6 tall-skinny forward / input "
-                                     "gradient, K6b short GEMMs, K5/K9 dense convs); fp32 accumulation, master parameters, activation storage and "
-                                     "every other kernel",
-                             "fp8": "BASELINE config 5: per-tensor scaled OCP fp8 operands (e4m3 activations and weights, e5m2 output gradients) on "
-                                    "v_mfma_f32_16x16x32_{fp8,bf8}_fp8 in the forward and input-gradient GEMMs / dense convs, delayed scaling "
-                                    f"re-calibrated on the device every {os.environ.get('ADNM_FP8_PERIOD', '16')} steps; bf16 operands for the weight "
-                                    "gradients; fp32 accumulation, master parameters, activation storage and every other kernel"}[args.dtype],
+                             "bf16": "bf16 x bf16 -> fp32 on v_mfma_f32_16x16x32_bf16 in every GEMM-shaped kernel; fp32 accumulation, master "
+                                     "parameters and every other kernel",
+                             "fp8": "config 5: per-tensor scaled OCP e4m3 / e5m2 operands on v_mfma_f32_16x16x32_{fp8,bf8}_fp8, delayed scaling; "
+                                    "exemptions in DESIGN.md 3a"}[args.dtype],
             "data": "synthetic",
             "config": {"workload": f"ADNM-UNet create_ADNMUNet({args.in_frames},{args.out_frames},6) {args.size}x{args.size} full training step "
                                    "(fwd + enRainfallLoss + bwd + clip_grad_norm_ + AdamW), recipe parameters, synthetic radar frames in HBM",
@@ -462,9 +490,16 @@ def main():
             res["cpu_baseline"] = cpu_baseline(args, args.cpu_steps)
         else:
             res["cpu_baseline"] = None
-        res["families"] = families
-        res["kernels"] = kernels
-        print(json.dumps(res), flush=True)
+        tables = {"families": families, "kernels": kernels}
+        tables_path = args.dump_json
+        try:
+            with open(tables_path, "w") as f:
+                json.dump(dict(res, **tables), f, indent=1)
+        except OSError as e:   # a read-only checkout must not cost the measurement
+            print(f"[bench] could not write {tables_path}: {e}", file=sys.stderr)
+            tables_path = None
+        print("[bench] tables " + json.dumps(tables), file=sys.stderr, flush=True)
+        print(stdout_line(res, families, tables_path and os.path.basename(tables_path)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -124,3 +124,39 @@ def test_radar_ingest_slot_bookkeeping():
     with pytest.raises(RuntimeError):
         dataio.RadarIngest.submit(ing, None)
     assert ing._pending.pop(0) == 0 and ing._pending.pop(0) == 1
+
+
+def test_bench_stdout_line_is_small_and_parses():
+    """the driver parses ONE stdout line; it must stay under 4 kB however many kernels the profile holds.
+    Canned profile = round 3's per-(kernel, shape) table (profiles/r03_kernel_shapes_bf16.tsv)."""
+    import json
+    import bench
+    prof = {}
+    with open(os.path.join(ROOT, "profiles", "r03_kernel_shapes_bf16.tsv")) as f:
+        next(f)
+        for row in f:
+            key, n, avg_us, ms, _ = row.rstrip("\n").split("\t")
+            n = max(1, round(float(n)))
+            prof[key] = {"launches": 3 * n, "ms": 3 * float(ms), "bytes": 3 * n * float(key.split("@")[1])}
+    assert len(prof) > 100
+    pmc = {"kernels": {k.split("@")[0]: {"hbm_bytes_per_step": 1.5e8, "launches_per_step": 1} for k in prof}}
+    kernels, families, roofline = bench.summarise(prof, 3, pmc, "canned " + "x" * 200, 8.5e-3, 11.0)
+    assert roofline["kernel"] in kernels and roofline["traffic"] is not None and 0 < roofline["frac"] < 1
+    res = {"metric": "sequences/sec training ADNM-UNet 5->20x128x128", "value": 468.4, "unit": "sequences/s", "n_gpus": 1, "steps": 20, "warmup": 10,
+           "ms_per_step": 8.54, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "dtype_detail": "d" * 300,
+           "data": "synthetic", "config": {"workload": "w" * 250, "per_gpu_batch": 4, "protocol": "p" * 150},
+           "windows_ms_per_step": [8.5] * 5, "roofline": roofline,
+           "cpu_baseline": {"value": 3.7, "unit": "sequences/s", "cores": 16, "kind": "port", "sample": "s" * 200}}
+    line = bench.stdout_line(res, families, "bench_tables.json")
+    assert "\n" not in line and len(line) < 4096
+    back = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline"):
+        assert k in back
+    assert back["roofline"]["frac"] == roofline["frac"] and 1 <= len(back["families_top"]) <= 8
+    assert "kernels" not in back and "families" not in back
+    # a pathological record still comes out under the cap (families dropped from the tail) ...
+    fat = dict(res, dtype_detail="d" * 1500)
+    assert len(bench.stdout_line(fat, families, "t.json")) < 4096
+    # ... and one that cannot fit raises instead of printing a line the driver will not parse
+    with pytest.raises(RuntimeError):
+        bench.stdout_line(dict(res, dtype_detail="d" * 5000), families, "t.json")
