@@ -16,7 +16,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import lib
+from . import lib, ops
 
 
 class GraphedForward:
@@ -41,11 +41,17 @@ class GraphedForward:
                     self.model(sx)
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = self.model(sx)
+            # the graph's split GEMM launches get their own uncached workspace (kept with the graph: a training graph replayed on
+            # another stream beside this one must not share it); fp8: the quantisation table's rows stay put while the graph lives
+            scope = ops.SPLITWS.open_scope(x.device)
+            if ops.mfma_precision() == "fp8":
+                ops.QUANT.pin(x.device)
+            with ops.SPLITWS.capturing(scope):
+                with torch.cuda.graph(g):
+                    out = self.model(sx)
             self.model.train(was_training)
-            ent = self._graphs[key] = (g, sx, out)
-        g, sx, out = ent
+            ent = self._graphs[key] = (g, sx, out, scope)
+        g, sx, out, _ = ent
         sx.copy_(x, non_blocking=True)
         g.replay()
         return out

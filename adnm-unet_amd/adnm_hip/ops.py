@@ -124,11 +124,35 @@ class QuantTable:
         lib.call("adnm_quant_update", ent["tab"].data_ptr(), len(ent["keys"]), ent["state"].data_ptr(), float(self.headroom), _stream())
 
     def reset(self, device=None):
+        """Start a new calibration.  The table's memory is NEVER given back (captured hipGraphs have `tab.data_ptr() + 32 * row` baked
+        into their kernel arguments).  While a capture that may hold record pointers is alive on the device (pin() / unpin(), taken by
+        FlatTrainer and GraphedForward around the lifetime of their graphs) the key -> row map is kept as well and only the VALUES go
+        back to their defaults (scale 1, recording on), so a replayed graph keeps reading the record of ITS call site — freshly
+        calibrated by whoever asked for the reset.  With nothing pinned the keys are forgotten too (tests building model after model)."""
         with self._lock:
-            if device is None:
-                self._dev.clear()
-            else:
-                self._dev.pop(self._idx(device), None)
+            ents = list(self._dev.values()) if device is None else [e for e in (self._dev.get(self._idx(device)),) if e is not None]
+            for ent in ents:
+                if ent.get("pins", 0) > 0:
+                    n = len(ent["keys"])
+                    ent["tab"][:n, 0:2] = 1.0
+                    ent["tab"][:n, 2:4] = 0.0
+                    ent["tab"][:n, 6] = 1.0
+                else:
+                    ent["keys"].clear()
+                    ent["tab"].zero_()
+                ent["state"].copy_(torch.tensor([0.0, float(self.period)]))
+
+    def pin(self, device):
+        """a captured graph that may hold record pointers of this device's table now exists (see reset())"""
+        with self._lock:
+            ent = self._ent(device)
+            ent["pins"] = ent.get("pins", 0) + 1
+
+    def unpin(self, device):
+        with self._lock:
+            ent = self._dev.get(self._idx(device))
+            if ent is not None and ent.get("pins", 0) > 0:
+                ent["pins"] -= 1
 
     def dump(self, device):
         ent = self._dev.get(self._idx(device))
@@ -521,7 +545,100 @@ class _SideActive:
         return False
 
 
+class _UncachedRegion:
+    """`nbytes` of zero-filled uncached device memory (include/adnm_hip.h: adnm_uncached_alloc); freed with the object."""
+
+    def __init__(self, device, nbytes):
+        with torch.cuda.device(device):
+            self.ptr = lib.load().adnm_uncached_alloc(int(nbytes))
+        if not self.ptr:
+            raise RuntimeError(f"adnm_hip: {lib.last_error()}")
+        self.nbytes, self.device = int(nbytes), device
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                with torch.cuda.device(self.device):
+                    lib.load().adnm_uncached_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class SplitWorkspaces:
+    """The caller's side of the in-launch split-K combine (include/adnm_hip.h, adnm_skgemm): the [arrival counters | slabs] workspace
+    of a split NT / NN launch, in UNCACHED device memory, owned here per unit of ordering — never shared by launches that could run
+    at the same time:
+      * eager launches: one region per (device, stream); launches on a stream are ordered, so one region serves them all.  It grows
+        (a new, larger region; outgrown ones are kept until release(), an in-flight launch may still use them);
+      * stream capture: one region per capture SCOPE.  The owner of the graphs (FlatTrainer, GraphedForward) opens a scope before it
+        captures and keeps it as long as its graphs live; every split launch captured inside uses the scope's region, sized by the
+        largest request this device has seen (the eager warm-up steps).  All graphs of one scope must replay on one stream, one at a
+        time (FlatTrainer's stage graphs do).  A capture nobody opened a scope for gets an ordinary torch workspace with freshly
+        zeroed counters and the fenced protocol."""
+    MIN_BYTES = 8 << 20
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._streams = {}   # (device index, stream handle) -> [regions, newest last]
+        self._seen = {}      # device index -> largest request so far
+        self._scope = {}     # device index -> the open capture scope (a dict holding its region)
+
+    def take(self, device, nbytes):
+        """-> (ptr, nbytes, uncached flag, keep-alive object) for one split launch on torch's current stream"""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        with self._lock:
+            self._seen[idx] = max(self._seen.get(idx, 0), nbytes)
+            if torch.cuda.is_current_stream_capturing():
+                scope = self._scope.get(idx)
+                if scope is None:
+                    return None
+                reg = scope["region"]
+                if reg.nbytes < nbytes:
+                    raise RuntimeError(f"adnm_hip: a split GEMM inside a hipGraph capture needs {nbytes} workspace bytes, the capture scope "
+                                       f"holds {reg.nbytes}: run the step eagerly once before capturing (FlatTrainer.prepare does)")
+                return reg.ptr, reg.nbytes, 1, reg
+            key = (idx, _stream())
+            regs = self._streams.setdefault(key, [])
+            if not regs or regs[-1].nbytes < nbytes:
+                regs.append(_UncachedRegion(device, max(self.MIN_BYTES, 2 * nbytes if regs else nbytes)))
+            return regs[-1].ptr, regs[-1].nbytes, 1, regs[-1]
+
+    def open_scope(self, device):
+        """Before a capture (NOT inside one: it allocates).  -> the scope; keep it alive as long as the captured graphs."""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        with self._lock:
+            need = max(self.MIN_BYTES, self._seen.get(idx, 0))
+        return {"region": _UncachedRegion(device, need), "device": idx}
+
+    def capturing(self, scope):
+        """with SPLITWS.capturing(scope): <torch.cuda.graph(...)> — split launches captured inside use the scope's region"""
+        return _ScopeActive(self, scope)
+
+    def release(self):
+        """forget every eager region (tests; nothing may be in flight)"""
+        with self._lock:
+            self._streams.clear()
+
+
+class _ScopeActive:
+    def __init__(self, reg, scope):
+        self.reg, self.scope = reg, scope
+
+    def __enter__(self):
+        if self.scope is not None:
+            with self.reg._lock:
+                self.reg._scope[self.scope["device"]] = self.scope
+
+    def __exit__(self, *exc):
+        if self.scope is not None:
+            with self.reg._lock:
+                self.reg._scope.pop(self.scope["device"], None)
+        return False
+
+
 FOLDS = FoldRegistry()
+SPLITWS = SplitWorkspaces()
 GRADS = GradRegistry()
 SIDE = SideStreams()
 grad_dst = GRADS.take
@@ -1611,7 +1728,9 @@ def prep_group(*roots):
                 adn.append(m)
             elif kind == "wt":
                 wt.append(m)
-    if adn and adn[0].in_proj.weight.is_cuda:
+    for m in adn[:1] + wt[:1]:   # the product path has no CPU fallback: a model left on the CPU raises here, not somewhere inside a module
+        _need_gpu(m.in_proj.weight if m.adnm_prep_kind == "adn" else m.base_conv.weight)
+    if adn:
         dims, params = [], []
         for m in adn:
             d, p = m.adnm_prep_args()
@@ -1620,7 +1739,7 @@ def prep_group(*roots):
         out = AdnPrepMultiFn.apply(dims, *params)
         for i, m in enumerate(adn):
             m.__dict__["_adnm_prepped"] = out[5 * i:5 * i + 5]
-    if wt and wt[0].base_conv.weight.is_cuda:
+    if wt:
         dims, ts = [], []
         for m in wt:
             d, t = m.adnm_prep_args()
@@ -1721,7 +1840,22 @@ def _skgemm(op, a, b, bias, c, dbias, M, N, K, defer=False, side=False, q=None, 
         raise RuntimeError(f"adnm_hip linear: no kernel takes op={('NT', 'NN', 'TN')[op]} M={M} N={N} K={K} "
                            "(every op needs N % 4 == 0 and K % 4 == 0)")
     nb = lib.query("adnm_skgemm_ws_bytes", op, M, N, K)
-    ws = _ws(nb, a.device)
+    uc = 0
+    if op != SK_TN and nb > 16:
+        # NT / NN split over workgroups: the slabs are combined inside the launch — [arrival counters | slabs] in this stream's (or this
+        # capture scope's) uncached region (SplitWorkspaces); an un-scoped capture takes a torch workspace with zeroed counters instead
+        got = SPLITWS.take(a.device, nb)
+        if got is None:
+            ws = _ws(nb, a.device)
+            ws.zero_()
+            wsp, wsn = ws.data_ptr(), nb
+        else:
+            wsp, wsn, uc, ws = got
+            if os.environ.get("ADNM_SK_UC_SLABS", "1") == "0":   # measurement aid: the fenced protocol on the same memory
+                uc = 0
+    else:
+        ws = _ws(nb, a.device)
+        wsp, wsn = ws.data_ptr(), nb
     # only the weight-gradient op (TN) may wait for its split-K fold, and only it leaves the critical path for the side stream
     pc, ldc, pdb = c.data_ptr(), c.stride(0), _p(dbias)   # (the outputs are not captured: see SideStreams)
     if op == SK_TN:   # the weight gradient: bf16 operands in the fp8 configuration, no record
@@ -1729,7 +1863,7 @@ def _skgemm(op, a, b, bias, c, dbias, M, N, K, defer=False, side=False, q=None, 
     else:
         prec, qp = _gemm_prec(q, role)
     call = lambda: lib.call("adnm_skgemm", op, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _p(bias), pc, ldc, pdb,
-                            ws.data_ptr(), nb, M, N, K, prec, qp, _stream())
+                            wsp, wsn, uc, M, N, K, prec, qp, _stream())
     if side:   # (a, b are kept with the workspace: under a bound leaf queue the launch itself waits for the grouped flush)
         SIDE.submit(a.device, (a, b), FOLDS.defer(a.device, ws, a, b) if defer else _NODEFER, call)
     else:
@@ -2377,6 +2511,9 @@ def bridge_pool(xs):
     return list(out[:-1]), out[-1]
 
 
+_BRIDGE_ROWS = 8   # csrc/bridge.hip: kMaxB sample rows of att per launch
+
+
 class BridgeHeadsFn(torch.autograd.Function):
     """The live heads of Channel_Att_Bridge in one launch each way + one fold (csrc/bridge.hip): for every head i,
     gate_i = IntensityGate(att . W_i^T + b_i).  args: att (B, 1, S), enhance, threshold, then W_0, b_0, W_1, b_1, ...; returns the gates
@@ -2392,8 +2529,10 @@ class BridgeHeadsFn(torch.autograd.Function):
         dev = att.device
         zs = [torch.empty((B, c), dtype=torch.float32, device=dev) for c in Cs]
         ys = [torch.empty((B, 1, c), dtype=torch.float32, device=dev) for c in Cs]
-        lib.call("adnm_bridge_heads_fwd", a2.data_ptr(), lib.ptr_table(Ws), lib.ptr_table(bs), lib.i64_table(Cs), len(Ws), enhance.data_ptr(),
-                 threshold.data_ptr(), lib.ptr_table(zs), lib.ptr_table(ys), B, S, _stream())
+        for b0 in range(0, B, _BRIDGE_ROWS):   # the kernel holds <= 8 sample rows of att in LDS: a larger batch goes through in row chunks
+            nb_ = min(_BRIDGE_ROWS, B - b0)
+            lib.call("adnm_bridge_heads_fwd", a2[b0:].data_ptr(), lib.ptr_table(Ws), lib.ptr_table(bs), lib.i64_table(Cs), len(Ws), enhance.data_ptr(),
+                     threshold.data_ptr(), lib.ptr_table([z[b0:] for z in zs]), lib.ptr_table([y[b0:] for y in ys]), nb_, S, _stream())
         ctx.save_for_backward(a2, enhance, threshold, *Ws, *zs)
         ctx.meta = (B, S, Cs, [b is not None for b in bs], [b.data_ptr() if b is not None else 0 for b in bs], att.shape)
         ctx.set_materialize_grads(False)
@@ -2411,11 +2550,22 @@ class BridgeHeadsFn(torch.autograd.Function):
         dWs = [grad_dst(w.data_ptr(), w.shape, dev) for w in Ws]
         dbs = [grad_dst(p, (c,), dev) if h else None for p, c, h in zip(b_ptrs, Cs, has_b)]
         de, dt = grad_dst(enhance.data_ptr(), enhance.shape, dev), grad_dst(threshold.data_ptr(), threshold.shape, dev)
-        nb = lib.query("adnm_bridge_heads_bwd_ws_bytes", sum(Cs), B, S)
+        nb = lib.query("adnm_bridge_heads_bwd_ws_bytes", sum(Cs), min(B, _BRIDGE_ROWS), S)
         ws = _ws(nb, dev)
-        lib.call("adnm_bridge_heads_bwd", a2.data_ptr(), lib.ptr_table(Ws), lib.i64_table(Cs), n, enhance.data_ptr(), threshold.data_ptr(),
-                 lib.ptr_table(zs), lib.ptr_table(dys), datt.data_ptr(), lib.ptr_table(dWs), lib.ptr_table(dbs), de.data_ptr(), dt.data_ptr(),
-                 ws.data_ptr(), nb, B, S, _stream())
+        for b0 in range(0, B, _BRIDGE_ROWS):
+            nb_ = min(_BRIDGE_ROWS, B - b0)
+            if b0 == 0:
+                tW, tb, te, tt = dWs, dbs, de, dt
+            else:   # row chunks after the first: their parameter-gradient contributions are added to the first chunk's
+                tW = [torch.empty_like(w) for w in dWs]
+                tb = [torch.empty_like(b) if b is not None else None for b in dbs]
+                te, tt = torch.empty_like(de), torch.empty_like(dt)
+            lib.call("adnm_bridge_heads_bwd", a2[b0:].data_ptr(), lib.ptr_table(Ws), lib.i64_table(Cs), n, enhance.data_ptr(), threshold.data_ptr(),
+                     lib.ptr_table([z[b0:] for z in zs]), lib.ptr_table([d[b0:] for d in dys]), datt[b0:].data_ptr(), lib.ptr_table(tW), lib.ptr_table(tb),
+                     te.data_ptr(), tt.data_ptr(), ws.data_ptr(), nb, nb_, S, _stream())
+            if b0:
+                dst = dWs + [b for b in dbs if b is not None] + [de, dt]
+                torch._foreach_add_(dst, tW + [b for b in tb if b is not None] + [te, tt])
         out = [datt.view(ashape), de, dt]
         for dw, db in zip(dWs, dbs):
             out += [dw, db]
@@ -2426,9 +2576,9 @@ def bridge_heads(att, enhance, threshold, weights, biases):
     """att (B, 1, S) -> [IntensityGate(att . W_i^T + b_i) for i]: every live head of Channel_Att_Bridge in one launch."""
     _need_gpu(att)
     B, one, S = att.shape
-    if att.dtype != torch.float32 or one != 1 or S % 4 or S > 3072 or not 1 <= B <= 8 or not 1 <= len(weights) <= 8 or \
+    if att.dtype != torch.float32 or one != 1 or S % 4 or S > 3072 or B < 1 or not 1 <= len(weights) <= 8 or \
             any(w.dim() != 2 or w.shape[1] != S for w in weights) or enhance.numel() != 1 or threshold.numel() != 1:
-        _unsupported("bridge_heads", f"needs fp32 (B <= 8, 1, S) pooled channels with 4 | S <= 3072 and 1..8 (C_i, S) weights, got {tuple(att.shape)}, "
+        _unsupported("bridge_heads", f"needs fp32 (B, 1, S) pooled channels with 4 | S <= 3072 and 1..8 (C_i, S) weights, got {tuple(att.shape)}, "
                                      f"{[tuple(w.shape) for w in weights]}")
     wb = []
     for w, b in zip(weights, biases):

@@ -123,27 +123,37 @@ class FlatTrainer:
         if self.staged:
             K = len(self.stage_defs)
             claimed = set().union(*[ids for _, ids in self.stage_defs if ids is not None])
+            owners = {}
+            for k, (_, ids) in enumerate(self.stage_defs):
+                for i in (ids or ()):
+                    owners.setdefault(i, []).append(k)
+            twice = [n for n, p in self.model.named_parameters() if len(owners.get(id(p), ())) > 1]
+            if twice:
+                raise RuntimeError(f"FlatTrainer: parameters claimed by more than one stage of forward_stages(): {twice[:8]}")
+            catch_all = any(ids is None for _, ids in self.stage_defs)
             groups = []
             for k in range(K - 1, -1, -1):
                 ids = self.stage_defs[k][1]
                 groups.append([p for p in used if (id(p) in ids if ids is not None else id(p) not in claimed)])
             left = {id(p) for p in used} - {id(p) for g in groups for p in g}
-            groups[0] += [p for p in used if id(p) in left]   # a parameter no stage names rides in the first bucket (ready first: safe only
-            used = [p for g in groups for p in g]             # if its gradient is complete there — the model's stage lists are exhaustive)
+            if left and not catch_all:
+                # a parameter no stage names would be asked for in no part's backward(inputs=...): it would never get a gradient and
+                # only be weight-decayed — refuse instead of training a model with silently frozen parameters
+                names = [n for n, p in self.model.named_parameters() if id(p) in left]
+                raise RuntimeError(f"FlatTrainer: parameters that receive gradients but belong to no stage of forward_stages(): {names[:8]}")
+            used = [p for g in groups for p in g]
         self.late, self.early = groups[0], [p for g in groups[1:] for p in g]
         dev, dt = used[0].device, used[0].dtype
-        offs, total, bounds = [], 0, []
-        starts = set()
-        n = 0
+        # one (lo, hi) bucket PER GROUP, empty groups included (a frozen or parameter-free stage): buckets[j] belongs to backward part j
+        offs, total, buckets = [], 0, []
         for g in groups:
-            starts.add(n)
-            n += len(g)
-        for i, p in enumerate(used):
-            if i in starts:
-                total = (total + 7) // 8 * 8  # a stage boundary is also a bucket boundary of the bf16 wire buffer (16-byte aligned there too)
-                bounds.append(total)
-            offs.append(total)
-            total += (p.numel() + 3) // 4 * 4  # keep every tensor 16-byte aligned inside the flat buffers
+            total = (total + 7) // 8 * 8  # a stage boundary is also a bucket boundary of the bf16 wire buffer (16-byte aligned there too)
+            lo = total
+            for p in g:
+                offs.append(total)
+                total += (p.numel() + 3) // 4 * 4  # keep every tensor 16-byte aligned inside the flat buffers
+            buckets.append((lo, total))
+        assert len(buckets) == len(groups) and (not self.staged or len(buckets) == len(self.stage_defs))
         self.groups = groups
         self.flat_p = torch.zeros(total, dtype=dt, device=dev)
         self.flat_g = torch.zeros(total, dtype=dt, device=dev)
@@ -170,8 +180,9 @@ class FlatTrainer:
             self.g_views.append(shaped(self.flat_g, o, p))
             p.grad = None
         self.used, self.n = used, total
-        # gradient buckets in the order they become ready (= the order they are all-reduced); an empty stage leaves an empty bucket
-        self.buckets = [(bounds[j], bounds[j + 1] if j + 1 < len(bounds) else total) for j in range(len(bounds))]
+        # gradient buckets in the order they become ready (= the order they are all-reduced); an empty stage has an empty bucket
+        # (lo == hi), which _reduce_begin skips
+        self.buckets = buckets
         self.n_late = self.buckets[0][1]
         self.group_ranges, lo = [], 0
         for g in groups:
@@ -198,6 +209,13 @@ class FlatTrainer:
         self.static_loss = None
         self._carry = self._cuts = None
         self.sx = self.st = None
+        self._splitws = None   # (after the graphs: their launches point into it)
+        if getattr(self, "_quant_pinned", False):
+            self._quant_pinned = False
+            try:
+                ops.QUANT.unpin(self.flat_g.device)
+            except Exception:
+                pass
         try:
             ops.GRADS.drop(id(self))   # lock-free for a finaliser: queued, drained by the next register / take
         except Exception:
@@ -259,8 +277,10 @@ class FlatTrainer:
         for t in twins:
             t.grad = None
         j = len(self.stage_defs) - 1 - k
-        with self._deferred():
-            torch.autograd.backward(roots, grad_tensors=grads, inputs=self.groups[j] + twins)
+        wanted = self.groups[j] + twins
+        if wanted and roots:   # (a frozen FIRST stage has neither parameters nor an input cut: nothing to differentiate)
+            with self._deferred():
+                torch.autograd.backward(roots, grad_tensors=grads, inputs=wanted)
         self._carry = [(o, tw.grad) for o, tw in zip(self._cuts[k][0], twins) if tw.grad is not None] if k > 0 else []
         self._gather(*self.group_ranges[j])
 
@@ -305,6 +325,7 @@ class FlatTrainer:
         self.graph = None
         self.static_loss = None
         self._carry = self._cuts = None
+        self._splitws = None
 
     def _prepare(self, x, tgt):
         self.model.zero_grad(set_to_none=True)
@@ -347,21 +368,29 @@ class FlatTrainer:
         for p in self.used:
             p.grad = None
         self.graph = torch.cuda.CUDAGraph()
+        # what the graphs hold besides torch's pool: the uncached [arrival counters | slabs] region of their split GEMM launches (one
+        # scope for all of this trainer's graphs: they replay one after the other on one stream) and, in the fp8 configuration, pointers
+        # into the device's quantisation table (pinned: a later calibration re-uses the rows instead of re-assigning them)
+        self._splitws = ops.SPLITWS.open_scope(x.device)
+        if self.fp8 and not getattr(self, "_quant_pinned", False):
+            ops.QUANT.pin(x.device)
+            self._quant_pinned = True
         # thread_local: RCCL's watchdog thread may query events while we capture; only this thread's calls are checked
-        if not self.staged:
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.static_loss = self._fwd_bwd(self.sx, self.st)
-                self._gather()
-        else:
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.static_loss = self._stage_part0(self.sx, self.st)
-            self.graphs = []   # same memory pool: every part reads what the parts before saved for it
-            for j in range(1, len(self.stage_defs)):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.graph.pool(), capture_error_mode="thread_local"):
-                    self._stage_part(j)
-                self.graphs.append(g)
-            self.graph2 = self.graphs[0] if self.graphs else None
+        with ops.SPLITWS.capturing(self._splitws):
+            if not self.staged:
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    self.static_loss = self._fwd_bwd(self.sx, self.st)
+                    self._gather()
+            else:
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    self.static_loss = self._stage_part0(self.sx, self.st)
+                self.graphs = []   # same memory pool: every part reads what the parts before saved for it
+                for j in range(1, len(self.stage_defs)):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                        self._stage_part(j)
+                    self.graphs.append(g)
+                self.graph2 = self.graphs[0] if self.graphs else None
 
     def _run_eager(self, x, tgt, between=None):
         """between(j): called after part j (its bucket is complete) while parts remain — the N > 1 flow starts the bucket's all-reduce there"""

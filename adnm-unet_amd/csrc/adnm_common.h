@@ -32,16 +32,13 @@ void adnm_launch_fold(const char* prof_name, const float* part, int rows, int n,
                       AdnmFoldSeg s3, hipStream_t st);
 
 // LDS-tiled NT / NN GEMM (lgemm.hip), reached through adnm_skgemm.  b_oc: second operand contiguous along the output axis (op NN);
-// nbs: cross-workgroup split of the reduction (combined inside the launch).  adnm_take_tickets (skgemm.hip): `n` zeroed arrival
-// counters from the per-device ring, NULL on failure.
+// nbs: cross-workgroup split of the reduction (combined inside the launch).  A split launch's workspace is the CALLER's:
+// [arrival counters: one int per output tile, zero when idle, rounded up to 256 B | the slabs]; ws_uncached: it is uncached device memory
+// (adnm_uncached_alloc), so a slab store is at the device-wide coherence point once it has completed and the ticket needs no fences.
 int64_t adnm_lgemm_ws_bytes(int64_t I, int64_t J, int64_t R, int nbs);
 int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, void* ws,
-                      int64_t ws_bytes, int64_t I, int64_t J, int64_t R, int nbs, int prec, float* q, hipStream_t st);
-int* adnm_take_tickets(int n, hipStream_t st);
-// Slab space of the in-launch split-K combine (skgemm.hip): `bytes` of the per-device ring of UNCACHED device memory, or NULL (ring not
-// allocatable: first use under stream capture, allocation failure, request larger than the ring) — the caller then keeps its slabs in the
-// workspace it was given and brackets the ticket with agent-scope fences.
-float* adnm_take_slabs(int64_t bytes, hipStream_t st);
+                      int64_t ws_bytes, int ws_uncached, int64_t I, int64_t J, int64_t R, int nbs, int prec, float* q, hipStream_t st);
+static inline int64_t adnm_ticket_bytes(int64_t ntiles) { return (ntiles * 4 + 255) / 256 * 256; }
 
 // Deferred LEAF launches (core.hip, include/adnm_hip.h: adnm_leafq_*).  A weight-gradient kernel is a leaf of the backward pass: nothing reads
 // its result before the optimiser.  While the calling thread has bound a leaf queue (AND a fold queue: the fold of a leaf's partials must

@@ -17,7 +17,7 @@ void adnm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* adnm_last_error(void) { return g_err; }
-extern "C" int adnm_abi_version(void) { return 8; }   // 8: adnm_mixnorm_*, adnm_bridge_pool_* (adnm_tokmean_* gone), up1 / up2 of adnm_haar_idwt; 7: precision ladder (`q` of the GEMM-shaped entry points, adnm_quant_update, fp8); 6: tap_ld of adnm_adnprep_*; 5: `prec` of adnm_tsgemm_nt; 4: workspace of adnm_colsum
+extern "C" int adnm_abi_version(void) { return 9; }   // 9: the split-K workspace is the caller's (ws_uncached of adnm_skgemm, adnm_uncached_alloc / _free; the per-device rings are gone); 8: adnm_mixnorm_*, adnm_bridge_pool_* (adnm_tokmean_* gone), up1 / up2 of adnm_haar_idwt; 7: precision ladder (`q` of the GEMM-shaped entry points, adnm_quant_update, fp8); 6: tap_ld of adnm_adnprep_*; 5: `prec` of adnm_tsgemm_nt; 4: workspace of adnm_colsum
 
 // ---- profiler: OFF by default (one relaxed atomic load per launch).  When bench.py enables it, every kernel
 // launch of the library is bracketed by hipEventRecord on the stream it is launched on; adnm_prof_collect()
@@ -448,5 +448,34 @@ extern "C" int adnm_quant_update(float* table, int64_t n, float* state, float he
   ADNM_PROF("quant_update", st, 64.0 * (double)n);
   quant_update_kernel<<<1, 256, 0, st>>>(reinterpret_cast<AdnmQuant*>(table), (int)n, state, headroom);
   ADNM_CHECK_LAUNCH("quant_update");
+  return ADNM_OK;
+}
+
+
+// Host-side allocation helpers for the workspace of split GEMM launches (include/adnm_hip.h).  Setup-time calls (they synchronise the
+// device): never made by a compute entry point, never under stream capture.
+extern "C" void* adnm_uncached_alloc(int64_t bytes) {
+  if (bytes <= 0) return nullptr;
+  void* ptr = nullptr;
+  if (hipExtMallocWithFlags(&ptr, (size_t)bytes, hipDeviceMallocUncached) != hipSuccess || !ptr) {
+    (void)hipGetLastError();
+    adnm_set_error("adnm_uncached_alloc: hipExtMallocWithFlags(%lld bytes, hipDeviceMallocUncached) failed", (long long)bytes);
+    return nullptr;
+  }
+  if (hipMemset(ptr, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(ptr);
+    adnm_set_error("adnm_uncached_alloc: zero fill failed");
+    return nullptr;
+  }
+  return ptr;
+}
+extern "C" int adnm_uncached_free(void* ptr) {
+  if (!ptr) return ADNM_OK;
+  if (hipFree(ptr) != hipSuccess) {
+    (void)hipGetLastError();
+    adnm_set_error("adnm_uncached_free: hipFree failed");
+    return ADNM_EINVAL;
+  }
   return ADNM_OK;
 }

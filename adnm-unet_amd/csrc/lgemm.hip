@@ -49,7 +49,7 @@ struct LgArgs {
   int64_t ldc;
   float* slab;          // nbs > 1: [tile][slice][64][64]
   int* tickets;
-  int uc;               // the slabs live in uncached memory (adnm_take_slabs): no agent-scope fences around the ticket
+  int uc;               // the slabs live in uncached memory (the caller said so: ws_uncached): no agent-scope fences around the ticket
   int I, J, R;
   int tiles_j, nbs, kt_per_slice, nkt;
   AdnmQuant* q;         // quantisation record (fp8 scales, amax collection) or NULL
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kThreads) void lgemm_kernel(LgArgs p) {
   if (!split) return;
 
   // In-launch combine of the nbs slabs of this tile.  Publish: every wave drains its slab stores, the workgroup meets, one lane
-  // (releases at agent scope unless the slabs are in uncached memory, skgemm.hip: adnm_take_slabs, and) draws a ticket; the workgroup that
+  // (releases at agent scope unless the slabs are in uncached memory — ws_uncached — and) draws a ticket; the workgroup that
   // draws the last one (acquires at agent scope and) adds the slabs in
   // slice order 0 .. nbs-1 (its own included, re-read from memory), so the sum does not depend on which slice arrived last.  The
   // counter goes back to zero for the next launch on the stream.  Correct wherever the slices ran (any CU / XCD).
@@ -377,11 +377,11 @@ LgPlan make_plan(int64_t I, int64_t J, int64_t R, int nbs) {
 // Shared with skgemm.hip (adnm_skgemm routes op NT / NN here).  b_oc: the second operand is contiguous along the OUTPUT axis (op NN).
 int64_t adnm_lgemm_ws_bytes(int64_t I, int64_t J, int64_t R, int nbs) {
   const LgPlan pl = make_plan(I, J, R, nbs);
-  return pl.nbs > 1 ? (int64_t)pl.ntiles * pl.nbs * kTile * kTile * (int64_t)sizeof(float) : 16;
+  return pl.nbs > 1 ? adnm_ticket_bytes(pl.ntiles) + (int64_t)pl.ntiles * pl.nbs * kTile * kTile * (int64_t)sizeof(float) : 16;
 }
 
 int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, void* ws,
-                      int64_t ws_bytes, int64_t I, int64_t J, int64_t R, int nbs, int prec, float* q, hipStream_t st) {
+                      int64_t ws_bytes, int ws_uncached, int64_t I, int64_t J, int64_t R, int nbs, int prec, float* q, hipStream_t st) {
   const LgPlan pl = make_plan(I, J, R, nbs);
   LgArgs p;
   p.A = a, p.lda = lda, p.B = b, p.ldb = ldb, p.bias = bias, p.C = c, p.ldc = ldc;
@@ -394,10 +394,11 @@ int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, in
       adnm_set_error("skgemm: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_lgemm_ws_bytes(I, J, R, nbs));
       return ADNM_EWORKSPACE;
     }
-    p.slab = (float*)ws;
-    if (float* slabs = adnm_take_slabs(adnm_lgemm_ws_bytes(I, J, R, nbs), st)) p.slab = slabs, p.uc = 1;
-    p.tickets = adnm_take_tickets(pl.ntiles, st);
-    ADNM_REQUIRE(p.tickets, "skgemm: no arrival counters (first split launch of a device under stream capture, or hipMalloc failed)");
+    // the caller's workspace = [arrival counters, zero when idle | slabs]; in uncached memory the ticket needs no fences
+    ADNM_REQUIRE(((uintptr_t)ws & 255) == 0, "skgemm: a split launch needs a 256-byte aligned workspace");
+    p.tickets = (int*)ws;
+    p.slab = (float*)((char*)ws + adnm_ticket_bytes(pl.ntiles));
+    p.uc = ws_uncached ? 1 : 0;
   }
   const unsigned grid = (unsigned)(pl.ntiles * pl.nbs);
 #define LG(OC)                                                                                                                    \

@@ -28,8 +28,6 @@
 // Which reduction steps a lane feeds to which MFMA is a permutation shared by both operands ("k-permutation").
 #include "adnm_common.h"
 
-#include <mutex>
-
 namespace {
 
 using f32x4 = adnm_f32x4;
@@ -49,7 +47,7 @@ struct SkArgs {
   int I, J, R;
   int tiles_j, ntiles, nbs, wpt, chunks_per_wave, nchunks;   // nbs workgroup-slices x wpt waves per tile; a chunk = 16 KC steps
   int* tickets;         // NT / NN with nbs > 1: one arrival counter per output tile (zero when idle); the result goes to `out`
-  int uc;               // the slabs live in uncached memory (adnm_take_slabs): no agent-scope fences around the ticket
+  int uc;               // the slabs live in uncached memory (the caller said so: ws_uncached): no agent-scope fences around the ticket
   float* out;
   int64_t ldo;
   AdnmQuant* q;         // quantisation record (fp8 scales, amax collection) or NULL
@@ -533,81 +531,7 @@ Plan make_plan(int op, int64_t I, int64_t J, int64_t R, bool direct, bool bf16) 
   return op == ADNM_SKGEMM_TN ? plan_deferred(I, J, R, direct, bf16) : plan_critical(op, I, J, R, !direct && J % 4 == 0, bf16);
 }
 
-// Arrival counters of the in-launch combine: a per-device ring of zero-initialised ints owned by the library (allocated on the first
-// split launch of a device, which therefore must not happen under stream capture: every caller here runs eager steps first).  A
-// launch takes the next `ntiles` counters; the workgroup that draws a tile's last ticket puts the counter back to zero, so a slot is
-// clean again when its launch retires, long before the ring (1 M counters) comes round.  A captured launch keeps its slots for every
-// replay, which is safe for the same reason: replays of one graph are ordered on their stream.
-constexpr int kTicketInts = 1 << 20, kMaxDevices = 64;
-struct TicketRing {
-  int* base = nullptr;
-  int next = 0;
-};
-std::mutex ticket_mutex;
-TicketRing ticket_rings[kMaxDevices];
 }  // namespace
-
-int* adnm_take_tickets(int n, hipStream_t st) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || n > kTicketInts) return nullptr;
-  std::lock_guard<std::mutex> lock(ticket_mutex);
-  TicketRing& r = ticket_rings[dev];
-  if (!r.base) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-    if (hipMalloc((void**)&r.base, sizeof(int) * kTicketInts) != hipSuccess) return r.base = nullptr;
-    if (hipMemset(r.base, 0, sizeof(int) * kTicketInts) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
-  }
-  if (r.next + n > kTicketInts) r.next = 0;
-  int* t = r.base + r.next;
-  r.next += n;
-  return t;
-}
-
-// Slabs of the in-launch combine in UNCACHED device memory.  The per-XCD L2s are not coherent with one another for ordinary (cached) device
-// memory, so publishing a slab written with plain stores needs an agent-scope release = a write-back of the whole L2 of the publishing
-// XCD (buffer_wbl2), and reading it an acquire = an invalidate (buffer_inv) — per WORKGROUP of a split launch: measured, the launch time grew in
-// proportion to the slice count (profiles/r03_splitk_slices.txt).  Memory allocated uncached (MTYPE UC: hipDeviceMallocUncached) is not
-// held in L2 at all: a slab store is at the device-wide coherence point when it has completed (s_waitcnt vmcnt(0)), a load reads it from there,
-// and the ticket needs no fence.  One ring per device (128 MB, taken in launch order like the counters; launches on one stream are ordered,
-// so a region is idle again long before the ring comes round; a captured launch keeps its region for every replay).
-namespace {
-constexpr int64_t kSlabRingBytes = 128ll << 20;
-struct SlabRing {
-  char* base = nullptr;
-  int64_t next = 0;
-  bool failed = false;
-};
-SlabRing slab_rings[kMaxDevices];
-bool slabs_uncached() {   // ADNM_SK_UC_SLABS=0: measurement aid / the fenced protocol of round 2 (tests/test_kernels_gpu.py runs both)
-  const char* e = getenv("ADNM_SK_UC_SLABS");
-  return !(e && e[0] == '0');
-}
-}  // namespace
-
-float* adnm_take_slabs(int64_t bytes, hipStream_t st) {
-  int dev = 0;
-  if (!slabs_uncached() || bytes <= 0 || bytes > kSlabRingBytes || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
-  std::lock_guard<std::mutex> lock(ticket_mutex);
-  SlabRing& r = slab_rings[dev];
-  if (r.failed) return nullptr;
-  if (!r.base) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-    void* ptr = nullptr;
-    if (hipExtMallocWithFlags(&ptr, (size_t)kSlabRingBytes, hipDeviceMallocUncached) != hipSuccess || !ptr) {
-      (void)hipGetLastError();
-      r.failed = true;
-      return nullptr;
-    }
-    r.base = (char*)ptr;
-  }
-  const int64_t need = (bytes + 255) & ~255ll;
-  if (r.next + need > kSlabRingBytes) r.next = 0;
-  float* out = reinterpret_cast<float*>(r.base + r.next);
-  r.next += need;
-  return out;
-}
 
 namespace {
 int shape_ok(int op, int64_t M, int64_t N, int64_t K) {
@@ -638,7 +562,9 @@ namespace {
 int64_t ws_need(const Plan& pl, int64_t I, int64_t J, int64_t R) {
   if (pl.kernel == KERNEL_LDS) return adnm_lgemm_ws_bytes(I, J, R, pl.nbs);
   if (pl.kernel < 0) return 16;
-  return pl.nbs > 1 ? (int64_t)pl.nbs * (I * J + I) * (int64_t)sizeof(float) : 16;
+  if (pl.nbs <= 1) return 16;
+  // [arrival counters (in-launch combine only) | nbs slabs of I*J (+ I bias-gradient sums: op TN)]
+  return (pl.combine ? adnm_ticket_bytes(pl.ntiles) : 0) + (int64_t)pl.nbs * (I * J + I) * (int64_t)sizeof(float);
 }
 }  // namespace
 
@@ -652,7 +578,7 @@ extern "C" int64_t adnm_skgemm_ws_bytes(int op, int64_t M, int64_t N, int64_t K)
 }
 
 extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, float* dbias,
-                           void* ws, int64_t ws_bytes, int64_t M, int64_t N, int64_t K, int prec, float* q, adnm_stream_t stream) {
+                           void* ws, int64_t ws_bytes, int ws_uncached, int64_t M, int64_t N, int64_t K, int prec, float* q, adnm_stream_t stream) {
   ADNM_REQUIRE(prec >= ADNM_MFMA_F32 && prec <= ADNM_MFMA_FP8_GRAD, "skgemm: bad prec %d", prec);
   const bool fp8 = prec == ADNM_MFMA_FP8 || prec == ADNM_MFMA_FP8_GRAD;
   ADNM_REQUIRE(!fp8 || q, "skgemm: the fp8 modes need a quantisation record");
@@ -677,7 +603,7 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   const double algo_bytes = 4.0 * ((double)M * (K + N) + (double)N * K);
   if (pl.kernel == KERNEL_LDS) {
     ADNM_PROF(scope, st, algo_bytes);
-    const int rc = adnm_lgemm_launch(op == ADNM_SKGEMM_NN, a, lda, b, ldb, bias, c, ldc, ws, ws_bytes, I, J, R, pl.nbs, prec, q, st);
+    const int rc = adnm_lgemm_launch(op == ADNM_SKGEMM_NN, a, lda, b, ldb, bias, c, ldc, ws, ws_bytes, ws_uncached, I, J, R, pl.nbs, prec, q, st);
     if (rc != ADNM_OK) return rc;
     ADNM_CHECK_LAUNCH("skgemm");
     return ADNM_OK;
@@ -704,11 +630,11 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   p.tickets = nullptr, p.out = c, p.ldo = ldc, p.uc = 0;
   p.q = reinterpret_cast<AdnmQuant*>(q);
   if (pl.combine) {
-    if (float* slabs = adnm_take_slabs(ws_need(pl, I, J, R), st)) {   // (the bias-gradient rows of a partial row exist for op TN only)
-      p.C = slabs, p.uc = 1;
-    }
-    p.tickets = adnm_take_tickets(pl.ntiles, st);
-    ADNM_REQUIRE(p.tickets, "skgemm: no arrival counters (first split launch of a device under stream capture, or hipMalloc failed)");
+    // the caller's workspace = [arrival counters, zero when idle | slabs]; in uncached memory the ticket needs no fences
+    ADNM_REQUIRE(((uintptr_t)ws & 255) == 0, "skgemm: a split launch needs a 256-byte aligned workspace");
+    p.tickets = (int*)ws;
+    p.C = (float*)((char*)ws + adnm_ticket_bytes(pl.ntiles));
+    p.uc = ws_uncached ? 1 : 0;
   }
   const unsigned grid = (unsigned)adnm_cdiv((int64_t)pl.ntiles * pl.nbs, kWaves / pl.wpt);
   bool queued = false;

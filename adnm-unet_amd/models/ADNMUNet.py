@@ -373,12 +373,12 @@ class VisionMamba(nn.Module):
         enc, dec = self.encoder, self.decoder
 
         def s0(x):                      # encoder1-3 + attn: 128x128 .. 16x16 conv stages
-            ops.prep_group(*enc.lo_modules()) if x.is_cuda else None
+            ops.prep_group(*enc.lo_modules())
             x, skips, res = enc.forward_lo(x.squeeze(2))
             return (x, res, *skips)
 
         def s1(x, res, *lo):            # encoder4-6 + attn2: the mixer stages
-            ops.prep_group(*enc.hi_modules()) if x.is_cuda else None
+            ops.prep_group(*enc.hi_modules())
             x, hi = enc.forward_hi(x)
             return (x, res, *lo, *hi)
 
@@ -387,24 +387,22 @@ class VisionMamba(nn.Module):
             return (x, res, *skips, *feats)
 
         def s3(x, res, *rest):          # decoder blocks
-            ops.prep_group(*dec.block_modules()) if x.is_cuda else None
+            ops.prep_group(*dec.block_modules())
             return (dec.forward_blocks(x, list(rest[:7]), list(rest[7:])), res)
 
         def s4(x, res):                 # refiner + output head
-            ops.prep_group(self.refiner) if x.is_cuda else None
+            ops.prep_group(self.refiner)
             return (self.refiner(x, res).unsqueeze(2),)
 
         return [(s0, enc.lo_modules()), (s1, enc.hi_modules()), (s2, dec.skip_modules()), (s3, dec.block_modules()), (s4, [self.refiner])]
 
     def forward_stage1(self, x):
-        if x.is_cuda:
-            ops.prep_group(self.encoder)   # kernel-layout parameters of all its mixers / WTConv2ds: one launch per kind
+        ops.prep_group(self.encoder)   # kernel-layout parameters of all its mixers / WTConv2ds: one launch per kind
         x, skips, res = self.encoder(x.squeeze(2))
         return (x, res, *skips)
 
     def forward_stage2(self, x, res, *skips):
-        if x.is_cuda:
-            ops.prep_group(self.decoder, self.refiner)
+        ops.prep_group(self.decoder, self.refiner)
         return self.refiner(self.decoder(x, list(skips)), res).unsqueeze(2)
 
     def stage1_parameters(self):

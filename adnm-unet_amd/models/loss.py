@@ -12,12 +12,17 @@ class enRainfallLoss(nn.Module):
         self.omega_t, self.alpha, self.gamma = omega_t, alpha, gamma
 
     def forward(self, pred, target):
-        if pred.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.float32 and pred.shape == target.shape:
-            return ops.rainloss(pred, target, self.omega_t, self.alpha, self.gamma)  # value + gradient in one HIP pass
-        return self.forward_torch(pred, target)
+        # the product path is the fused HIP pass (value + gradient); like every other adnm_hip op it has no CPU / other-dtype fallback
+        if not (pred.is_cuda and target.is_cuda):
+            raise RuntimeError("enRainfallLoss: adnm_hip kernels run on the GPU only (there is no CPU fallback); got CPU tensors "
+                               "(forward_torch() states the same expression in torch ops for checks)")
+        if pred.dtype != torch.float32 or target.dtype != torch.float32 or pred.shape != target.shape:
+            raise RuntimeError(f"enRainfallLoss: needs fp32 pred / target of one shape, got {pred.dtype} {tuple(pred.shape)}, "
+                               f"{target.dtype} {tuple(target.shape)}")
+        return ops.rainloss(pred, target, self.omega_t, self.alpha, self.gamma)
 
     def forward_torch(self, pred, target):
-        """The same expression in device-agnostic torch ops (CPU tensors, odd dtypes)."""
+        """The same expression in device-agnostic torch ops: a checker for the tests (fp64 on the CPU), never called by forward()."""
         err = (pred - target).abs()
         over = pred >= target
         w = torch.where(over, 1.0 - self.omega_t, self.omega_t)                # asymmetric L1 (loss.py:40-41)

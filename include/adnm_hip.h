@@ -9,8 +9,10 @@
  * ctypes (adnm-unet_amd/adnm_hip/lib.py); INTEGRATION.md shows the binding.
  *
  * Conventions
- *  - every pointer is a DEVICE pointer owned by the caller (torch allocator); no entry point
- *    allocates, frees, synchronises or touches the host copy of anything;
+ *  - every pointer is a DEVICE pointer owned by the caller (torch allocator); no compute entry point
+ *    allocates, frees, synchronises or touches the host copy of anything (the two setup-time helpers
+ *    adnm_uncached_alloc / adnm_uncached_free exist so that the CALLER can own the uncached workspace
+ *    of split GEMM launches: see adnm_skgemm);
  *  - kernels are enqueued on `stream` (torch.cuda.current_stream().cuda_stream) and are
  *    hipGraph-capturable; workspace is passed in, its size comes from the *_ws_bytes helper;
  *  - token tensors are channels-last ("BLD" = (B, H*W, C) = NHWC), the layout the reference
@@ -20,8 +22,9 @@
  *  - return value 0 = launched; negative = rejected (nothing launched), text via
  *    adnm_last_error() (thread-local).  The compute entry points keep no global mutable state: they are re-entrant
  *    per thread / stream / device (the reference's nn.DataParallel calls them from one thread per device).  The only
- *    process-wide state is the opt-in profiler's record list (adnm_prof_*, mutex-guarded) and per-device "dynamic LDS
- *    limit raised" flags (atomics; setting one twice is harmless).
+ *    process-wide state is the opt-in profiler's record list (adnm_prof_*, mutex-guarded), per-device "dynamic LDS
+ *    limit raised" flags (atomics; setting one twice is harmless) and the thread-local error string and fold- / leaf-queue
+ *    bindings.  There are no library-owned device buffers.
  */
 #ifndef ADNM_HIP_H
 #define ADNM_HIP_H
@@ -361,14 +364,27 @@ int adnm_colsum(const float* x, float* out, int64_t rows, int64_t n, void* ws, i
  *   ADNM_SKGEMM_TN: c[N,K] = a[M,N]^T . b[M,K]; dbias[N] = sum_m a   weight gradient  N % 4 == 0, K % 4 == 0
  * lda / ldb / ldc: row strides in elements (multiples of 4); bias only with NT, dbias only with TN; c / dbias OVERWRITTEN.
  * prec / q: the precision ladder and the call site's quantisation record (see ADNM_MFMA_*); a = the "first operand", b = the weight.
- * TN (the weight gradient) runs on bf16 operands in the fp8 modes. */
+ * TN (the weight gradient) runs on bf16 operands in the fp8 modes.
+ * Workspace (adnm_skgemm_ws_bytes; 16 = the shape is not split): a reduction that would leave CUs idle is split over workgroups.
+ *   TN: ws holds fp32 partials for the shared fold — ordinary device memory.
+ *   NT / NN: the slabs are combined INSIDE the launch: ws = [arrival counters: one int per output tile, rounded up to 256 B | slabs],
+ *     256-byte aligned.  The counters must be ZERO when the launch starts and are zero again when it ends, so one workspace serves
+ *     every launch of a stream (launches on a stream are ordered); it must not be shared by launches that can run concurrently
+ *     (another stream, another captured graph replayed beside this one).  ws_uncached != 0: the workspace is uncached device memory
+ *     (adnm_uncached_alloc): a completed slab store is then at the device-wide coherence point and the arrival ticket needs no
+ *     agent-scope release / acquire (= no per-workgroup write-back / invalidate of an XCD's L2); ws_uncached == 0: any device memory,
+ *     fenced protocol.  Both give bitwise identical results (slabs are added in slice order).
+ * adnm_uncached_alloc: `bytes` of zero-filled uncached device memory on the current device (hipExtMallocWithFlags +
+ * hipDeviceMallocUncached), NULL on failure; a host-side setup call (it synchronises; not under stream capture). */
 #define ADNM_SKGEMM_NT 0
 #define ADNM_SKGEMM_NN 1
 #define ADNM_SKGEMM_TN 2
 int adnm_skgemm_supported(int op, int64_t M, int64_t N, int64_t K);
 int64_t adnm_skgemm_ws_bytes(int op, int64_t M, int64_t N, int64_t K);
 int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, float* dbias,
-                void* ws, int64_t ws_bytes, int64_t M, int64_t N, int64_t K, int prec, float* q, adnm_stream_t stream);
+                void* ws, int64_t ws_bytes, int ws_uncached, int64_t M, int64_t N, int64_t K, int prec, float* q, adnm_stream_t stream);
+void* adnm_uncached_alloc(int64_t bytes);
+int adnm_uncached_free(void* ptr);
 
 /* ---------------------------------------------------------------- enRainfallLoss (K14)
  * models/loss.py:30-57 of the reference (train_untils.py:43 builds it with omega_t 0.57, alpha 0.25, gamma 0):

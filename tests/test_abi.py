@@ -15,7 +15,7 @@ def test_header_parses_and_library_exports_every_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for name in protos:
         assert hasattr(so, name), f"{name} declared in include/adnm_hip.h but not exported"
-    assert lib.load().adnm_abi_version() == 8
+    assert lib.load().adnm_abi_version() == 9
 
 
 def test_ws_queries_are_pure_host_functions():
@@ -37,3 +37,15 @@ def test_argument_validation_happens_before_any_launch():
 def test_no_cpu_fallback():
     with pytest.raises(RuntimeError, match="GPU only"):
         ops.rownorm(torch.zeros(4, 8), torch.ones(8), None, None, None, 1e-5, True)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_loss_and_model_refuse_cpu_tensors():
+    """the loss module and the model's parameter preparation raise on the CPU like every kernel wrapper (no silent torch path)."""
+    from models.loss import enRainfallLoss
+    with pytest.raises(RuntimeError, match="GPU only"):
+        enRainfallLoss(0.57, 0.25, 0.0)(torch.zeros(1, 2, 1, 8, 8), torch.zeros(1, 2, 1, 8, 8))
+    from models.ADNMUNet import create_ADNMUNet
+    model = create_ADNMUNet(5, 20, 6, img_size=64)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        model(torch.zeros(1, 5, 1, 64, 64))

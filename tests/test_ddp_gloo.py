@@ -391,3 +391,61 @@ def test_real_model_bucket_map_is_deterministic():
     assert bucket_of(offs["decoder.e2ds.0.ffd.project_in.conv.weight"]) == 2 and bucket_of(offs["decoder.fusion.att7.weight"]) == 2
     assert bucket_of(offs["encoder.encoder6.mixer_layers.0.in_proj.weight"]) == 3 and bucket_of(offs["encoder.attn2.attn_mlp.fc1.weight"]) == 3
     assert bucket_of(offs["encoder.encoder1.conv2.0.conv.weight"]) == 4 and bucket_of(offs["encoder.attn.attn_mlp.fc1.weight"]) == 4
+
+
+def _frozen_mid_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adnm-unet_amd"))
+    from adnm_hip.trainer import FlatTrainer
+    model = Toy3()
+    for p in model.m.parameters():   # the MIDDLE stage is frozen: its bucket is empty, the buckets either side keep their parts
+        p.requires_grad_(False)
+    tr = FlatTrainer(model, lambda o, t: (o - t).pow(2).mean(), lr=1e-2, eps=1e-9, weight_decay=1e-2, max_norm=0.5, use_graph=False, fused=False)
+    torch.manual_seed(100 + rank)
+    xs = [torch.randn(5, 8) for _ in range(3)]
+    ts = [torch.randn(5, 4) for _ in range(3)]
+    for x, t in zip(xs, ts):
+        tr.step(x, t)
+    assert tr.staged and len(tr.buckets) == len(tr.stage_defs) == 3
+    assert [len(g) for g in tr.groups] == [3, 0, 2] and tr.buckets[1][0] == tr.buckets[1][1]
+    q.put((rank, _plain({"final": {k: p.detach().clone() for k, p in model.named_parameters()}, "xs": xs, "ts": ts})))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_trainer_frozen_middle_stage():
+    """a stage without trainable parameters must keep its (empty) bucket, so that bucket j still belongs to backward part j:
+    2 ranks x batch 5 with the middle stage frozen == 1 process on the concatenated batch."""
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_frozen_mid_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: _torchify(o) for r, o in (q.get(timeout=180) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k in res[0]["final"]:
+        assert torch.equal(res[0]["final"][k], res[1]["final"][k]), f"replicas diverged at {k}"
+    model = Toy3()
+    for p in model.m.parameters():
+        p.requires_grad_(False)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-2, eps=1e-9, weight_decay=1e-2)
+    for i in range(3):
+        x = torch.cat([res[r]["xs"][i] for r in range(world)])
+        t = torch.cat([res[r]["ts"][i] for r in range(world)])
+        (model(x) - t).pow(2).mean().backward()
+        torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.requires_grad], 0.5)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    for k, p in model.named_parameters():
+        if k.startswith("dead"):
+            continue
+        assert torch.allclose(res[0]["final"][k], p, atol=2e-6, rtol=1e-5), k

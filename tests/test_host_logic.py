@@ -160,3 +160,34 @@ def test_bench_stdout_line_is_small_and_parses():
     # ... and one that cannot fit raises instead of printing a line the driver will not parse
     with pytest.raises(RuntimeError):
         bench.stdout_line(dict(res, dtype_detail="d" * 5000), families, "t.json")
+
+
+def test_flat_trainer_refuses_unclaimed_and_doubly_claimed_parameters():
+    """a parameter that receives a gradient but is named by no stage (it would never be trained, only decayed), or by two
+    stages, is an error, not a silent layout decision."""
+    from adnm_hip.trainer import FlatTrainer
+
+    class M(nn.Module):
+        def __init__(self, stages):
+            super().__init__()
+            torch.manual_seed(0)
+            self.a, self.b = nn.Linear(4, 4), nn.Linear(4, 2)
+            self.extra = nn.Parameter(torch.ones(()))
+            self._stages = stages
+
+        def forward(self, x):
+            return self.b(torch.tanh(self.a(x))) * self.extra
+
+        def forward_stages(self):
+            s0 = lambda x: (torch.tanh(self.a(x)),)
+            s1 = lambda h: (self.b(h) * self.extra,)
+            return [(s0, self._stages[0](self)), (s1, self._stages[1](self))]
+
+    x, t = torch.randn(3, 4), torch.randn(3, 2)
+    loss = lambda o, tt: (o - tt).pow(2).mean()
+    tr = FlatTrainer(M((lambda m: [m.a], lambda m: [m.b])), loss, use_graph=False, fused=False, overlap=True)
+    with pytest.raises(RuntimeError, match="belong to no stage.*extra"):
+        tr.prepare(x, t)
+    tr = FlatTrainer(M((lambda m: [m.a, m.b], lambda m: [m.b])), loss, use_graph=False, fused=False, overlap=True)
+    with pytest.raises(RuntimeError, match="more than one stage"):
+        tr.prepare(x, t)

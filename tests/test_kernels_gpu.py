@@ -653,9 +653,9 @@ def test_skgemm_linear(M, K, N, bias):
 
 @pytest.mark.parametrize("M,K,N", [(64, 4096, 1024), (256, 4096, 1024), (64, 1024, 4672), (1024, 2048, 512), (4, 2144, 256)])
 def test_skgemm_split_slab_protocols_agree(M, K, N, monkeypatch):
-    """The in-launch split-K combine publishes its slabs either through the library's ring of UNCACHED device memory (no fences around
-    the arrival ticket) or, as a fallback, through the caller's workspace bracketed by agent-scope release / acquire fences: same
-    slabs, same summation order — forward and input gradient must agree bit for bit, run to run and between the two protocols."""
+    """The in-launch split-K combine publishes its slabs through the CALLER's workspace: this stream's region of UNCACHED device memory
+    (ops.SPLITWS; no fences around the arrival ticket) or, with ws_uncached = 0, any memory bracketed by agent-scope release / acquire
+    fences: same slabs, same summation order — forward and input gradient must agree bit for bit, run to run and between the protocols."""
     x, w, cot = T(f"sp.x{M}{K}", (M, K)).to(DEV), T(f"sp.w{N}{K}", (N, K), 0.05).to(DEV), T(f"sp.c{M}{N}", (M, N)).to(DEV)
     outs = []
     for mode in ("1", "0", "1"):
@@ -667,6 +667,51 @@ def test_skgemm_split_slab_protocols_agree(M, K, N, monkeypatch):
     for y, dx in outs[1:]:
         assert torch.equal(outs[0][0], y) and torch.equal(outs[0][1], dx)
     assert_close(outs[0][0], x.double() @ w.double().t(), OUT_TOL, "y")
+
+
+def test_split_gemm_graphs_replay_side_by_side():
+    """the split-K workspace is owned per unit of ordering.  Two captured graphs of split GEMMs, each with its own
+    capture scope, replayed AT THE SAME TIME on two streams (plus eager split launches on a third) give the single-stream results bit
+    for bit; a capture nobody opened a scope for (ordinary memory, zeroed counters, fenced protocol) agrees too."""
+    shapes = [(64, 4096, 1024), (256, 4096, 1024), (64, 1024, 4672)]
+    data = [(T(f"sg.x{M}{K}", (M, K)).to(DEV), T(f"sg.w{N}{K}", (N, K), 0.05).to(DEV), T(f"sg.c{M}{N}", (M, N)).to(DEV)) for M, K, N in shapes]
+    assert all(lib.query("adnm_skgemm_ws_bytes", 0, M, N, K) > 16 for M, K, N in shapes), "these shapes are meant to split"
+
+    def work():
+        out = []
+        for _ in range(4):
+            for x, w, cot in data:
+                out += [ops.k_linear(x, w, None), ops.k_linear_dx(cot, w)]
+        return out
+    ref = [t.clone() for t in work()]
+    torch.cuda.synchronize()
+    graphs = []
+    for scoped in (True, True, False):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        scope = ops.SPLITWS.open_scope(torch.device(DEV)) if scoped else None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            work()
+            with ops.SPLITWS.capturing(scope), torch.cuda.graph(g, stream=s):
+                outs = work()
+        torch.cuda.synchronize()
+        graphs.append((g, s, outs, scope))
+    eager_stream = torch.cuda.Stream()
+    for rep in range(5):
+        for _, _, outs, _ in graphs:
+            for t in outs:
+                t.fill_(float("nan"))
+        torch.cuda.synchronize()
+        for g, s, _, _ in graphs:
+            with torch.cuda.stream(s):
+                g.replay()
+        with torch.cuda.stream(eager_stream):
+            eager = work()
+        torch.cuda.synchronize()
+        for k, (_, _, outs, _) in enumerate(graphs):
+            assert all(torch.equal(a, b) for a, b in zip(outs, ref)), f"graph {k}, replay {rep}"
+        assert all(torch.equal(a, b) for a, b in zip(eager, ref)), f"eager beside the graphs, replay {rep}"
 
 
 def test_skgemm_strided_operands():
@@ -1029,7 +1074,7 @@ def test_fp8_amax_collection_and_update(fp8_mfma):
         ops.set_mfma_precision("f32")
 
 
-@pytest.mark.parametrize("B,Cs", [(4, [256, 512, 1024]), (2, [32, 64, 128, 128, 256, 512, 1024]), (7, [36, 20])])
+@pytest.mark.parametrize("B,Cs", [(4, [256, 512, 1024]), (2, [32, 64, 128, 128, 256, 512, 1024]), (7, [36, 20]), (16, [256, 512, 1024]), (19, [36, 20])])
 def test_bridge_heads(B, Cs):
     """every head of Channel_Att_Bridge (Linear + IntensityGate, model_untils.py:594-613,744-750) in one launch each way vs fp64 torch ops;
     the enhance / threshold scalars are shared by all heads"""

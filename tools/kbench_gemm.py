@@ -47,7 +47,8 @@ def graph_time(fn, nvar=1, defer=False):
     with torch.cuda.stream(s):
         fn(0)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s):
+        scope = ops.SPLITWS.open_scope(torch.device(dev, torch.cuda.current_device()))   # the split launches' uncached workspace, kept with the graph
+        with ops.SPLITWS.capturing(scope), torch.cuda.graph(g, stream=s):
             # the weight-gradient op defers its split-K folds exactly as under the trainer: queued, batched, flushed at the end
             with ops.FOLDS.active(torch.device(dev, torch.cuda.current_device()), defer):
                 for r in range(reps):
