@@ -565,10 +565,20 @@ class _UncachedRegion:
             pass
 
 
+class _SplitRegion:
+    """what one unit of ordering owns for its split GEMM launches: zeroed arrival counters in ordinary device memory (a torch tensor from
+    the regular allocator — allocated OUTSIDE any capture) and `nbytes` of uncached slab space"""
+    COUNTER_BYTES = 1 << 20   # 256 k output tiles per launch
+
+    def __init__(self, device, nbytes):
+        self.counters = torch.zeros(self.COUNTER_BYTES // 4, dtype=torch.int32, device=device)
+        self.slabs = _UncachedRegion(device, nbytes)
+        self.nbytes = self.slabs.nbytes
+
+
 class SplitWorkspaces:
-    """The caller's side of the in-launch split-K combine (include/adnm_hip.h, adnm_skgemm): the [arrival counters | slabs] workspace
-    of a split NT / NN launch, in UNCACHED device memory, owned here per unit of ordering — never shared by launches that could run
-    at the same time:
+    """The caller's side of the in-launch split-K combine (include/adnm_hip.h, adnm_skgemm): the arrival counters and the UNCACHED slab
+    space of a split NT / NN launch, owned here per unit of ordering — never shared by launches that could run at the same time:
       * eager launches: one region per (device, stream); launches on a stream are ordered, so one region serves them all.  It grows
         (a new, larger region; outgrown ones are kept until release(), an in-flight launch may still use them);
       * stream capture: one region per capture SCOPE.  The owner of the graphs (FlatTrainer, GraphedForward) opens a scope before it
@@ -576,7 +586,7 @@ class SplitWorkspaces:
         largest request this device has seen (the eager warm-up steps).  All graphs of one scope must replay on one stream, one at a
         time (FlatTrainer's stage graphs do).  A capture nobody opened a scope for gets an ordinary torch workspace with freshly
         zeroed counters and the fenced protocol."""
-    MIN_BYTES = 8 << 20
+    MIN_BYTES = 16 << 20
 
     def __init__(self):
         self._lock = threading.Lock()
@@ -584,9 +594,11 @@ class SplitWorkspaces:
         self._seen = {}      # device index -> largest request so far
         self._scope = {}     # device index -> the open capture scope (a dict holding its region)
 
-    def take(self, device, nbytes):
-        """-> (ptr, nbytes, uncached flag, keep-alive object) for one split launch on torch's current stream"""
+    def take(self, device, nbytes, counter_bytes):
+        """-> the region (counters + uncached slab space) of one split launch on torch's current stream, or None (an un-scoped capture)"""
         idx = device.index if device.index is not None else torch.cuda.current_device()
+        if counter_bytes > _SplitRegion.COUNTER_BYTES:
+            raise RuntimeError(f"adnm_hip: a split GEMM with {counter_bytes // 4} output tiles (more than {_SplitRegion.COUNTER_BYTES // 4})")
         with self._lock:
             self._seen[idx] = max(self._seen.get(idx, 0), nbytes)
             if torch.cuda.is_current_stream_capturing():
@@ -595,21 +607,21 @@ class SplitWorkspaces:
                     return None
                 reg = scope["region"]
                 if reg.nbytes < nbytes:
-                    raise RuntimeError(f"adnm_hip: a split GEMM inside a hipGraph capture needs {nbytes} workspace bytes, the capture scope "
+                    raise RuntimeError(f"adnm_hip: a split GEMM inside a hipGraph capture needs {nbytes} slab bytes, the capture scope "
                                        f"holds {reg.nbytes}: run the step eagerly once before capturing (FlatTrainer.prepare does)")
-                return reg.ptr, reg.nbytes, 1, reg
+                return reg
             key = (idx, _stream())
             regs = self._streams.setdefault(key, [])
             if not regs or regs[-1].nbytes < nbytes:
-                regs.append(_UncachedRegion(device, max(self.MIN_BYTES, 2 * nbytes if regs else nbytes)))
-            return regs[-1].ptr, regs[-1].nbytes, 1, regs[-1]
+                regs.append(_SplitRegion(device, max(self.MIN_BYTES, 2 * nbytes if regs else nbytes)))
+            return regs[-1]
 
     def open_scope(self, device):
         """Before a capture (NOT inside one: it allocates).  -> the scope; keep it alive as long as the captured graphs."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
         with self._lock:
             need = max(self.MIN_BYTES, self._seen.get(idx, 0))
-        return {"region": _UncachedRegion(device, need), "device": idx}
+        return {"region": _SplitRegion(device, need), "device": idx}
 
     def capturing(self, scope):
         """with SPLITWS.capturing(scope): <torch.cuda.graph(...)> — split launches captured inside use the scope's region"""
@@ -1840,19 +1852,25 @@ def _skgemm(op, a, b, bias, c, dbias, M, N, K, defer=False, side=False, q=None, 
         raise RuntimeError(f"adnm_hip linear: no kernel takes op={('NT', 'NN', 'TN')[op]} M={M} N={N} K={K} "
                            "(every op needs N % 4 == 0 and K % 4 == 0)")
     nb = lib.query("adnm_skgemm_ws_bytes", op, M, N, K)
-    uc = 0
+    ucp, ucn = None, 0
     if op != SK_TN and nb > 16:
-        # NT / NN split over workgroups: the slabs are combined inside the launch — [arrival counters | slabs] in this stream's (or this
-        # capture scope's) uncached region (SplitWorkspaces); an un-scoped capture takes a torch workspace with zeroed counters instead
-        got = SPLITWS.take(a.device, nb)
-        if got is None:
-            ws = _ws(nb, a.device)
+        # NT / NN split over workgroups: the slabs are combined inside the launch — arrival counters + uncached slab space of this stream
+        # (or this capture scope: SplitWorkspaces); an un-scoped capture takes a torch workspace [zeroed counters | slabs], fenced protocol
+        reg = SPLITWS.take(a.device, nb, lib.query("adnm_skgemm_counter_bytes", op, M, N, K))
+        if reg is None:
+            ws = _ws((nb + 255) // 256 * 256 + 256, a.device)
             ws.zero_()
-            wsp, wsn = ws.data_ptr(), nb
+            off = (-ws.data_ptr()) % 256
+            wsp, wsn = ws.data_ptr() + off, nb
         else:
-            wsp, wsn, uc, ws = got
-            if os.environ.get("ADNM_SK_UC_SLABS", "1") == "0":   # measurement aid: the fenced protocol on the same memory
-                uc = 0
+            ws = reg
+            wsp, wsn = reg.counters.data_ptr(), reg.counters.numel() * 4
+            if os.environ.get("ADNM_SK_UC_SLABS", "1") == "0":   # measurement aid / test: the fenced protocol, slabs behind the counters
+                ws = (reg, _ws(nb + 256, a.device))
+                ws[1].zero_()
+                wsp, wsn = ws[1].data_ptr() + (-ws[1].data_ptr()) % 256, nb
+            else:
+                ucp, ucn = reg.slabs.ptr, reg.slabs.nbytes
     else:
         ws = _ws(nb, a.device)
         wsp, wsn = ws.data_ptr(), nb
@@ -1863,7 +1881,7 @@ def _skgemm(op, a, b, bias, c, dbias, M, N, K, defer=False, side=False, q=None, 
     else:
         prec, qp = _gemm_prec(q, role)
     call = lambda: lib.call("adnm_skgemm", op, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _p(bias), pc, ldc, pdb,
-                            wsp, wsn, uc, M, N, K, prec, qp, _stream())
+                            wsp, wsn, ucp, ucn, M, N, K, prec, qp, _stream())
     if side:   # (a, b are kept with the workspace: under a bound leaf queue the launch itself waits for the grouped flush)
         SIDE.submit(a.device, (a, b), FOLDS.defer(a.device, ws, a, b) if defer else _NODEFER, call)
     else:

@@ -32,12 +32,13 @@ void adnm_launch_fold(const char* prof_name, const float* part, int rows, int n,
                       AdnmFoldSeg s3, hipStream_t st);
 
 // LDS-tiled NT / NN GEMM (lgemm.hip), reached through adnm_skgemm.  b_oc: second operand contiguous along the output axis (op NN);
-// nbs: cross-workgroup split of the reduction (combined inside the launch).  A split launch's workspace is the CALLER's:
-// [arrival counters: one int per output tile, zero when idle, rounded up to 256 B | the slabs]; ws_uncached: it is uncached device memory
-// (adnm_uncached_alloc), so a slab store is at the device-wide coherence point once it has completed and the ticket needs no fences.
+// nbs: cross-workgroup split of the reduction (combined inside the launch).  A split launch's workspaces are the CALLER's: ws = ordinary
+// device memory [arrival counters: one int per output tile, zero when idle, rounded up to 256 B | slabs]; slabs_uc: optional uncached
+// device memory (adnm_uncached_alloc) for the slabs alone — a slab store is then at the device-wide coherence point once it has
+// completed and the ticket needs no fences (ws only has to hold the counters).
 int64_t adnm_lgemm_ws_bytes(int64_t I, int64_t J, int64_t R, int nbs);
 int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, void* ws,
-                      int64_t ws_bytes, int ws_uncached, int64_t I, int64_t J, int64_t R, int nbs, int prec, float* q, hipStream_t st);
+                      int64_t ws_bytes, void* slabs_uc, int64_t slabs_uc_bytes, int64_t I, int64_t J, int64_t R, int nbs, int prec, float* q, hipStream_t st);
 static inline int64_t adnm_ticket_bytes(int64_t ntiles) { return (ntiles * 4 + 255) / 256 * 256; }
 
 // Deferred LEAF launches (core.hip, include/adnm_hip.h: adnm_leafq_*).  A weight-gradient kernel is a leaf of the backward pass: nothing reads

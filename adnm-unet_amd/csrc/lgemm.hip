@@ -381,7 +381,7 @@ int64_t adnm_lgemm_ws_bytes(int64_t I, int64_t J, int64_t R, int nbs) {
 }
 
 int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, void* ws,
-                      int64_t ws_bytes, int ws_uncached, int64_t I, int64_t J, int64_t R, int nbs, int prec, float* q, hipStream_t st) {
+                      int64_t ws_bytes, void* slabs_uc, int64_t slabs_uc_bytes, int64_t I, int64_t J, int64_t R, int nbs, int prec, float* q, hipStream_t st) {
   const LgPlan pl = make_plan(I, J, R, nbs);
   LgArgs p;
   p.A = a, p.lda = lda, p.B = b, p.ldb = ldb, p.bias = bias, p.C = c, p.ldc = ldc;
@@ -390,15 +390,19 @@ int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, in
   p.slab = nullptr, p.tickets = nullptr, p.uc = 0;
   p.q = reinterpret_cast<AdnmQuant*>(q);
   if (pl.nbs > 1) {
-    if (!ws || ws_bytes < adnm_lgemm_ws_bytes(I, J, R, nbs)) {
-      adnm_set_error("skgemm: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_lgemm_ws_bytes(I, J, R, nbs));
+    // arrival counters (zero when idle) at the head of ws, in ordinary memory; the slabs behind them (fenced protocol) or in the caller's
+    // uncached space (no fences around the ticket)
+    const int64_t slab_bytes = (int64_t)pl.ntiles * pl.nbs * kTile * kTile * (int64_t)sizeof(float);
+    const bool uc = slabs_uc && slabs_uc_bytes >= slab_bytes;
+    const int64_t need = uc ? adnm_ticket_bytes(pl.ntiles) : adnm_lgemm_ws_bytes(I, J, R, nbs);
+    if (!ws || ws_bytes < need) {
+      adnm_set_error("skgemm: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
       return ADNM_EWORKSPACE;
     }
-    // the caller's workspace = [arrival counters, zero when idle | slabs]; in uncached memory the ticket needs no fences
-    ADNM_REQUIRE(((uintptr_t)ws & 255) == 0, "skgemm: a split launch needs a 256-byte aligned workspace");
+    ADNM_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)slabs_uc & 255) == 0, "skgemm: a split launch needs 256-byte aligned workspaces");
     p.tickets = (int*)ws;
-    p.slab = (float*)((char*)ws + adnm_ticket_bytes(pl.ntiles));
-    p.uc = ws_uncached ? 1 : 0;
+    p.slab = uc ? (float*)slabs_uc : (float*)((char*)ws + adnm_ticket_bytes(pl.ntiles));
+    p.uc = uc ? 1 : 0;
   }
   const unsigned grid = (unsigned)(pl.ntiles * pl.nbs);
 #define LG(OC)                                                                                                                    \

@@ -577,8 +577,28 @@ extern "C" int64_t adnm_skgemm_ws_bytes(int op, int64_t M, int64_t N, int64_t K)
   return a > b ? a : b;
 }
 
+// the counter part of a split NT / NN launch's workspace (what ws must hold when the slabs go to uncached space); 0: never split
+extern "C" int64_t adnm_skgemm_counter_bytes(int op, int64_t M, int64_t N, int64_t K) {
+  if (!shape_ok(op, M, N, K)) return -1;
+  if (op == ADNM_SKGEMM_TN) return 0;
+  int64_t I, J, R, need = 0;
+  dims(op, M, N, K, &I, &J, &R);
+  for (int bf = 0; bf < 2; ++bf) {
+    const Plan pl = make_plan(op, I, J, R, false, bf != 0);
+    if (pl.kernel < 0) continue;
+    int64_t ntiles = pl.ntiles, nbs = pl.nbs;
+    if (pl.kernel == KERNEL_LDS) {
+      ntiles = adnm_cdiv(I, 64) * adnm_cdiv(J, 64);
+      nbs = adnm_lgemm_ws_bytes(I, J, R, pl.nbs) > 16 ? 2 : 1;
+    }
+    if (nbs > 1 && adnm_ticket_bytes(ntiles) > need) need = adnm_ticket_bytes(ntiles);
+  }
+  return need;
+}
+
 extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, float* dbias,
-                           void* ws, int64_t ws_bytes, int ws_uncached, int64_t M, int64_t N, int64_t K, int prec, float* q, adnm_stream_t stream) {
+                           void* ws, int64_t ws_bytes, void* slabs_uc, int64_t slabs_uc_bytes, int64_t M, int64_t N, int64_t K, int prec, float* q,
+                           adnm_stream_t stream) {
   ADNM_REQUIRE(prec >= ADNM_MFMA_F32 && prec <= ADNM_MFMA_FP8_GRAD, "skgemm: bad prec %d", prec);
   const bool fp8 = prec == ADNM_MFMA_FP8 || prec == ADNM_MFMA_FP8_GRAD;
   ADNM_REQUIRE(!fp8 || q, "skgemm: the fp8 modes need a quantisation record");
@@ -603,14 +623,18 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   const double algo_bytes = 4.0 * ((double)M * (K + N) + (double)N * K);
   if (pl.kernel == KERNEL_LDS) {
     ADNM_PROF(scope, st, algo_bytes);
-    const int rc = adnm_lgemm_launch(op == ADNM_SKGEMM_NN, a, lda, b, ldb, bias, c, ldc, ws, ws_bytes, ws_uncached, I, J, R, pl.nbs, prec, q, st);
+    const int rc = adnm_lgemm_launch(op == ADNM_SKGEMM_NN, a, lda, b, ldb, bias, c, ldc, ws, ws_bytes, slabs_uc, slabs_uc_bytes, I, J, R, pl.nbs, prec, q, st);
     if (rc != ADNM_OK) return rc;
     ADNM_CHECK_LAUNCH("skgemm");
     return ADNM_OK;
   }
   const bool split = pl.nbs > 1;
-  if (split && (!ws || ws_bytes < ws_need(pl, I, J, R))) {
-    adnm_set_error("skgemm: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)ws_need(pl, I, J, R));
+  // split NT / NN: ws = [arrival counters | slabs], or just the counters when the caller also hands over uncached slab space
+  const int64_t slab_bytes = split ? (int64_t)pl.nbs * (I * J + (dbias ? I : 0)) * (int64_t)sizeof(float) : 0;
+  const bool uc = split && pl.combine && slabs_uc && slabs_uc_bytes >= slab_bytes;
+  const int64_t need = !split ? 0 : (uc ? adnm_ticket_bytes(pl.ntiles) : ws_need(pl, I, J, R));
+  if (split && (!ws || ws_bytes < need)) {
+    adnm_set_error("skgemm: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
     return ADNM_EWORKSPACE;
   }
   SkArgs p;
@@ -630,11 +654,12 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   p.tickets = nullptr, p.out = c, p.ldo = ldc, p.uc = 0;
   p.q = reinterpret_cast<AdnmQuant*>(q);
   if (pl.combine) {
-    // the caller's workspace = [arrival counters, zero when idle | slabs]; in uncached memory the ticket needs no fences
-    ADNM_REQUIRE(((uintptr_t)ws & 255) == 0, "skgemm: a split launch needs a 256-byte aligned workspace");
+    // arrival counters (zero when idle) at the head of ws, in ordinary memory (agent-scope atomics); the slabs behind them (fenced
+    // protocol) or in the caller's uncached space (a completed store is at the coherence point: no fences around the ticket)
+    ADNM_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)slabs_uc & 255) == 0, "skgemm: a split launch needs 256-byte aligned workspaces");
     p.tickets = (int*)ws;
-    p.C = (float*)((char*)ws + adnm_ticket_bytes(pl.ntiles));
-    p.uc = ws_uncached ? 1 : 0;
+    p.C = uc ? (float*)slabs_uc : (float*)((char*)ws + adnm_ticket_bytes(pl.ntiles));
+    p.uc = uc ? 1 : 0;
   }
   const unsigned grid = (unsigned)adnm_cdiv((int64_t)pl.ntiles * pl.nbs, kWaves / pl.wpt);
   bool queued = false;

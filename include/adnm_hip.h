@@ -367,22 +367,26 @@ int adnm_colsum(const float* x, float* out, int64_t rows, int64_t n, void* ws, i
  * TN (the weight gradient) runs on bf16 operands in the fp8 modes.
  * Workspace (adnm_skgemm_ws_bytes; 16 = the shape is not split): a reduction that would leave CUs idle is split over workgroups.
  *   TN: ws holds fp32 partials for the shared fold — ordinary device memory.
- *   NT / NN: the slabs are combined INSIDE the launch: ws = [arrival counters: one int per output tile, rounded up to 256 B | slabs],
- *     256-byte aligned.  The counters must be ZERO when the launch starts and are zero again when it ends, so one workspace serves
- *     every launch of a stream (launches on a stream are ordered); it must not be shared by launches that can run concurrently
- *     (another stream, another captured graph replayed beside this one).  ws_uncached != 0: the workspace is uncached device memory
- *     (adnm_uncached_alloc): a completed slab store is then at the device-wide coherence point and the arrival ticket needs no
- *     agent-scope release / acquire (= no per-workgroup write-back / invalidate of an XCD's L2); ws_uncached == 0: any device memory,
- *     fenced protocol.  Both give bitwise identical results (slabs are added in slice order).
+ *   NT / NN: the slabs are combined INSIDE the launch (arrival counters; the last workgroup of a tile adds the slabs in slice order:
+ *     bitwise reproducible).  ws = [arrival counters: one int per output tile, rounded up to 256 B | slabs], 256-byte aligned ordinary
+ *     device memory; the counters must be ZERO when the launch starts and are zero again when it ends, so one workspace serves every
+ *     launch of a stream (launches on a stream are ordered) but must not be shared by launches that can run concurrently (another
+ *     stream, another captured graph replayed beside this one).  slabs_uc (optional, NULL = none): uncached device memory
+ *     (adnm_uncached_alloc) of at least the slab part; the slabs then live there — a completed slab store is at the device-wide
+ *     coherence point, so the arrival ticket needs no agent-scope release / acquire (= no per-workgroup write-back / invalidate of an
+ *     XCD's L2) — and ws only has to hold the counters (adnm_skgemm_counter_bytes).  Same sharing rule.  Both protocols give bitwise
+ *     identical results.
  * adnm_uncached_alloc: `bytes` of zero-filled uncached device memory on the current device (hipExtMallocWithFlags +
  * hipDeviceMallocUncached), NULL on failure; a host-side setup call (it synchronises; not under stream capture). */
 #define ADNM_SKGEMM_NT 0
 #define ADNM_SKGEMM_NN 1
 #define ADNM_SKGEMM_TN 2
 int adnm_skgemm_supported(int op, int64_t M, int64_t N, int64_t K);
-int64_t adnm_skgemm_ws_bytes(int op, int64_t M, int64_t N, int64_t K);
+int64_t adnm_skgemm_ws_bytes(int op, int64_t M, int64_t N, int64_t K);   /* counters + slabs (NT / NN), partials (TN) */
 int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, float* dbias,
-                void* ws, int64_t ws_bytes, int ws_uncached, int64_t M, int64_t N, int64_t K, int prec, float* q, adnm_stream_t stream);
+                void* ws, int64_t ws_bytes, void* slabs_uc, int64_t slabs_uc_bytes, int64_t M, int64_t N, int64_t K, int prec, float* q,
+                adnm_stream_t stream);
+int64_t adnm_skgemm_counter_bytes(int op, int64_t M, int64_t N, int64_t K);
 void* adnm_uncached_alloc(int64_t bytes);
 int adnm_uncached_free(void* ptr);
 
