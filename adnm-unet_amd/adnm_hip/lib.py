@@ -16,7 +16,7 @@ _CT = {
     "const void*": ctypes.c_void_p, "void*": ctypes.c_void_p, "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p,
     "int64_t": ctypes.c_int64, "int": ctypes.c_int, "float": ctypes.c_float, "adnm_stream_t": ctypes.c_void_p,
     "const char*": ctypes.c_char_p, "char*": ctypes.c_char_p, "void": None,
-    "float* const*": ctypes.c_void_p, "const float* const*": ctypes.c_void_p, "const int64_t*": ctypes.c_void_p,
+    "float* const*": ctypes.c_void_p, "const float* const*": ctypes.c_void_p, "const int64_t*": ctypes.c_void_p, "const int*": ctypes.c_void_p,
 }
 
 

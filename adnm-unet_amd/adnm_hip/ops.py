@@ -101,6 +101,29 @@ class QuantTable:
         return torch.tensor([scale_a, scale_b, 0.0, 0.0, 57344.0 if grad_a else 448.0, 448.0, 1.0 if record else 0.0, 0.0], dtype=torch.float32,
                             device=device)
 
+    def weight_row(self, device, key):
+        """-> row of the record of WEIGHT `key` (a parameter's data_ptr) in this device's table: the b-slots hold the scale its fp8 shadow is
+        written with (adnm_adamw_step) and the max |w| the optimiser pass collects for the next one; the a-slots are unused."""
+        with self._lock:
+            ent = self._ent(device)
+            row = ent["keys"].get((key, "w"))
+            if row is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("adnm_hip fp8: weight records are created before capture (FlatTrainer.prepare)")
+                row = len(ent["keys"])
+                if row >= self.CAP:
+                    raise RuntimeError(f"adnm_hip fp8: more than {self.CAP} records")
+                ent["keys"][(key, "w")] = row
+                ent["tab"][row] = torch.tensor([1.0, 1.0, 0.0, 0.0, 0.0, 448.0, 1.0, 0.0])
+            return row
+
+    def table_ptr(self, device):
+        return self._ent(device)["tab"].data_ptr()
+
+    def scale_b_view(self, device, row):
+        """1-element view of a record's scale_b (what the fp8 shadow of a weight was / will be multiplied by)"""
+        return self._ent(device)["tab"][row, 1:2]
+
     ROLES = {"linear_fwd": "fnt", "linear_dgrad": "gnn", "conv3_fwd": "fc3", "conv3_dgrad": "gc3", "convt_fwd": "fnn", "convt_dgrad": "gnt"}
 
     def set(self, device, key, site, scale_a, scale_b, record=False):
@@ -649,8 +672,57 @@ class _ScopeActive:
         return False
 
 
+class ShadowRegistry:
+    """Narrow SHADOW copies of the GEMM weights (include/adnm_hip.h: adnm_adamw_step `shadow`, adnm_skgemm `b_dtype`).  A FlatTrainer keeps,
+    beside its flat fp32 parameter buffer, one buffer of the same element layout in bf16 (bf16 configuration) or per-tensor scaled OCP
+    e4m3 (fp8 configuration), rewritten by the optimiser pass that updates the parameters.  The weight-streaming GEMMs (k_linear /
+    k_linear_dx on the short-GEMM kernels) look their weight up here and read the shadow instead of the fp32 values: half / a quarter of
+    the bytes of the two passes that stream the 72 M parameters every step, bit for bit the result of rounding the fp32 operand the
+    same way.  Outside a trainer (plain autograd use) nothing is registered and the kernels convert the fp32 weight on the fly."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._own = {}   # owner id -> entry
+
+    def register(self, owner, flat_p, shadow, b_dtype, seg_start, seg_row):
+        """seg_start: sorted element offsets of the tensors inside flat_p; seg_row[k]: QUANT row of tensor k's weight record (fp8) or -1"""
+        with self._lock:
+            self._own[owner] = {"lo": flat_p.data_ptr(), "hi": flat_p.data_ptr() + 4 * flat_p.numel(), "shadow": shadow, "dt": b_dtype,
+                                "starts": list(seg_start), "rows": list(seg_row), "dev": flat_p.device, "valid": False}
+
+    def set_valid(self, owner, ok=True):
+        with self._lock:
+            if owner in self._own:
+                self._own[owner]["valid"] = ok
+
+    def drop(self, owner):
+        self._own.pop(owner, None)   # (atomic: callable from a finaliser)
+
+    def lookup(self, w, prec):
+        """-> (shadow pointer of w, b_dtype, scale tensor or None) when the weight tensor `w` lies in a registered flat buffer whose shadow
+        matches the matrix-core precision `prec` of the call (1: bf16 shadow; 2 / 3: fp8 shadow and a weight record), else None."""
+        if not self._own or prec == 0 or QUANT.calibrating:
+            return None
+        ptr = w.data_ptr()
+        for ent in list(self._own.values()):
+            if ent["lo"] <= ptr < ent["hi"] and ent["valid"]:
+                if (ent["dt"] == 1) != (prec == 1):
+                    return None
+                off = (ptr - ent["lo"]) // 4
+                if ent["dt"] == 1:
+                    return ent["shadow"].data_ptr() + 2 * off, 1, None
+                import bisect
+                k = bisect.bisect_right(ent["starts"], off) - 1
+                row = ent["rows"][k]
+                if row < 0:
+                    return None
+                return ent["shadow"].data_ptr() + off, 2, QUANT.scale_b_view(ent["dev"], row)
+        return None
+
+
 FOLDS = FoldRegistry()
 SPLITWS = SplitWorkspaces()
+SHADOWS = ShadowRegistry()
 GRADS = GradRegistry()
 SIDE = SideStreams()
 grad_dst = GRADS.take
@@ -1248,7 +1320,12 @@ class ADNMixerFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk=0, scan_groups=2, qkeys=(None, None)):
+    def forward(ctx, u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk=0, scan_groups=2, qkeys=(None, None),
+                narrow=(None, None, None, None)):
+        """narrow = (w_in_n, s_in, w_out_n, s_out): the prep's narrow copies of the two projections (AdnPrepMultiFn); w_in / w_out are then
+        storage-less handles"""
+        n_in = (narrow[0].data_ptr(), 1 if narrow[0].dtype == torch.bfloat16 else 2, narrow[1]) if narrow[0] is not None else None
+        n_out = (narrow[2].data_ptr(), 1 if narrow[2].dtype == torch.bfloat16 else 2, narrow[3]) if narrow[2] is not None else None
         Bsz, L, dm = u.shape
         M = Bsz * L
         di = w_out.shape[1] // 2
@@ -1259,7 +1336,7 @@ class ADNMixerFn(torch.autograd.Function):
         # storage type of the node's wide internal tensors (proj, wide, y and their gradients): bf16 at the full-resolution level in the
         # bf16 configuration (low_storage), fp32 otherwise; u, the result and every parameter gradient stay fp32
         st = low_storage(M, [(w_in.shape[0], dm), (dm, 2 * di), (2 * di, dm), (dm, w_in.shape[0])]) if scan_chunk == 0 else u.dtype
-        proj = k_linear(u2, w_in, None, qkey=qkeys[0], out_dtype=st)  # (M, 2di+2gN+nh) = [z | xBC | dt]
+        proj = k_linear(u2, w_in, None, qkey=qkeys[0], out_dtype=st, narrow=n_in)  # (M, 2di+2gN+nh) = [z | xBC | dt]
         # one wide buffer [LN(y) | silu(conv_z(z)) | silu(conv(xBC))]: its first 2di columns are out_proj's input, the rest K1's operands;
         # z and xBC are adjacent in `proj` and their conv outputs adjacent here, so ONE depthwise launch (taps = [czw | cw]) does both
         wide = torch.empty((M, 2 * di + cx), dtype=st, device=u.device)
@@ -1282,10 +1359,11 @@ class ADNMixerFn(torch.autograd.Function):
             mu = None
         if mu is None:
             _, mu, rstd = k_rownorm_fwd(y, ln_w, ln_b, None, None, 1e-5, True, out=cat[:, :di])
-        out = k_linear(cat, w_out, None, qkey=qkeys[1], out_dtype=u.dtype)
+        out = k_linear(cat, w_out, None, qkey=qkeys[1], out_dtype=u.dtype, narrow=n_out)
         ctx.save_for_backward(u2, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, proj, wide, y, kv, mu, rstd)
         ctx.dims = (Bsz, L, dm, H, W, P, N, di, cx, nh, scan_chunk, scan_groups)
         ctx.qkeys = qkeys
+        ctx.narrow = (n_in, n_out, narrow)   # (the tuples hold raw pointers: `narrow` keeps the tensors alive)
         return out.view(Bsz, L, dm)
 
     @staticmethod
@@ -1301,7 +1379,7 @@ class ADNMixerFn(torch.autograd.Function):
         # merged depthwise backward reads [d zc | d xbc] as one column range
         dwide = torch.empty_like(wide)
         dcat, dxbc = dwide[:, :2 * di], dwide[:, 2 * di:]
-        k_linear_dx(do, w_out, out=dcat, qkey=ctx.qkeys[1])
+        k_linear_dx(do, w_out, out=dcat, qkey=ctx.qkeys[1], narrow=ctx.narrow[1])
         dy, dln_w, dln_b, _, _ = k_rownorm_bwd(dcat[:, :di], y, ln_w, ln_b, None, mu, rstd, True, True, False, defer=True)
         dproj = torch.empty_like(proj)
         if scan_chunk == 0:
@@ -1317,15 +1395,16 @@ class ADNMixerFn(torch.autograd.Function):
             ddtb, dA, dD = (torch.stack((parts[0][k], parts[1][k]), dim=1).reshape(nh) for k in range(3))
         _, dtaps, dtb = k_dwconv_bwd(dwide[:, di:], proj[:, :di + cx], taps, tb, Bsz, H, W, di + cx, 3, lib.ACT_SILU, dx=dproj[:, :di + cx],
                                      want_bias=tb is not None)
-        du = k_linear_dx(dproj, w_in, qkey=ctx.qkeys[0], out_dtype=u2.dtype)
+        du = k_linear_dx(dproj, w_in, qkey=ctx.qkeys[0], out_dtype=u2.dtype, narrow=ctx.narrow[0])
         dw_in, _ = k_linear_dw(dproj, u2, False)
-        return (du.view(Bsz, L, dm), dw_in, dtaps, dtb, ddtb, dA, dD, dln_w, dln_b, dw_out, None, None, None, None, None, None, None)
+        return (du.view(Bsz, L, dm), dw_in, dtaps, dtb, ddtb, dA, dD, dln_w, dln_b, dw_out, None, None, None, None, None, None, None, None)
 
 
-def adn_mixer(u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk=0, scan_groups=2, qkeys=(None, None)):
+def adn_mixer(u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk=0, scan_groups=2, qkeys=(None, None),
+              narrow=(None, None, None, None)):
     """qkeys: stable identities (data_ptr of in_proj.weight / out_proj.weight) of the two projections for the fp8 call-site records —
-    w_in / w_out themselves are per-step temporaries."""
-    return ADNMixerFn.apply(u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk, scan_groups, qkeys)
+    w_in / w_out themselves are per-step temporaries.  narrow: the prep's narrow copies (see ADNMixerFn.forward)."""
+    return ADNMixerFn.apply(u, w_in, taps, tb, dt_bias, A_log, D, ln_w, ln_b, w_out, H, W, P, N, scan_chunk, scan_groups, qkeys, narrow)
 
 
 class FeedForwardFn(torch.autograd.Function):
@@ -1625,9 +1704,22 @@ def wt_prep(C, Cp, K, levels, bias, weights, scales):
     return out[0], out[1], list(out[2:])
 
 
+def narrow_weight_mode():
+    """1 / 2: the big matrices the mixer prep emits are written as bf16 / scaled e4m3 copies only (the weight-streaming GEMMs read those:
+    adnm_skgemm b_dtype); 0: fp32 (exact mode, calibration passes, ADNM_NARROW_WEIGHTS=0)"""
+    if QUANT.calibrating or os.environ.get("ADNM_NARROW_WEIGHTS", "1") == "0":
+        return 0
+    return MFMA_PREC[0] if MFMA_PREC[0] in (1, 2) else 0
+
+
 class AdnPrepMultiFn(torch.autograd.Function):
     """AdnPrepFn for every mixer of a model stage in ONE launch each way (include/adnm_hip.h: adnm_adnprep_*_multi).
-    args: dims = [(dm, di, gn, P), ...], then 15 parameters per mixer; returns 5 tensors per mixer (w_in, taps, ln_w, ln_b, w_out)."""
+    args: dims = [(dm, di, gn, P), ...], then 15 parameters per mixer; returns 9 entries per mixer:
+    (w_in, taps, ln_w, ln_b, w_out, w_in_n, s_in, w_out_n, s_out).  In the narrow modes a matrix too large for the tall-skinny kernel
+    (N K > 8192: it goes through the weight-streaming short GEMMs) is written ONLY as its bf16 / scaled-e4m3 copy w_*_n (s_*: the fp8
+    scale, a 1-element tensor); the fp32 entry of that name is then a storage-less (N, K) handle that carries shape and autograd edge
+    (its gradient arrives as an ordinary fp32 matrix).  fp8 copies need the weight records of a FlatTrainer; without them (plain autograd
+    use) the fp32 matrices are written as before."""
 
     @staticmethod
     def forward(ctx, dims, *params):
@@ -1636,16 +1728,41 @@ class AdnPrepMultiFn(torch.autograd.Function):
         dev = params[0].device
         _need_gpu(params[0])
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-        outs, table, dflat = [], [], []
-        for dm, di, gn, P in dims:
+        mode = narrow_weight_mode()
+        ndt = {1: torch.bfloat16, 2: torch.uint8}.get(mode)
+        handle = lambda N, K: torch.empty(1, dtype=torch.float32, device=dev).expand(N, K)
+        outs, table, dflat, ntab, nondiff = [], [], [], [], []
+        any_narrow = False
+        for i, (dm, di, gn, P) in enumerate(dims):
             nh, cx = di // P, di + 2 * gn
-            w_in, taps, ln_w, ln_b, w_out = f(2 * di + 2 * gn + nh, dm), f(9, di + cx), f(di), f(di), f(dm, 2 * di)
-            outs += [w_in, taps, ln_w, ln_b, w_out]
-            table += [w_in, taps[:, di:], taps[:, :di], ln_w, ln_b, w_out]
+            n_in, n_out = 2 * di + 2 * gn + nh, dm
+            taps, ln_w, ln_b = f(9, di + cx), f(di), f(di)
+            w_in_p, w_out_p = params[15 * i], params[15 * i + 13]
+            s_in = s_out_src = None
+            ok = mode != 0
+            if mode == 2:   # the fp8 scales come from the weight records the optimiser pass maintains
+                a, b = SHADOWS.lookup(w_in_p, 2), SHADOWS.lookup(w_out_p, 2)
+                ok = a is not None and b is not None
+                if ok:
+                    s_in, s_out_src = a[2], b[2]
+            big_in, big_out = ok and n_in * dm > 8192, ok and n_out * 2 * di > 8192
+            w_in_n = torch.empty((n_in, dm), dtype=ndt, device=dev) if big_in else None
+            w_out_n = torch.empty((n_out, 2 * di), dtype=ndt, device=dev) if big_out else None
+            w_in = handle(n_in, dm) if big_in else f(n_in, dm)
+            w_out = handle(n_out, 2 * di) if big_out else f(n_out, 2 * di)
+            s_out = torch.empty(1, dtype=torch.float32, device=dev) if (big_out and mode == 2) else None
+            any_narrow = any_narrow or big_in or big_out
+            outs += [w_in, taps, ln_w, ln_b, w_out, w_in_n, s_in if big_in else None, w_out_n, s_out]
+            nondiff += [t for t in (w_in_n, w_out_n, s_out) if t is not None]
+            table += [None if big_in else w_in, taps[:, di:], taps[:, :di], ln_w, ln_b, None if big_out else w_out]
+            ntab += [w_in_n, w_out_n, s_in if big_in else None, s_out_src if big_out else None, s_out]
             dflat += [dm, di, gn, P, di + cx]
-        lib.call("adnm_adnprep_fwd_multi", n, lib.ptr_table(params), lib.ptr_table(table), lib.i64_table(dflat), _stream())
+        lib.call("adnm_adnprep_fwd_multi", n, lib.ptr_table(params), lib.ptr_table(table), lib.i64_table(dflat),
+                 lib.ptr_table(ntab) if any_narrow else None, mode if any_narrow else 0, _stream())
         ctx.save_for_backward(*params)
         ctx.dims = dims
+        ctx.mark_non_differentiable(*nondiff)
+        ctx.set_materialize_grads(False)
         return tuple(outs)
 
     @staticmethod
@@ -1655,16 +1772,19 @@ class AdnPrepMultiFn(torch.autograd.Function):
         n = len(dims)
         dev = params[0].device
         FOLDS.flush(dev)   # the incoming gradients are (deferred) fold results of the mixers' backward
-        g = [t.contiguous() for t in g]
-        gtab, dflat = [], []
+        gtab, dflat, keep = [], [], []
         for i, (dm, di, gn, P) in enumerate(dims):
-            g_w_in, g_taps, g_ln_w, g_ln_b, g_w_out = g[5 * i:5 * i + 5]
+            nh, cx = di // P, di + 2 * gn
+            shapes = [(2 * di + 2 * gn + nh, dm), (9, di + cx), (di,), (di,), (dm, 2 * di)]
+            gi = [t.contiguous() if t is not None else torch.zeros(shp, dtype=torch.float32, device=dev) for t, shp in zip(g[9 * i:9 * i + 5], shapes)]
+            keep += gi
+            g_w_in, g_taps, g_ln_w, g_ln_b, g_w_out = gi
             gtab += [g_w_in, g_taps[:, di:], g_taps[:, :di], g_ln_w, g_ln_b, g_w_out]
             dflat += [dm, di, gn, P, 2 * di + 2 * gn]
         dparams = [grad_dst(p.data_ptr(), p.shape, dev, p.dtype) for p in params]
         nb = lib.query("adnm_adnprep_bwd_multi_ws_bytes", n)
         ws = _ws(nb, dev)
-        with FOLDS.defer(dev, ws, *g):
+        with FOLDS.defer(dev, ws, *keep):
             lib.call("adnm_adnprep_bwd_multi", n, lib.ptr_table(params), lib.ptr_table(gtab), lib.ptr_table(dparams), lib.i64_table(dflat),
                      ws.data_ptr(), nb, _stream())
         return (None, *dparams)
@@ -1750,7 +1870,7 @@ def prep_group(*roots):
             params += p
         out = AdnPrepMultiFn.apply(dims, *params)
         for i, m in enumerate(adn):
-            m.__dict__["_adnm_prepped"] = out[5 * i:5 * i + 5]
+            m.__dict__["_adnm_prepped"] = out[9 * i:9 * i + 9]   # (w_in, taps, ln_w, ln_b, w_out, w_in_n, s_in, w_out_n, s_out)
     if wt:
         dims, ts = [], []
         for m in wt:
@@ -1847,7 +1967,9 @@ def _sk_operand(t, what):
     return t
 
 
-def _skgemm(op, a, b, bias, c, dbias, M, N, K, defer=False, side=False, q=None, role="f"):
+def _skgemm(op, a, b, bias, c, dbias, M, N, K, defer=False, side=False, q=None, role="f", narrow=None):
+    """narrow = (pointer, b_dtype, scale tensor | None): read the weight operand from its narrow shadow (ShadowRegistry / the mixer prep's
+    narrow copies) instead of the fp32 tensor b, which then only provides the shape and row stride"""
     if lib.query("adnm_skgemm_supported", op, M, N, K) != 1:
         raise RuntimeError(f"adnm_hip linear: no kernel takes op={('NT', 'NN', 'TN')[op]} M={M} N={N} K={K} "
                            "(every op needs N % 4 == 0 and K % 4 == 0)")
@@ -1880,7 +2002,16 @@ def _skgemm(op, a, b, bias, c, dbias, M, N, K, defer=False, side=False, q=None, 
         prec, qp = (1 if MFMA_PREC[0] == 2 or QUANT.calibrating else MFMA_PREC[0]), None
     else:
         prec, qp = _gemm_prec(q, role)
-    call = lambda: lib.call("adnm_skgemm", op, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _p(bias), pc, ldc, pdb,
+    bp, bdt, bsc = b.data_ptr(), 0, None
+    if narrow is None and op != SK_TN:
+        narrow = SHADOWS.lookup(b, prec)   # a parameter of a FlatTrainer: its bf16 / fp8 shadow, kept current by the optimiser pass
+    if narrow is not None and op != SK_TN:
+        if narrow[1] == 1 and prec == 1:
+            bp, bdt = narrow[0], 1
+        elif narrow[1] == 2 and prec in (2, 3):
+            bp, bdt, bsc = narrow[0], 2, narrow[2]
+    ldb = b.stride(0)
+    call = lambda: lib.call("adnm_skgemm", op, a.data_ptr(), a.stride(0), bp, ldb, bdt, _p(bsc), _p(bias), pc, ldc, pdb,
                             wsp, wsn, ucp, ucn, M, N, K, prec, qp, _stream())
     if side:   # (a, b are kept with the workspace: under a bound leaf queue the launch itself waits for the grouped flush)
         SIDE.submit(a.device, (a, b), FOLDS.defer(a.device, ws, a, b) if defer else _NODEFER, call)
@@ -1893,7 +2024,20 @@ def _out_view_ok(out):
     return out.stride(-1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0
 
 
-def k_linear(x2, w, bias, out=None, qkey=None, role="f", out_dtype=None):
+class _NarrowW:
+    """stand-in for a weight that exists only as a narrow copy (the mixer prep's bf16 / fp8 matrices): shape, row stride, device"""
+
+    def __init__(self, narrow, N, K, device):
+        self.narrow, self.shape, self.device = narrow, (N, K), device
+
+    def data_ptr(self):
+        return self.narrow[0]
+
+    def stride(self, i):
+        return (self.shape[1], 1)[i]
+
+
+def k_linear(x2, w, bias, out=None, qkey=None, role="f", out_dtype=None, narrow=None):
     """Y = X W^T (+bias) for row views X (M,K) [stride (ld,1)], W (N,K) contiguous.
     qkey: stable identity of the weight for the fp8 call-site record (default: its data_ptr — right for parameters, wrong for
     per-step temporaries such as the mixer's prepared weights, whose callers pass the parameter's); role "f": X are activations,
@@ -1908,16 +2052,17 @@ def k_linear(x2, w, bias, out=None, qkey=None, role="f", out_dtype=None):
         lib.call("adnm_tsgemm_nt", x2.data_ptr(), x2.stride(0), w.data_ptr(), K, 1, _p(bias), y.data_ptr(), y.stride(0), M, N, K, prec, qp, _dt(x2),
                  _dt(y), _stream())
         return y
-    x2, w = _sk_operand(x2, "input"), _sk_operand(w, "weight")
+    x2 = _sk_operand(x2, "input")
+    w = _sk_operand(w, "weight") if narrow is None else _NarrowW(narrow, N, K, x2.device)
     y = out if out is not None and _out_view_ok(out) else torch.empty((M, N), dtype=x2.dtype, device=x2.device)
-    _skgemm(SK_NT, x2, w, bias, y, None, M, N, K, q=q, role=role)
+    _skgemm(SK_NT, x2, w, bias, y, None, M, N, K, q=q, role=role, narrow=narrow)
     if out is not None and y is not out:
         out.copy_(y)
         return out
     return y
 
 
-def k_linear_dx(dy2, w, out=None, qkey=None, role="g", out_dtype=None):
+def k_linear_dx(dy2, w, out=None, qkey=None, role="g", out_dtype=None, narrow=None):
     """dX = dY W for dY (M,N) row view, W (N,K) contiguous.  (qkey / role: see k_linear; the transposed conv's FORWARD is this product
     with activations as the first operand, role "f".)"""
     M, N = dy2.shape
@@ -1929,9 +2074,10 @@ def k_linear_dx(dy2, w, out=None, qkey=None, role="g", out_dtype=None):
         lib.call("adnm_tsgemm_nt", dy2.data_ptr(), dy2.stride(0), w.data_ptr(), 1, K, None, dx.data_ptr(), dx.stride(0), M, K, N, prec, qp, _dt(dy2),
                  _dt(dx), _stream())
         return dx
-    dy2, w = _sk_operand(dy2, "output gradient"), _sk_operand(w, "weight")
+    dy2 = _sk_operand(dy2, "output gradient")
+    w = _sk_operand(w, "weight") if narrow is None else _NarrowW(narrow, N, K, dy2.device)
     dx = out if out is not None and _out_view_ok(out) else torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
-    _skgemm(SK_NN, dy2, w, None, dx, None, M, N, K, q=q, role=role)
+    _skgemm(SK_NN, dy2, w, None, dx, None, M, N, K, q=q, role=role, narrow=narrow)
     if out is not None and dx is not out:
         out.copy_(dx)
         return out

@@ -180,6 +180,7 @@ class FlatTrainer:
             self.g_views.append(shaped(self.flat_g, o, p))
             p.grad = None
         self.used, self.n = used, total
+        self.offs = offs
         # gradient buckets in the order they become ready (= the order they are all-reduced); an empty stage has an empty bucket
         # (lo == hi), which _reduce_begin skips
         self.buckets = buckets
@@ -194,6 +195,38 @@ class FlatTrainer:
         ops.GRADS.register(id(self), {p.data_ptr(): gv for p, gv in zip(used, self.g_views)})
         if self.fused:
             self.ws = torch.empty(int(lib.query("adnm_adamw_ws_bytes")), dtype=torch.uint8, device=dev)
+
+    def _setup_shadows(self, mode):
+        """The narrow SHADOW of the flat parameter buffer (ops.ShadowRegistry; include/adnm_hip.h: adnm_adamw_step): mode 1 = bf16, 2 = per-tensor
+        scaled e4m3 (weight records in ops.QUANT's table, one per matrix-shaped parameter), rewritten by every optimiser pass.  The
+        weight-streaming GEMMs read it instead of the fp32 values.  mode 0 (exact fp32, CPU, ADNM_NARROW_WEIGHTS=0): none."""
+        self.shadow, self.shadow_mode = None, 0
+        import os
+        if mode == 0 or not self.fused or not self.flat_p.is_cuda or os.environ.get("ADNM_NARROW_WEIGHTS", "1") == "0":
+            return
+        dev = self.flat_p.device
+        self.shadow_mode = mode
+        self.shadow = torch.zeros(self.n, dtype=torch.bfloat16 if mode == 1 else torch.uint8, device=dev)
+        rows = []
+        for p in self.used:   # fp8: a record per GEMM-shaped weight (every other tensor: no scale, its shadow bytes are never read)
+            rows.append(ops.QUANT.weight_row(dev, p.data_ptr()) if (mode == 2 and p.dim() >= 2 and p.numel() >= 1024) else -1)
+        ends = [o // 4 for o in self.offs[1:]] + [self.n // 4]
+        self.seg_end = torch.tensor(ends, dtype=torch.int32, device=dev)
+        self.seg_rec = torch.tensor(rows, dtype=torch.int32, device=dev)
+        ops.SHADOWS.register(id(self), self.flat_p, self.shadow, mode, self.offs, rows)
+
+    def refresh_shadows(self, collect_only=False):
+        """rewrite the shadow from the parameters as they are (after they moved into the flat buffer; after a checkpoint was loaded into a
+        prepared trainer).  collect_only (fp8): only gather max |w| per weight record — the first calibration."""
+        if not getattr(self, "shadow_mode", 0):
+            return
+        dev = self.flat_p.device
+        tab = ops.QUANT.table_ptr(dev) if self.shadow_mode == 2 else None
+        lib.call("adnm_shadow_refresh", self.flat_p.data_ptr(), self.n, None if collect_only else self.shadow.data_ptr(), self.shadow_mode,
+                 self.seg_end.data_ptr(), self.seg_rec.data_ptr(), self.seg_end.numel(), tab, int(collect_only or self.shadow_mode == 2),
+                 torch.cuda.current_stream().cuda_stream)
+        if not collect_only:
+            ops.SHADOWS.set_valid(id(self), True)
 
     def close(self):
         """Give back everything this trainer owns on the device, in a fixed order, NOW (not whenever the cyclic collector gets to
@@ -216,6 +249,10 @@ class FlatTrainer:
                 ops.QUANT.unpin(self.flat_g.device)
             except Exception:
                 pass
+        try:
+            ops.SHADOWS.drop(id(self))
+        except Exception:
+            pass
         try:
             ops.GRADS.drop(id(self))   # lock-free for a finaliser: queued, drained by the next register / take
         except Exception:
@@ -341,14 +378,20 @@ class FlatTrainer:
             self._flatten()
             if self.fp8:
                 ops.QUANT.reset(x.device)
+                self._setup_shadows(2)                        # weight records (after the reset: it may forget the keys)
+                self.refresh_shadows(collect_only=True)      # max |w| of every GEMM weight
                 ops.QUANT.calibrating = True
                 for p in self.used:
                     p.grad = None
-                self._run_eager(x, tgt)
+                self._run_eager(x, tgt)                       # bf16 operands, fp32 weights: every call site's activation / gradient maxima
                 ops.QUANT.calibrating = False
-                ops.QUANT.update(x.device)
+                ops.QUANT.update(x.device)                    # -> the first scales, weights included
+                self.refresh_shadows()                        # the e4m3 shadow, written with them
                 for p in self.used:
                     p.grad = None
+            else:
+                self._setup_shadows(1 if (x.is_cuda and ops.mfma_precision() == "bf16") else 0)
+                self.refresh_shadows()
         finally:
             ops.QUANT.calibrating = False
             if self.fp8:
@@ -470,17 +513,22 @@ class FlatTrainer:
             for p in self.used:
                 p.grad = None
         self._reduce_end(pending)
-        self._optimizer_step()
         if getattr(self, "fp8", False):
-            ops.QUANT.update(self.flat_g.device)   # one launch: amax -> scales on calibration steps, the next step's record flags
+            # one launch: amax -> scales on calibration steps, the next step's record flags.  BEFORE the optimiser pass: that pass writes the
+            # e4m3 shadow of the updated weights with the scales the next step's GEMMs will read
+            ops.QUANT.update(self.flat_g.device)
+        self._optimizer_step()
         self._steps += 1
         return loss
 
     def _optimizer_step(self):
         if self.fused:
+            mode = getattr(self, "shadow_mode", 0)
+            sh = (self.shadow.data_ptr(), mode, self.seg_end.data_ptr(), self.seg_rec.data_ptr(), self.seg_end.numel(),
+                  ops.QUANT.table_ptr(self.flat_p.device) if mode == 2 else None) if mode else (None, 0, None, None, 0, None)
             lib.call("adnm_adamw_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                      self.exp_avg_sq.data_ptr(), self.n, self.state.data_ptr(), float(self.lr), float(self.betas[0]), float(self.betas[1]),
-                     float(self.eps), float(self.wd), float(self.max_norm), self.ws.data_ptr(), self.ws.numel(),
+                     float(self.eps), float(self.wd), float(self.max_norm), self.ws.data_ptr(), self.ws.numel(), *sh,
                      torch.cuda.current_stream().cuda_stream)
         else:
             self._torch_adamw_for_tests()

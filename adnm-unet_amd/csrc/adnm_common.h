@@ -37,8 +37,9 @@ void adnm_launch_fold(const char* prof_name, const float* part, int rows, int n,
 // device memory (adnm_uncached_alloc) for the slabs alone — a slab store is then at the device-wide coherence point once it has
 // completed and the ticket needs no fences (ws only has to hold the counters).
 int64_t adnm_lgemm_ws_bytes(int64_t I, int64_t J, int64_t R, int nbs);
-int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, void* ws,
-                      int64_t ws_bytes, void* slabs_uc, int64_t slabs_uc_bytes, int64_t I, int64_t J, int64_t R, int nbs, int prec, float* q, hipStream_t st);
+int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const void* b, int64_t ldb, int b_dtype, const float* b_scale, const float* bias, float* c,
+                      int64_t ldc, void* ws, int64_t ws_bytes, void* slabs_uc, int64_t slabs_uc_bytes, int64_t I, int64_t J, int64_t R, int nbs, int prec,
+                      float* q, hipStream_t st);
 static inline int64_t adnm_ticket_bytes(int64_t ntiles) { return (ntiles * 4 + 255) / 256 * 256; }
 
 // Deferred LEAF launches (core.hip, include/adnm_hip.h: adnm_leafq_*).  A weight-gradient kernel is a leaf of the backward pass: nothing reads
@@ -140,6 +141,25 @@ struct Io<uint16_t> {  // bf16 storage
   static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16(v); }
   static __device__ __forceinline__ float rt(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 };
+
+// ---- storage of a GEMM's WEIGHT operand (include/adnm_hip.h: b_dtype of adnm_skgemm): the fp32 master values, or the narrow shadow copy
+// the optimiser pass keeps beside them — bf16 (ADNM_MFMA_BF16) or per-tensor scaled OCP e4m3 (the fp8 modes).  4 consecutive elements at
+// element offset `off` -> floats: the loaders of the GEMM kernels are otherwise unchanged (same lane -> k map), only the bytes shrink.  The
+// decoded values round-trip exactly through the fragment builders (a bf16 / e4m3 value is a fixed point of its own rounding).
+template <int BT>
+__device__ __forceinline__ float4 adnm_ldb4(const void* base, int64_t off) {
+  if constexpr (BT == ADNM_B_BF16) {
+    const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + off);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+  } else if constexpr (BT == ADNM_B_FP8) {
+    using f2 = __attribute__((ext_vector_type(2))) float;
+    const int r = *reinterpret_cast<const int*>(reinterpret_cast<const uint8_t*>(base) + off);
+    const f2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(r, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(r, true);
+    return make_float4(lo[0], lo[1], hi[0], hi[1]);
+  } else {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+  }
+}
 
 // ---- MFMA precision ladder of the GEMM-shaped kernels (tsgemm, skgemm / lgemm, conv3) — all on gfx950's own instructions:
 //   ADNM_MFMA_F32  = v_mfma_f32_16x16x4_f32   (exact fp32: an fmaf chain; the bit-level parity path);

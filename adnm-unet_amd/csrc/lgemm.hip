@@ -42,8 +42,9 @@ struct Geo {
 struct LgArgs {
   const float* A;
   int64_t lda;          // A(i, r) = A[i*lda + r]
-  const float* B;
-  int64_t ldb;          // RC: B(r, j) = B[j*ldb + r];  OC: B(r, j) = B[r*ldb + j]
+  const void* B;        // fp32, or the weight's narrow shadow (BT: bf16 / scaled e4m3)
+  int64_t ldb;          // RC: B(r, j) = B[j*ldb + r];  OC: B(r, j) = B[r*ldb + j]   (element stride)
+  const float* b_scale; // fp8 shadow: the weight's scale (value = e4m3 / *b_scale); else NULL
   const float* bias;
   float* C;
   int64_t ldc;
@@ -64,8 +65,10 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));
 }
 
-template <bool B_OC, int PREC, bool A_BF8, int D>
+template <bool B_OC, int PREC, bool A_BF8, int D, int BT>
 __global__ __launch_bounds__(kThreads) void lgemm_kernel(LgArgs p) {
+  static_assert(BT == ADNM_B_F32 || (BT == ADNM_B_BF16 && PREC == ADNM_MFMA_BF16) || (BT == ADNM_B_FP8 && PREC == ADNM_MFMA_FP8),
+                "a narrow weight shadow feeds the matrix-core precision it was made for");
   constexpr bool BF16 = PREC == ADNM_MFMA_BF16;
   using G = Geo<BF16>;
   constexpr int kAW = G::rc_words, kBW = B_OC ? G::oc_words : G::rc_words;
@@ -93,17 +96,17 @@ __global__ __launch_bounds__(kThreads) void lgemm_kernel(LgArgs p) {
   const int q = tid & 7, lrow = tid >> 3;
   const int cq = tid & 15, lr = tid >> 4;
   const float* a_row[2];
-  const float* b_row[2];
+  int b_off[2];   // element offset of this lane's B row / column quad (the operand may be a 2- or 1-byte shadow: offsets, not pointers)
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int ia = i0 + lrow + 32 * u;
     a_row[u] = p.A + (int64_t)(ia < p.I ? ia : p.I - 1) * p.lda + 4 * q;
     if (!B_OC) {
       const int jb = j0 + lrow + 32 * u;
-      b_row[u] = p.B + (int64_t)(jb < p.J ? jb : p.J - 1) * p.ldb + 4 * q;
+      b_off[u] = (int)((int64_t)(jb < p.J ? jb : p.J - 1) * p.ldb + 4 * q);
     } else {
       const int jb = j0 + 4 * cq;
-      b_row[u] = p.B + (jb + 4 <= p.J ? jb : p.J - 4) + (int64_t)(BF16 ? 2 * lr + u : lr + 16 * u) * p.ldb;
+      b_off[u] = (int)((jb + 4 <= p.J ? jb : p.J - 4) + (int64_t)(BF16 ? 2 * lr + u : lr + 16 * u) * p.ldb);
     }
   }
   float4 ra[D][2], rb[D][2];
@@ -112,29 +115,31 @@ __global__ __launch_bounds__(kThreads) void lgemm_kernel(LgArgs p) {
     if (!B_OC) return kt < nkt && (kt0 + kt) * kStep + 4 * q < p.R;
     return kt < nkt && (kt0 + kt) * kStep + (BF16 ? 2 * lr + u : lr + 16 * u) < p.R;
   };
-  // element offsets from a lane's own row pointers back to the operand's first word (the "dead" address): selecting a 32-bit offset
+  // element offsets from a lane's own row pointer back to the operand's first word (the "dead" address): selecting a 32-bit offset
   // is one v_cndmask, selecting between two pointers makes the compiler branch around the address arithmetic
-  int a_dead[2], b_dead[2];
+  int a_dead[2];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) a_dead[u] = (int)(p.A - a_row[u]), b_dead[u] = (int)(p.B - b_row[u]);
+  for (int u = 0; u < 2; ++u) a_dead[u] = (int)(p.A - a_row[u]);
   auto load = [&](int kt, float4 (&av)[2], float4 (&bv)[2]) {
     const int r0 = (kt0 + kt) * kStep;
     const bool oka = a_ok(kt);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       av[u] = *reinterpret_cast<const float4*>(a_row[u] + (oka ? r0 : a_dead[u]));
-      bv[u] = *reinterpret_cast<const float4*>(b_row[u] + (b_ok(kt, u) ? (B_OC ? r0 * (int)p.ldb : r0) : b_dead[u]));
+      bv[u] = adnm_ldb4<BT>(p.B, b_ok(kt, u) ? b_off[u] + (B_OC ? r0 * (int)p.ldb : r0) : 0);
     }
   };
   // fp8: per-tensor scales from the call site's quantisation record (the accumulators are un-scaled in the epilogue); rec_a / rec_b
   // (workgroup-uniform): collect max |value| of the A rows / B columns this workgroup stages — the first tile column / tile row only
-  float q_sa = 1.f, q_sb = 1.f, amax_a = 0.f, amax_b = 0.f;
+  // (an fp8 SHADOW is already scaled and rounded: it passes through the fragment builder with scale 1; q_sbo divides the accumulators)
+  float q_sa = 1.f, q_sb = 1.f, q_sbo = 1.f, amax_a = 0.f, amax_b = 0.f;
   bool rec_a = false, rec_b = false;
   if (p.q) {
-    if (PREC == ADNM_MFMA_FP8) q_sa = p.q->scale_a, q_sb = p.q->scale_b;
+    if (PREC == ADNM_MFMA_FP8) q_sa = p.q->scale_a, q_sb = q_sbo = p.q->scale_b;
     const bool rec = p.q->record != 0.f;
-    rec_a = rec && (tile % p.tiles_j) == 0, rec_b = rec && (tile / p.tiles_j) == 0;
+    rec_a = rec && (tile % p.tiles_j) == 0, rec_b = BT == ADNM_B_F32 && rec && (tile / p.tiles_j) == 0;
   }
+  if (BT == ADNM_B_FP8) q_sb = 1.f, q_sbo = *p.b_scale;
   auto stage = [&](int kt, int buf, const float4 (&av)[2], const float4 (&bv)[2]) {
     uint32_t* const sa = ldsA + buf * kAW;
     uint32_t* const sb = ldsB + buf * kBW;
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void lgemm_kernel(LgArgs p) {
   if (rec_a) adnm_amax_commit(&p.q->amax_a, amax_a);
   if (rec_b) adnm_amax_commit(&p.q->amax_b, amax_b);
   if (PREC == ADNM_MFMA_FP8) {   // back to the operands' own scale, before bias / slabs
-    const float inv = 1.0f / (q_sa * q_sb);
+    const float inv = 1.0f / (q_sa * q_sbo);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -380,11 +385,13 @@ int64_t adnm_lgemm_ws_bytes(int64_t I, int64_t J, int64_t R, int nbs) {
   return pl.nbs > 1 ? adnm_ticket_bytes(pl.ntiles) + (int64_t)pl.ntiles * pl.nbs * kTile * kTile * (int64_t)sizeof(float) : 16;
 }
 
-int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, void* ws,
-                      int64_t ws_bytes, void* slabs_uc, int64_t slabs_uc_bytes, int64_t I, int64_t J, int64_t R, int nbs, int prec, float* q, hipStream_t st) {
+int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const void* b, int64_t ldb, int b_dtype, const float* b_scale, const float* bias, float* c,
+                      int64_t ldc, void* ws, int64_t ws_bytes, void* slabs_uc, int64_t slabs_uc_bytes, int64_t I, int64_t J, int64_t R, int nbs, int prec,
+                      float* q, hipStream_t st) {
   const LgPlan pl = make_plan(I, J, R, nbs);
   LgArgs p;
-  p.A = a, p.lda = lda, p.B = b, p.ldb = ldb, p.bias = bias, p.C = c, p.ldc = ldc;
+  p.A = a, p.lda = lda, p.B = b, p.ldb = ldb, p.b_scale = b_scale, p.bias = bias, p.C = c, p.ldc = ldc;
+  ADNM_REQUIRE(J * ldb < (1ll << 31) && R * ldb < (1ll << 31), "skgemm: weight beyond 2^31 elements (32-bit lane offsets)");
   p.I = (int)I, p.J = (int)J, p.R = (int)R;
   p.tiles_j = pl.tiles_j, p.nbs = pl.nbs, p.kt_per_slice = pl.kt_per_slice, p.nkt = pl.nkt;
   p.slab = nullptr, p.tickets = nullptr, p.uc = 0;
@@ -405,12 +412,15 @@ int adnm_lgemm_launch(bool b_oc, const float* a, int64_t lda, const float* b, in
     p.uc = uc ? 1 : 0;
   }
   const unsigned grid = (unsigned)(pl.ntiles * pl.nbs);
-#define LG(OC)                                                                                                                    \
-  do {                                                                                                                            \
-    if (prec == ADNM_MFMA_BF16) lgemm_kernel<OC, ADNM_MFMA_BF16, false, kRingDepth><<<grid, kThreads, 0, st>>>(p);                \
-    else if (prec == ADNM_MFMA_FP8) lgemm_kernel<OC, ADNM_MFMA_FP8, false, kRingDepth><<<grid, kThreads, 0, st>>>(p);             \
-    else if (prec == ADNM_MFMA_FP8_GRAD) lgemm_kernel<OC, ADNM_MFMA_FP8, true, kRingDepth><<<grid, kThreads, 0, st>>>(p);         \
-    else lgemm_kernel<OC, ADNM_MFMA_F32, false, kRingDepth><<<grid, kThreads, 0, st>>>(p);                                        \
+#define LG(OC)                                                                                                                             \
+  do {                                                                                                                                     \
+    if (b_dtype == ADNM_B_BF16) lgemm_kernel<OC, ADNM_MFMA_BF16, false, kRingDepth, ADNM_B_BF16><<<grid, kThreads, 0, st>>>(p);             \
+    else if (b_dtype == ADNM_B_FP8 && prec == ADNM_MFMA_FP8) lgemm_kernel<OC, ADNM_MFMA_FP8, false, kRingDepth, ADNM_B_FP8><<<grid, kThreads, 0, st>>>(p); \
+    else if (b_dtype == ADNM_B_FP8) lgemm_kernel<OC, ADNM_MFMA_FP8, true, kRingDepth, ADNM_B_FP8><<<grid, kThreads, 0, st>>>(p);            \
+    else if (prec == ADNM_MFMA_BF16) lgemm_kernel<OC, ADNM_MFMA_BF16, false, kRingDepth, ADNM_B_F32><<<grid, kThreads, 0, st>>>(p);         \
+    else if (prec == ADNM_MFMA_FP8) lgemm_kernel<OC, ADNM_MFMA_FP8, false, kRingDepth, ADNM_B_F32><<<grid, kThreads, 0, st>>>(p);           \
+    else if (prec == ADNM_MFMA_FP8_GRAD) lgemm_kernel<OC, ADNM_MFMA_FP8, true, kRingDepth, ADNM_B_F32><<<grid, kThreads, 0, st>>>(p);       \
+    else lgemm_kernel<OC, ADNM_MFMA_F32, false, kRingDepth, ADNM_B_F32><<<grid, kThreads, 0, st>>>(p);                                      \
   } while (0)
   if (!b_oc) LG(false);
   else LG(true);

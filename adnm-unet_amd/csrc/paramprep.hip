@@ -54,7 +54,25 @@ struct AdnParams {      // reference-layout parameters (or their gradients)
 };
 struct AdnPrepped {     // kernel-layout tensors (or their gradients)
   float *w_in, *cw, *czw, *ln_w, *ln_b, *w_out;
+  // forward only: NARROW copies of the two big matrices for the weight-streaming GEMMs (adnm_skgemm b_dtype) instead of the fp32 ones
+  // (ndt = ADNM_B_BF16 / ADNM_B_FP8; NULL = keep fp32).  fp8: w_in_n = e4m3(w_in * *s_in); w_out carries alpha1, so its effective scale
+  // *s_out / |alpha1| is published at s_out_eff for the GEMMs that read w_out_n.
+  void *w_in_n, *w_out_n;
+  const float *s_in, *s_out;
+  float* s_out_eff;
+  int ndt;
 };
+__device__ __forceinline__ void adn_store_narrow(void* dst, int64_t off, int ndt, float4 v, float scale) {
+  if (ndt == ADNM_B_BF16) {
+    Io<uint16_t>::st4(reinterpret_cast<uint16_t*>(dst) + off, v);
+  } else {
+    const float c0 = __builtin_amdgcn_fmed3f(v.x * scale, 448.f, -448.f), c1 = __builtin_amdgcn_fmed3f(v.y * scale, 448.f, -448.f);
+    const float c2 = __builtin_amdgcn_fmed3f(v.z * scale, 448.f, -448.f), c3 = __builtin_amdgcn_fmed3f(v.w * scale, 448.f, -448.f);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c0, c1, w, false), w = __builtin_amdgcn_cvt_pk_fp8_f32(c2, c3, w, true);
+    *reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(dst) + off) = w;
+  }
+}
 
 // chain of reference xBC channel `co` (odd): which (c31,c13) pair and which row
 template <typename D>
@@ -76,12 +94,22 @@ __device__ __forceinline__ void adn_prep_fwd_body(const P& p, const O& o, const 
   const int cx = d.di + 2 * d.gn, dinp = 2 * d.di + 2 * d.gn + d.nh, dm4 = d.dm >> 2, oq = d.di >> 1;   // oq: quads per out_proj row (2 di / 4)
   const int64_t n0 = (int64_t)dinp * dm4, n1 = n0 + 9 * cx, n2 = n1 + 9 * d.di, n3 = n2 + 2 * d.di, n4 = n3 + (int64_t)d.dm * oq;
   const float a1 = *p.alpha1;
+  float sc_in = 1.f, sc_out = 1.f;
+  if (o.ndt == ADNM_B_FP8) {
+    if (o.w_in_n) sc_in = *o.s_in;
+    if (o.w_out_n) {
+      sc_out = *o.s_out / fmaxf(fabsf(a1), 1e-30f);
+      if (bid == 0 && threadIdx.x == 0) *o.s_out_eff = sc_out;
+    }
+  }
   for (int64_t i = (int64_t)bid * kBlock + threadIdx.x; i < n4; i += (int64_t)nblk * kBlock) {
     if (i < n0) {
       const int r = (int)(i / dm4), c = (int)(i - (int64_t)r * dm4) * 4;
       int src = r;
       if (r >= d.di && r < d.di + cx) src = d.di + adn_fwd_map(r - d.di, d);
-      *reinterpret_cast<float4*>(o.w_in + (int64_t)r * d.dm + c) = *reinterpret_cast<const float4*>(p.w_in + (int64_t)src * d.dm + c);
+      const float4 v = *reinterpret_cast<const float4*>(p.w_in + (int64_t)src * d.dm + c);
+      if (o.w_in_n) adn_store_narrow(o.w_in_n, (int64_t)r * d.dm + c, o.ndt, v, sc_in);
+      else *reinterpret_cast<float4*>(o.w_in + (int64_t)r * d.dm + c) = v;
     } else if (i < n1) {
       const int j = (int)(i - n0), t = j / cx, ch = j - t * cx;
       const int co = adn_fwd_map(ch, d);
@@ -107,7 +135,9 @@ __device__ __forceinline__ void adn_prep_fwd_body(const P& p, const O& o, const 
       float4 v;
       if (k >= d.di) v = *reinterpret_cast<const float4*>(row + k);
       else v = make_float4(row[adn_fwd_map(k, d)], row[adn_fwd_map(k + 1, d)], row[adn_fwd_map(k + 2, d)], row[adn_fwd_map(k + 3, d)]);
-      *reinterpret_cast<float4*>(o.w_out + (int64_t)r * 2 * d.di + k) = make_float4(a1 * v.x, a1 * v.y, a1 * v.z, a1 * v.w);
+      const float4 av = make_float4(a1 * v.x, a1 * v.y, a1 * v.z, a1 * v.w);
+      if (o.w_out_n) adn_store_narrow(o.w_out_n, (int64_t)r * 2 * d.di + k, o.ndt, av, sc_out);
+      else *reinterpret_cast<float4*>(o.w_out + (int64_t)r * 2 * d.di + k) = av;
     }
   }
 }
@@ -350,6 +380,7 @@ static AdnParams adn_params(float* const* a) {
 static AdnPrepped adn_prepped(float* const* a) {
   AdnPrepped o;
   o.w_in = a[0]; o.cw = a[1]; o.czw = a[2]; o.ln_w = a[3]; o.ln_b = a[4]; o.w_out = a[5];
+  o.w_in_n = o.w_out_n = nullptr, o.s_in = o.s_out = nullptr, o.s_out_eff = nullptr, o.ndt = ADNM_B_F32;
   return o;
 }
 
@@ -467,8 +498,10 @@ unsigned multi_blocks(int64_t items) {
 }
 }  // namespace
 
-extern "C" int adnm_adnprep_fwd_multi(int64_t n, float* const* params, float* const* prepped, const int64_t* dims, adnm_stream_t stream) {
+extern "C" int adnm_adnprep_fwd_multi(int64_t n, float* const* params, float* const* prepped, const int64_t* dims, float* const* narrow,
+                                      int narrow_dtype, adnm_stream_t stream) {
   ADNM_REQUIRE(n >= 1 && params && prepped && dims, "adnprep_fwd_multi: bad arguments");
+  ADNM_REQUIRE(!narrow || narrow_dtype == ADNM_B_BF16 || narrow_dtype == ADNM_B_FP8, "adnprep_fwd_multi: narrow copies are bf16 (1) or scaled e4m3 (2)");
   hipStream_t st = (hipStream_t)stream;
   for (int64_t i0 = 0; i0 < n; i0 += kMaxMulti) {
     MultiAdnFwd m;
@@ -478,8 +511,14 @@ extern "C" int adnm_adnprep_fwd_multi(int64_t n, float* const* params, float* co
     for (int k = 0; k < m.count; ++k) {
       const int64_t i = i0 + k;
       for (int j = 0; j < 15; ++j) ADNM_REQUIRE(params[15 * i + j], "adnprep_fwd_multi: params[%lld][%d] is null", (long long)i, j);
-      for (int j = 0; j < 6; ++j) ADNM_REQUIRE(prepped[6 * i + j], "adnprep_fwd_multi: prepped[%lld][%d] is null", (long long)i, j);
       m.p[k] = adn_params(params + 15 * i), m.o[k] = adn_prepped(prepped + 6 * i), m.d[k] = adn_dims(dims + 5 * i);
+      if (narrow) {   // narrow[5 i ..] = {w_in_n, w_out_n, s_in, s_out, s_out_eff}: a narrow copy replaces the fp32 matrix of the same name
+        float* const* t = narrow + 5 * i;
+        m.o[k].w_in_n = t[0], m.o[k].w_out_n = t[1], m.o[k].s_in = t[2], m.o[k].s_out = t[3], m.o[k].s_out_eff = t[4], m.o[k].ndt = narrow_dtype;
+        ADNM_REQUIRE(narrow_dtype != ADNM_B_FP8 || ((!t[0] || t[2]) && (!t[1] || (t[3] && t[4]))), "adnprep_fwd_multi: an fp8 copy needs its scale pointers");
+      }
+      for (int j = 0; j < 6; ++j)
+        ADNM_REQUIRE(prepped[6 * i + j] || (j == 0 && m.o[k].w_in_n) || (j == 5 && m.o[k].w_out_n), "adnprep_fwd_multi: prepped[%lld][%d] is null", (long long)i, j);
       if (int rc = adn_check("adnprep_fwd_multi", m.d[k])) return rc;
       blocks += (int)multi_blocks(adn_items_fwd(m.d[k]));
       m.blk_end[k] = blocks;

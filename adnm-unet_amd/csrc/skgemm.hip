@@ -37,8 +37,9 @@ constexpr int kWaves = kBlock / 64;
 struct SkArgs {
   const float* A;
   int64_t sa_i, sa_r;   // A(i, r) = A[i*sa_i + r*sa_r]
-  const float* B;
-  int64_t sb_r, sb_j;   // B(r, j) = B[r*sb_r + j*sb_j]
+  const void* B;        // fp32, or the weight's narrow shadow (BT of skgemm_body: bf16 / scaled e4m3)
+  int64_t sb_r, sb_j;   // B(r, j) = B[r*sb_r + j*sb_j]   (element strides)
+  const float* b_scale; // fp8 shadow: the weight's scale (value = e4m3 / *b_scale); else NULL
   const float* bias;    // NT: added once, or NULL
   float* C;             // output; with nbs > 1 the slab base ([slice][I*J (+I)])
   int64_t ldc, slice_stride;
@@ -57,8 +58,10 @@ struct SkArgs {
 // PREC: ADNM_MFMA_* (the matrix-core precision); A_BF8: in the fp8 mode the A operand is a gradient (e5m2).
 // (bid, nblk): this workgroup's index and the workgroup count of ITS problem — the whole grid of the single-problem launch, a block range of
 // the grouped weight-gradient launch (skgemm_tn_multi_kernel).  Args: SkArgs, possibly in the constant address space.
-template <bool A_RC, bool B_RC, int PREC, bool A_BF8, int TM, int TN, int KC, typename Args>
+template <bool A_RC, bool B_RC, int PREC, bool A_BF8, int TM, int TN, int KC, int BT = ADNM_B_F32, typename Args>
 __device__ __forceinline__ void skgemm_body(const Args& p, const int bid, const int nblk) {
+  static_assert(BT == ADNM_B_F32 || (BT == ADNM_B_BF16 && PREC == ADNM_MFMA_BF16) || (BT == ADNM_B_FP8 && PREC == ADNM_MFMA_FP8),
+                "a narrow weight shadow feeds the matrix-core precision it was made for");
   static_assert((A_RC || TM == 4) && (B_RC || TN == 4), "an operand contiguous along the output axis is 4 interleaved blocks wide");
   constexpr int kAcc = TM * TN * 256;        // one wave's accumulators ...
   constexpr int kBuf = kAcc + 4 * 64;        // ... + its bias-gradient lanes, in LDS
@@ -114,7 +117,7 @@ __device__ __forceinline__ void skgemm_body(const Args& p, const int bid, const 
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
           const int col = j0 + 16 * t + l15, cc = col < p.J ? col : p.J - 1;
-          const float4 v = *reinterpret_cast<const float4*>(p.B + (live ? (int64_t)cc * p.sb_j + rq4 : 0));
+          const float4 v = adnm_ldb4<BT>(p.B, live ? (int64_t)cc * p.sb_j + rq4 : 0);
           bv[t][s][0] = v.x, bv[t][s][1] = v.y, bv[t][s][2] = v.z, bv[t][s][3] = v.w;
         }
       } else {
@@ -122,7 +125,7 @@ __device__ __forceinline__ void skgemm_body(const Args& p, const int bid, const 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int rr = r0 + 4 * kk + e, rq = rr < p.R ? rr : p.R - 1;
-          const float4 v = *reinterpret_cast<const float4*>(p.B + (live ? (int64_t)rq * p.sb_r + cc : 0));
+          const float4 v = adnm_ldb4<BT>(p.B, live ? (int64_t)rq * p.sb_r + cc : 0);
           bv[0][s][e] = v.x, bv[1 % TN][s][e] = v.y, bv[2 % TN][s][e] = v.z, bv[3 % TN][s][e] = v.w;
         }
       }
@@ -138,13 +141,16 @@ __device__ __forceinline__ void skgemm_body(const Args& p, const int bid, const 
   // fp8: per-tensor scales from the call site's quantisation record; the accumulators are un-scaled in the epilogue.  rec_a / rec_b
   // (wave-uniform): this wave collects max |value| of the A rows / B columns it reads — only the first tile column / tile row do, so every
   // element is seen once per reduction slice and the atomics stay a handful per launch.
-  float q_sa = 1.f, q_sb = 1.f, amax_a = 0.f, amax_b = 0.f;
+  // (an fp8 SHADOW is already scaled and rounded: its values pass through the fragment builder with scale 1 and come out bit for bit;
+  // q_sbo = the scale the accumulators are divided by)
+  float q_sa = 1.f, q_sb = 1.f, q_sbo = 1.f, amax_a = 0.f, amax_b = 0.f;
   bool rec_a = false, rec_b = false;
   if (p.q) {
-    if (PREC == ADNM_MFMA_FP8) q_sa = p.q->scale_a, q_sb = p.q->scale_b;
+    if (PREC == ADNM_MFMA_FP8) q_sa = p.q->scale_a, q_sb = q_sbo = p.q->scale_b;
     const bool rec = p.q->record != 0.f && active;
-    rec_a = rec && (tile % p.tiles_j) == 0, rec_b = rec && (tile / p.tiles_j) == 0;
+    rec_a = rec && (tile % p.tiles_j) == 0, rec_b = BT == ADNM_B_F32 && rec && (tile / p.tiles_j) == 0;
   }
+  if (BT == ADNM_B_FP8) q_sb = 1.f, q_sbo = *p.b_scale;
   auto compute = [&](int c, float (&av)[TM][KC][4], const float (&bv)[TN][KC][4]) {
 #pragma unroll
     for (int s = 0; s < KC; ++s) {
@@ -218,7 +224,7 @@ __device__ __forceinline__ void skgemm_body(const Args& p, const int bid, const 
   if (rec_a) adnm_amax_commit(&p.q->amax_a, amax_a);
   if (rec_b) adnm_amax_commit(&p.q->amax_b, amax_b);
   if (PREC == ADNM_MFMA_FP8) {   // back to the operands' own scale (before slices are summed, bias is added or slabs are written)
-    const float inv = 1.0f / (q_sa * q_sb);
+    const float inv = 1.0f / (q_sa * q_sbo);
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -351,9 +357,9 @@ __device__ __forceinline__ void skgemm_body(const Args& p, const int bid, const 
   }
 }
 
-template <bool A_RC, bool B_RC, int PREC, bool A_BF8, int TM, int TN, int KC>
+template <bool A_RC, bool B_RC, int PREC, bool A_BF8, int TM, int TN, int KC, int BT>
 __global__ __launch_bounds__(kBlock) void skgemm_kernel(SkArgs p) {
-  skgemm_body<A_RC, B_RC, PREC, A_BF8, TM, TN, KC>(p, (int)blockIdx.x, (int)gridDim.x);
+  skgemm_body<A_RC, B_RC, PREC, A_BF8, TM, TN, KC, BT>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Grouped weight gradients: the TN problems of a backward pass are leaves (nothing reads dW before the optimiser) and individually small
@@ -548,11 +554,14 @@ void dims(int op, int64_t M, int64_t N, int64_t K, int64_t* I, int64_t* J, int64
 }
 
 template <bool A_RC, bool B_RC, int TM, int TN, int KC>
-void launch(int prec, unsigned grid, hipStream_t st, const SkArgs& p) {
-  if (prec == ADNM_MFMA_BF16) skgemm_kernel<A_RC, B_RC, ADNM_MFMA_BF16, false, TM, TN, KC><<<grid, kBlock, 0, st>>>(p);
-  else if (prec == ADNM_MFMA_FP8) skgemm_kernel<A_RC, B_RC, ADNM_MFMA_FP8, false, TM, TN, KC><<<grid, kBlock, 0, st>>>(p);
-  else if (prec == ADNM_MFMA_FP8_GRAD) skgemm_kernel<A_RC, B_RC, ADNM_MFMA_FP8, true, TM, TN, KC><<<grid, kBlock, 0, st>>>(p);
-  else skgemm_kernel<A_RC, B_RC, ADNM_MFMA_F32, false, TM, TN, KC><<<grid, kBlock, 0, st>>>(p);
+void launch(int prec, int bt, unsigned grid, hipStream_t st, const SkArgs& p) {
+  if (bt == ADNM_B_BF16) skgemm_kernel<A_RC, B_RC, ADNM_MFMA_BF16, false, TM, TN, KC, ADNM_B_BF16><<<grid, kBlock, 0, st>>>(p);
+  else if (bt == ADNM_B_FP8 && prec == ADNM_MFMA_FP8) skgemm_kernel<A_RC, B_RC, ADNM_MFMA_FP8, false, TM, TN, KC, ADNM_B_FP8><<<grid, kBlock, 0, st>>>(p);
+  else if (bt == ADNM_B_FP8) skgemm_kernel<A_RC, B_RC, ADNM_MFMA_FP8, true, TM, TN, KC, ADNM_B_FP8><<<grid, kBlock, 0, st>>>(p);
+  else if (prec == ADNM_MFMA_BF16) skgemm_kernel<A_RC, B_RC, ADNM_MFMA_BF16, false, TM, TN, KC, ADNM_B_F32><<<grid, kBlock, 0, st>>>(p);
+  else if (prec == ADNM_MFMA_FP8) skgemm_kernel<A_RC, B_RC, ADNM_MFMA_FP8, false, TM, TN, KC, ADNM_B_F32><<<grid, kBlock, 0, st>>>(p);
+  else if (prec == ADNM_MFMA_FP8_GRAD) skgemm_kernel<A_RC, B_RC, ADNM_MFMA_FP8, true, TM, TN, KC, ADNM_B_F32><<<grid, kBlock, 0, st>>>(p);
+  else skgemm_kernel<A_RC, B_RC, ADNM_MFMA_F32, false, TM, TN, KC, ADNM_B_F32><<<grid, kBlock, 0, st>>>(p);
 }
 }  // namespace
 
@@ -596,8 +605,8 @@ extern "C" int64_t adnm_skgemm_counter_bytes(int op, int64_t M, int64_t N, int64
   return need;
 }
 
-extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, float* dbias,
-                           void* ws, int64_t ws_bytes, void* slabs_uc, int64_t slabs_uc_bytes, int64_t M, int64_t N, int64_t K, int prec, float* q,
+extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const void* b, int64_t ldb, int b_dtype, const float* b_scale, const float* bias,
+                           float* c, int64_t ldc, float* dbias, void* ws, int64_t ws_bytes, void* slabs_uc, int64_t slabs_uc_bytes, int64_t M, int64_t N, int64_t K, int prec, float* q,
                            adnm_stream_t stream) {
   ADNM_REQUIRE(prec >= ADNM_MFMA_F32 && prec <= ADNM_MFMA_FP8_GRAD, "skgemm: bad prec %d", prec);
   const bool fp8 = prec == ADNM_MFMA_FP8 || prec == ADNM_MFMA_FP8_GRAD;
@@ -606,13 +615,17 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   // gradient; the record of the forward call site does not describe that pair)
   if (fp8 && op == ADNM_SKGEMM_TN) prec = ADNM_MFMA_BF16, q = nullptr;
   ADNM_REQUIRE(a && b && c, "skgemm: null pointer");
+  ADNM_REQUIRE(b_dtype == ADNM_B_F32 || (op != ADNM_SKGEMM_TN && ((b_dtype == ADNM_B_BF16 && prec == ADNM_MFMA_BF16) || (b_dtype == ADNM_B_FP8 && fp8 && b_scale))),
+               "skgemm: a narrow weight operand (b_dtype %d) needs op NT / NN and the matching prec (bf16 shadow: ADNM_MFMA_BF16; fp8 shadow: an fp8 mode "
+               "and its scale), got op %d prec %d", b_dtype, op, prec);
   ADNM_REQUIRE(shape_ok(op, M, N, K), "skgemm: unsupported op/shape op=%d M=%lld N=%lld K=%lld", op, (long long)M, (long long)N, (long long)K);
   int64_t I, J, R;
   dims(op, M, N, K, &I, &J, &R);
   ADNM_REQUIRE(ldc >= J && ldc % 4 == 0, "skgemm: bad output row stride");
   ADNM_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= (op == ADNM_SKGEMM_NT ? K : N) && ldb >= K, "skgemm: bad operand row strides");
   ADNM_REQUIRE(!(bias && op != ADNM_SKGEMM_NT) && !(dbias && op != ADNM_SKGEMM_TN), "skgemm: bias only with NT, dbias only with TN");
-  ADNM_REQUIRE(((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) % 16 == 0, "skgemm: operands must be 16-byte aligned");
+  ADNM_REQUIRE(((uintptr_t)a | (uintptr_t)c) % 16 == 0 && (uintptr_t)b % (b_dtype == ADNM_B_F32 ? 16 : (b_dtype == ADNM_B_BF16 ? 8 : 4)) == 0,
+               "skgemm: operands must be aligned to 4 elements (16 bytes of fp32)");
   hipStream_t st = (hipStream_t)stream;
   const bool bf = prec != ADNM_MFMA_F32;   // the narrow modes share the tile plan measured for bf16
   Plan pl = make_plan(op, I, J, R, false, bf);
@@ -620,10 +633,11 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   if (op == ADNM_SKGEMM_TN && ldc != J) pl = make_plan(op, I, J, R, true, bf);
   ADNM_REQUIRE(pl.kernel >= 0, "skgemm: ADNM_SK_FORCE names a configuration this op has no kernel for");
   const char* scope = op == ADNM_SKGEMM_NT ? "skgemm_nt" : (op == ADNM_SKGEMM_NN ? "skgemm_nn" : "skgemm_tn");
-  const double algo_bytes = 4.0 * ((double)M * (K + N) + (double)N * K);
+  // algorithmic bytes: activations in and out in fp32, the weight in the storage it is read from (fp32 / bf16 shadow / fp8 shadow)
+  const double algo_bytes = 4.0 * (double)M * (K + N) + (b_dtype == ADNM_B_BF16 ? 2.0 : (b_dtype == ADNM_B_FP8 ? 1.0 : 4.0)) * (double)N * K;
   if (pl.kernel == KERNEL_LDS) {
     ADNM_PROF(scope, st, algo_bytes);
-    const int rc = adnm_lgemm_launch(op == ADNM_SKGEMM_NN, a, lda, b, ldb, bias, c, ldc, ws, ws_bytes, slabs_uc, slabs_uc_bytes, I, J, R, pl.nbs, prec, q, st);
+    const int rc = adnm_lgemm_launch(op == ADNM_SKGEMM_NN, a, lda, b, ldb, b_dtype, b_scale, bias, c, ldc, ws, ws_bytes, slabs_uc, slabs_uc_bytes, I, J, R, pl.nbs, prec, q, st);
     if (rc != ADNM_OK) return rc;
     ADNM_CHECK_LAUNCH("skgemm");
     return ADNM_OK;
@@ -638,7 +652,7 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
     return ADNM_EWORKSPACE;
   }
   SkArgs p;
-  p.A = a, p.B = b, p.bias = bias;
+  p.A = a, p.B = b, p.bias = bias, p.b_scale = b_scale;
   if (op == ADNM_SKGEMM_NT) p.sa_i = lda, p.sa_r = 1, p.sb_r = 1, p.sb_j = ldb;
   else if (op == ADNM_SKGEMM_NN) p.sa_i = lda, p.sa_r = 1, p.sb_r = ldb, p.sb_j = 1;
   else p.sa_i = 1, p.sa_r = lda, p.sb_r = ldb, p.sb_j = 1;
@@ -673,15 +687,15 @@ extern "C" int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, 
   if (!queued) {
     ADNM_PROF(scope, st, algo_bytes);
     if (op == ADNM_SKGEMM_NT) {
-      if (pl.tm == 1) launch<true, true, 1, 1, 4>(prec, grid, st, p);
-      else if (pl.tm == 2) launch<true, true, 2, 2, 2>(prec, grid, st, p);
-      else launch<true, true, 4, 4, 1>(prec, grid, st, p);
+      if (pl.tm == 1) launch<true, true, 1, 1, 4>(prec, b_dtype, grid, st, p);
+      else if (pl.tm == 2) launch<true, true, 2, 2, 2>(prec, b_dtype, grid, st, p);
+      else launch<true, true, 4, 4, 1>(prec, b_dtype, grid, st, p);
     } else if (op == ADNM_SKGEMM_NN) {
-      if (pl.tm == 1) launch<true, false, 1, 4, 2>(prec, grid, st, p);
-      else if (pl.tm == 2) launch<true, false, 2, 4, 2>(prec, grid, st, p);
-      else launch<true, false, 4, 4, 1>(prec, grid, st, p);
+      if (pl.tm == 1) launch<true, false, 1, 4, 2>(prec, b_dtype, grid, st, p);
+      else if (pl.tm == 2) launch<true, false, 2, 4, 2>(prec, b_dtype, grid, st, p);
+      else launch<true, false, 4, 4, 1>(prec, b_dtype, grid, st, p);
     } else {
-      launch<false, false, 4, 4, 1>(prec, grid, st, p);
+      launch<false, false, 4, 4, 1>(prec, b_dtype, grid, st, p);
     }
   }
   ADNM_CHECK_LAUNCH("skgemm");

@@ -170,7 +170,8 @@ class Mamba2(nn.Module):
         if pre is None:
             dims, params = self.adnm_prep_args()
             pre = ops.adn_prep(*dims, params)
-        w_in, taps, ln_w, ln_b, w_out = pre
+        w_in, taps, ln_w, ln_b, w_out = pre[:5]
+        narrow = tuple(pre[5:9]) if len(pre) == 9 else (None, None, None, None)   # the grouped prep's bf16 / fp8 copies of the two projections
         return ops.adn_mixer(u, w_in, taps, None, self.dt_bias, self.A_log, self.D, ln_w, ln_b, w_out, H, W,
                              self.headdim, self.ngroups * self.d_state // 2, scan_chunk, self.ngroups,
-                             qkeys=(self.in_proj.weight.data_ptr(), self.out_proj.weight.data_ptr()))
+                             qkeys=(self.in_proj.weight.data_ptr(), self.out_proj.weight.data_ptr()), narrow=narrow)

@@ -53,6 +53,8 @@ enum { ADNM_OK = 0, ADNM_EINVAL = -1, ADNM_ELAUNCH = -2, ADNM_EWORKSPACE = -3 };
  * (atomic max, order-independent); adnm_quant_update turns them into the next scales (delayed per-tensor scaling: a tensor's scale
  * comes from an earlier step's amax, so quantisation costs no extra pass over the activations).  q == NULL: scales 1, nothing recorded. */
 enum { ADNM_MFMA_F32 = 0, ADNM_MFMA_BF16 = 1, ADNM_MFMA_FP8 = 2, ADNM_MFMA_FP8_GRAD = 3 };
+/* storage of a GEMM's weight operand (b_dtype of adnm_skgemm): fp32 master values or the narrow shadow kept beside them */
+enum { ADNM_B_F32 = 0, ADNM_B_BF16 = 1, ADNM_B_FP8 = 2 };
 
 /* One pass over a table of `n` quantisation records (n * 8 floats), once per training step:
  *   state = {step counter, period}: the counter advances; records collect amax (record = 1) during the steps where counter % period == 0;
@@ -365,6 +367,12 @@ int adnm_colsum(const float* x, float* out, int64_t rows, int64_t n, void* ws, i
  * lda / ldb / ldc: row strides in elements (multiples of 4); bias only with NT, dbias only with TN; c / dbias OVERWRITTEN.
  * prec / q: the precision ladder and the call site's quantisation record (see ADNM_MFMA_*); a = the "first operand", b = the weight.
  * TN (the weight gradient) runs on bf16 operands in the fp8 modes.
+ * b_dtype (NT / NN): storage of the weight operand b — ADNM_B_F32 (the fp32 master values, rounded / scaled on the way into the MFMA),
+ *   ADNM_B_BF16 (its bf16 shadow, prec ADNM_MFMA_BF16 only) or ADNM_B_FP8 (its per-tensor scaled OCP e4m3 shadow, the fp8 modes only;
+ *   b_scale = device pointer to the scale the shadow was made with: value = e4m3 / *b_scale; q's scale_b / amax_b are then unused).
+ *   The shadows are written by the optimiser pass (adnm_adamw_step) or the parameter-prep kernels; ldb counts ELEMENTS in every case.
+ *   A narrow weight halves / quarters the bytes of the weight-streaming shapes and gives bit for bit the result of the fp32 operand
+ *   rounded the same way.
  * Workspace (adnm_skgemm_ws_bytes; 16 = the shape is not split): a reduction that would leave CUs idle is split over workgroups.
  *   TN: ws holds fp32 partials for the shared fold — ordinary device memory.
  *   NT / NN: the slabs are combined INSIDE the launch (arrival counters; the last workgroup of a tile adds the slabs in slice order:
@@ -383,9 +391,9 @@ int adnm_colsum(const float* x, float* out, int64_t rows, int64_t n, void* ws, i
 #define ADNM_SKGEMM_TN 2
 int adnm_skgemm_supported(int op, int64_t M, int64_t N, int64_t K);
 int64_t adnm_skgemm_ws_bytes(int op, int64_t M, int64_t N, int64_t K);   /* counters + slabs (NT / NN), partials (TN) */
-int adnm_skgemm(int op, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* c, int64_t ldc, float* dbias,
-                void* ws, int64_t ws_bytes, void* slabs_uc, int64_t slabs_uc_bytes, int64_t M, int64_t N, int64_t K, int prec, float* q,
-                adnm_stream_t stream);
+int adnm_skgemm(int op, const float* a, int64_t lda, const void* b, int64_t ldb, int b_dtype, const float* b_scale, const float* bias, float* c,
+                int64_t ldc, float* dbias, void* ws, int64_t ws_bytes, void* slabs_uc, int64_t slabs_uc_bytes, int64_t M, int64_t N, int64_t K,
+                int prec, float* q, adnm_stream_t stream);
 int64_t adnm_skgemm_counter_bytes(int op, int64_t M, int64_t N, int64_t K);
 void* adnm_uncached_alloc(int64_t bytes);
 int adnm_uncached_free(void* ptr);
@@ -445,11 +453,25 @@ int adnm_mixnorm_bwd(const float* dyn, int64_t lddyn, const float* dres, int64_t
  *   state[1] = sum g^2;  coef = min(1, max_norm / (sqrt(state[1]) + 1e-6))  (max_norm <= 0: no clipping)
  *   state[0] += 1 (step);  p *= 1 - lr*wd;  m = lerp(m, coef*g, 1-beta1);  v = beta2*v + (1-beta2)(coef*g)^2
  *   p -= lr/(1-beta1^step) * m / (sqrt(v)/sqrt(1-beta2^step) + eps)        — torch.optim.AdamW's exact update order.
- * state: 4 device floats [step, sumsq, bc1, sqrt(bc2)], zero-initialised by the caller; n % 4 == 0. */
+ * state: 4 device floats [step, sumsq, bc1, sqrt(bc2)], zero-initialised by the caller; n % 4 == 0.
+ * shadow (optional, NULL = none): the narrow copy of the updated parameters the weight-streaming GEMMs read (adnm_skgemm b_dtype), written
+ *   in the same pass — the values are in registers anyway, so the step pays 2 (bf16) or 1 (fp8) more bytes per parameter and the two
+ *   passes that re-read the 72 M parameters every step (forward, input gradients) read a half / a quarter of the bytes:
+ *   shadow_dtype ADNM_B_BF16: shadow[i] = bf16(p[i]), n uint16;
+ *   shadow_dtype ADNM_B_FP8:  shadow[i] = e4m3(clamp(p[i] * scale_b(record of i's tensor))), n bytes.  Tensors = the segments of the flat
+ *     buffer: seg_end[s] = END of segment s in units of 4 elements (ascending; tensors are 16-byte aligned in the flat layout),
+ *     seg_rec[s] = row of its 8-float quantisation record in wtab (the layout of `q`; only scale_b / amax_b / fmax_b / record are used)
+ *     or < 0 for a tensor no GEMM reads (its shadow bytes are unspecified).  While a record's `record` flag is set the pass collects
+ *     max |p| of the UPDATED values into amax_b; adnm_quant_update (run over wtab BEFORE this pass in a step) turns it into the next
+ *     scale_b, with which this pass writes the shadow and the next step's GEMMs read it: shadow and scale never disagree.
+ * adnm_shadow_refresh: the shadow alone from the parameters as they are (after they moved into the flat buffer, after a checkpoint load);
+ *   shadow = NULL (fp8) with collect != 0: only collect max |p| (the first calibration). */
 int64_t adnm_adamw_ws_bytes(void);
 int adnm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float* state, float lr, float beta1,
-                    float beta2, float eps, float weight_decay, float max_norm, void* ws, int64_t ws_bytes,
-                    adnm_stream_t stream);
+                    float beta2, float eps, float weight_decay, float max_norm, void* ws, int64_t ws_bytes, void* shadow, int shadow_dtype,
+                    const int* seg_end, const int* seg_rec, int64_t nseg, float* wtab, adnm_stream_t stream);
+int adnm_shadow_refresh(const float* p, int64_t n, void* shadow, int shadow_dtype, const int* seg_end, const int* seg_rec, int64_t nseg,
+                        float* wtab, int collect, adnm_stream_t stream);
 
 /* ---------------------------------------------------------------- dense 3x3 'same' convolution, NHWC, on MFMA (K5)
  * nn.Conv2d(k=3, s=1, p=1) [+ bias] [+ GELU] of the U-Net conv stack: PatchEmbed.conv2 (model_untils.py:259-273), WTLayer.conv
@@ -568,8 +590,14 @@ int adnm_wtprep_bwd(float* const* w, float* const* s, float* bias, float* const*
  * microseconds each at config 2).  Tables are concatenated per module i: params[15 i ..], prepped / gprepped[6 i ..], dparams[15 i ..],
  * dims[5 i ..] = {d_model, d_inner, gn, headdim, tap_ld};  WTConv2d: w / s / taps / gtaps / dw / ds[5 i ..] (entries 0 .. levels), bias[i],
  * bias_t[i], gbias_t[i], dbias[i] (all NULL or all set per module), dims[4 i ..] = {C, Cp, K, levels}.  More than 8 modules are cut into
- * several launches.  Same results as the per-module entry points, bit for bit. */
-int adnm_adnprep_fwd_multi(int64_t n, float* const* params, float* const* prepped, const int64_t* dims, adnm_stream_t stream);
+ * several launches.  Same results as the per-module entry points, bit for bit.
+ * adnm_adnprep_fwd_multi, narrow (optional, NULL = none): narrow[5 i ..] = {w_in_n, w_out_n, s_in, s_out, s_out_eff} — NARROW copies of the
+ * two big matrices of mixer i for the weight-streaming GEMMs (adnm_skgemm b_dtype = narrow_dtype) INSTEAD of the fp32 ones (prepped[6 i]
+ * resp. prepped[6 i + 5] may then be NULL): ADNM_B_BF16: bf16 values; ADNM_B_FP8: w_in_n = e4m3(w_in * *s_in), w_out_n = e4m3(w_out * e)
+ * with e = *s_out / |alpha1| written to *s_out_eff (s_in / s_out: the scale_b of in_proj.weight's / out_proj.weight's quantisation
+ * records — a row / column permutation keeps a tensor's maximum, alpha1 scales it). */
+int adnm_adnprep_fwd_multi(int64_t n, float* const* params, float* const* prepped, const int64_t* dims, float* const* narrow, int narrow_dtype,
+                           adnm_stream_t stream);
 int64_t adnm_adnprep_bwd_multi_ws_bytes(int64_t n);
 int adnm_adnprep_bwd_multi(int64_t n, float* const* params, float* const* gprepped, float* const* dparams, const int64_t* dims, void* ws,
                            int64_t ws_bytes, adnm_stream_t stream);

@@ -1131,3 +1131,84 @@ def test_tsgemm_bf16_token_storage(M, K, N, bf16_mfma):
     assert_close(dw, cb.double().t() @ xb.double(), 1e-5, "dw from bf16 rows")
     dw2, _ = ops.k_linear_dw(cot.to(DEV), xb, False)                      # mixed: fp32 gradient rows, bf16 activations
     assert_close(dw2, cot.double().to(DEV).t() @ xb.double(), 1e-5, "dw from fp32 x bf16 rows")
+
+
+def _e4m3_bytes(t):
+    """e4m3 bytes of an fp32 tensor (saturating), as the kernels write them"""
+    return t.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+@pytest.mark.parametrize("M,K,N", [(64, 1024, 512), (1024, 256, 1216), (64, 4096, 1024), (256, 1024, 4672), (1024, 512, 2368), (16, 2048, 512)])
+def test_skgemm_narrow_weight_operand(M, K, N):
+    """the weight operand of the short GEMMs read from its narrow SHADOW (adnm_skgemm b_dtype) — bf16 in the bf16 mode,
+    per-tensor scaled e4m3 in the fp8 modes — gives BIT FOR BIT what the fp32 operand gives after the same rounding, forward (NT) and
+    input gradient (NN), on both kernels (register-streaming and LDS-tiled, split or not)."""
+    x, w, cot = T(f"nw.x{M}{K}", (M, K)).to(DEV), T(f"nw.w{N}{K}", (N, K), 0.05).to(DEV), T(f"nw.c{M}{N}", (M, N)).to(DEV)
+    try:
+        ops.set_mfma_precision("bf16")
+        w16 = w.to(torch.bfloat16)
+        y0, dx0 = ops.k_linear(x, w, None), ops.k_linear_dx(cot, w)
+        y1 = ops.k_linear(x, w, None, narrow=(w16.data_ptr(), 1, None))
+        dx1 = ops.k_linear_dx(cot, w, narrow=(w16.data_ptr(), 1, None))
+        assert torch.equal(y0, y1) and torch.equal(dx0, dx1), "bf16 shadow"
+        # fp8: explicit scales for both call sites; the shadow is what the optimiser pass would write: e4m3(w * s)
+        ops.QUANT.reset()
+        ops.set_mfma_precision("fp8")
+        rows, ops.QUANT.max_rows = ops.QUANT.max_rows, 1 << 30
+        sx, sw, sc = 448.0 / float(x.abs().max()) / 2, 448.0 / float(w.abs().max()) / 2, 57344.0 / float(cot.abs().max()) / 2
+        ops.QUANT.set(x.device, w.data_ptr(), "linear_fwd", sx, sw)
+        ops.QUANT.set(x.device, w.data_ptr(), "linear_dgrad", sc, sw)
+        w8 = _e4m3_bytes(w * sw)
+        s_t = torch.tensor([sw], dtype=torch.float32, device=DEV)
+        y0, dx0 = ops.k_linear(x, w, None), ops.k_linear_dx(cot, w)
+        y1 = ops.k_linear(x, w, None, narrow=(w8.data_ptr(), 2, s_t))
+        dx1 = ops.k_linear_dx(cot, w, narrow=(w8.data_ptr(), 2, s_t))
+        ops.QUANT.max_rows = rows
+        assert torch.equal(y0, y1) and torch.equal(dx0, dx1), "fp8 shadow"
+    finally:
+        ops.set_mfma_precision("f32")
+        ops.QUANT.reset()
+
+
+def test_adamw_writes_the_shadows():
+    """adnm_adamw_step with a shadow: the update itself is unchanged (bitwise the shadow-less pass), the bf16 shadow is bf16(p) of the
+    UPDATED values, the fp8 shadow e4m3(p * scale_b of the tensor's record) with max |p| collected per record while its flag is set."""
+    n_t = [4096, 12, 70000, 4, 1024 * 33]
+    offs, total = [], 0
+    for k in n_t:
+        offs.append(total)
+        total += (k + 3) // 4 * 4
+    g = T("aw.g", (total,), 0.01).to(DEV)
+    p0 = T("aw.p", (total,), 0.3).to(DEV)
+
+    def run(mode):
+        p, m, v = p0.clone(), torch.zeros(total, device=DEV), torch.zeros(total, device=DEV)
+        state = torch.zeros(4, device=DEV)
+        ws = torch.empty(int(lib.query("adnm_adamw_ws_bytes")), dtype=torch.uint8, device=DEV)
+        sh = torch.zeros(total, dtype=torch.bfloat16 if mode == 1 else torch.uint8, device=DEV) if mode else None
+        tab = torch.zeros((8, 8), device=DEV)
+        tab[:, 1], tab[:, 5], tab[:, 6] = torch.tensor([3.0, 1.0, 50.0, 1.0, 200.0, 1, 1, 1]), 448.0, 1.0
+        seg_end = torch.tensor([o // 4 for o in offs[1:]] + [total // 4], dtype=torch.int32, device=DEV)
+        seg_rec = torch.tensor([0, -1, 2, -1, 4], dtype=torch.int32, device=DEV)
+        for _ in range(2):
+            lib.call("adnm_adamw_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), total, state.data_ptr(), 1e-3, 0.9, 0.999, 1e-9, 1e-2, 0.05,
+                     ws.data_ptr(), ws.numel(), None if sh is None else sh.data_ptr(), mode, seg_end.data_ptr(), seg_rec.data_ptr(), 5,
+                     tab.data_ptr() if mode == 2 else None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return p, m, v, sh, tab
+    base = run(0)
+    b16 = run(1)
+    f8 = run(2)
+    for k in range(3):
+        assert torch.equal(base[k], b16[k]) and torch.equal(base[k], f8[k]), "the shadow must not change the update"
+    assert torch.equal(b16[3], base[0].to(torch.bfloat16))
+    p, sh, tab = f8[0], f8[3], f8[4]
+    for k, (o, nk) in enumerate(zip(offs, n_t)):
+        if k in (0, 2, 4):
+            s = float(tab[k, 1])
+            assert torch.equal(sh[o:o + nk], _e4m3_bytes(p[o:o + nk] * s)), f"fp8 shadow of tensor {k}"
+            # the maximum covers the tensor and whatever alignment padding follows it (zeros here: p0 is dense, so compare with the segment)
+            end = offs[k + 1] if k + 1 < len(offs) else total
+            assert float(tab[k, 3]) == float(p[o:end].abs().max()), f"max |p| of tensor {k}"
+        else:
+            assert float(tab[1, 3]) == 0.0 and float(tab[3, 3]) == 0.0

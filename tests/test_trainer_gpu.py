@@ -191,3 +191,36 @@ def test_side_stream_weight_gradients_are_bitwise_neutral(use_graph):
         del tr
     assert torch.equal(flats[0][1], flats[1][1]), "gradients differ with the side stream on"
     assert torch.equal(flats[0][0], flats[1][0]), "parameters differ with the side stream on"
+
+
+def test_bf16_shadow_weights_are_bitwise_neutral(monkeypatch):
+    """The bf16 configuration reads its GEMM weights from the bf16 shadow the optimiser pass writes (and the mixer prep's bf16 copies):
+    rounding the fp32 weight on the way into the MFMA or reading its pre-rounded twin is the same arithmetic — parameters and gradients
+    after several steps must agree bit for bit with ADNM_NARROW_WEIGHTS=0."""
+    from models.ADNMUNet import create_ADNMUNet
+    from models.loss import enRainfallLoss
+    from adnm_hip import ops
+    frames = recipe.radar_batch(2, 25, 64, name="shadow").to(DEV)
+    x, tgt = frames[:, :5].contiguous(), frames[:, 5:].contiguous()
+    flats = []
+    ops.set_mfma_precision("bf16")
+    try:
+        for narrow in ("0", "1"):
+            monkeypatch.setenv("ADNM_NARROW_WEIGHTS", narrow)
+            model = create_ADNMUNet(5, 20, 6, img_size=64)
+            recipe.fill_parameters(model)
+            model = model.to(DEV).train()
+            tr = FlatTrainer(model, enRainfallLoss(0.57, 0.25, gamma=0.0), lr=1e-3, max_norm=0.025, use_graph=True)
+            for _ in range(4):
+                tr.step(x, tgt)
+            torch.cuda.synchronize()
+            assert (getattr(tr, "shadow_mode", 0) == 1) == (narrow == "1")
+            if narrow == "1":
+                assert torch.equal(tr.shadow, tr.flat_p.to(torch.bfloat16)), "the shadow is bf16(p) after every step"
+            flats.append((tr.flat_p.clone(), tr.flat_g.clone()))
+            tr.close()
+            del tr
+    finally:
+        ops.set_mfma_precision("f32")
+    assert torch.equal(flats[0][1], flats[1][1]), "gradients differ with the shadow weights"
+    assert torch.equal(flats[0][0], flats[1][0]), "parameters differ with the shadow weights"
