@@ -31,6 +31,72 @@ __device__ __forceinline__ float4 apply_act_grad(float4 v, int act) {
   return make_float4(1.f, 1.f, 1.f, 1.f);
 }
 
+// A lane's channel vector: ONE 16-byte access per pixel whatever the storage type — 4 fp32 channels or 8 bf16 channels (half the bytes AND
+// half the load / store instructions per channel: a bf16 path that kept 4 channels = 8 bytes per lane moved half the bytes per request and
+// ran no faster than fp32, profiles/r03_bf16_storage_ab.txt).  Arithmetic is fp32 in both.
+template <typename T>
+struct CVec;
+template <>
+struct CVec<float> {
+  static constexpr int N = 4, Q = 1;
+  float4 q[1];
+};
+template <>
+struct CVec<uint16_t> {
+  static constexpr int N = 8, Q = 2;
+  float4 q[2];
+};
+template <typename T>
+__device__ __forceinline__ CVec<T> cv_zero() {
+  CVec<T> v;
+#pragma unroll
+  for (int i = 0; i < CVec<T>::Q; ++i) v.q[i] = f4zero();
+  return v;
+}
+__device__ __forceinline__ CVec<float> cv_ld(const float* p) {
+  CVec<float> v;
+  v.q[0] = *reinterpret_cast<const float4*>(p);
+  return v;
+}
+__device__ __forceinline__ CVec<uint16_t> cv_ld(const uint16_t* p) {
+  const uint4 r = *reinterpret_cast<const uint4*>(p);
+  CVec<uint16_t> v;
+  v.q[0] = make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+  v.q[1] = make_float4(__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u), __uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u));
+  return v;
+}
+__device__ __forceinline__ void cv_st(float* p, const CVec<float>& v) { *reinterpret_cast<float4*>(p) = v.q[0]; }
+__device__ __forceinline__ void cv_st(uint16_t* p, const CVec<uint16_t>& v) {
+  uint4 r;
+  r.x = (uint32_t)f32_to_bf16(v.q[0].x) | ((uint32_t)f32_to_bf16(v.q[0].y) << 16);
+  r.y = (uint32_t)f32_to_bf16(v.q[0].z) | ((uint32_t)f32_to_bf16(v.q[0].w) << 16);
+  r.z = (uint32_t)f32_to_bf16(v.q[1].x) | ((uint32_t)f32_to_bf16(v.q[1].y) << 16);
+  r.w = (uint32_t)f32_to_bf16(v.q[1].z) | ((uint32_t)f32_to_bf16(v.q[1].w) << 16);
+  *reinterpret_cast<uint4*>(p) = r;
+}
+template <typename T>
+__device__ __forceinline__ CVec<T> cv_ldf(const float* p) {   // N consecutive fp32 values (a tap, a bias)
+  CVec<T> v;
+#pragma unroll
+  for (int i = 0; i < CVec<T>::Q; ++i) v.q[i] = *reinterpret_cast<const float4*>(p + 4 * i);
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ void cv_stf(float* p, const CVec<T>& v) {
+#pragma unroll
+  for (int i = 0; i < CVec<T>::Q; ++i) *reinterpret_cast<float4*>(p + 4 * i) = v.q[i];
+}
+template <typename T>
+__device__ __forceinline__ void cv_fma(CVec<T>& a, const CVec<T>& w, const CVec<T>& x) {
+#pragma unroll
+  for (int i = 0; i < CVec<T>::Q; ++i) fma4(a.q[i], w.q[i], x.q[i]);
+}
+template <typename T>
+__device__ __forceinline__ void cv_add(CVec<T>& a, const CVec<T>& x) {
+#pragma unroll
+  for (int i = 0; i < CVec<T>::Q; ++i) a.q[i].x += x.q[i].x, a.q[i].y += x.q[i].y, a.q[i].z += x.q[i].z, a.q[i].w += x.q[i].w;
+}
+
 // MODE 0: y = act(conv(x) + bias) (+ addend)         [forward]
 // MODE 1: y = dy * act'(conv(x) + bias)              [backward step (a); `aux` = dy with pixel stride ldaux]
 // MODE 2: y = conv_flipped(x)                        [backward step (b); x = dpre]
@@ -39,8 +105,9 @@ __global__ __launch_bounds__(kBlock) void dwconv_kernel(const T* __restrict__ x,
                                                         const float* __restrict__ bias, const T* __restrict__ aux,
                                                         int64_t ldaux, T* __restrict__ y, int64_t ldy, int B, int H, int W,
                                                         int C, int act) {
-  constexpr int R = K / 2;
-  const int C4 = C >> 2;
+  constexpr int R = K / 2, N = CVec<T>::N, Q = CVec<T>::Q;
+  using V = CVec<T>;
+  const int C4 = C / N;   // channel vectors per pixel
   const int WT = (W + TW - 1) / TW;
   const int64_t total = (int64_t)B * H * WT * C4;
   // XCD-aware block order: consecutive blockIdx round-robin over the 8 XCDs (private L2 each), but the halo rows of a
@@ -56,61 +123,71 @@ __global__ __launch_bounds__(kBlock) void dwconv_kernel(const T* __restrict__ x,
   t /= WT;
   const int h = (int)(t % H);
   const int b = (int)(t / H);
-  const int c = cg * 4;
+  const int c = cg * N;
   const int w0 = wt * TW;
-  float wcmv[WCM ? 4 * K * K : 1];
+  float wcmv[WCM ? N * K * K : 1];
   if (WCM) {
 #pragma unroll
-    for (int q = 0; q < K * K; ++q) {
+    for (int q = 0; q < N * K * K / 4; ++q) {
       const float4 t4 = *reinterpret_cast<const float4*>(wgt + (int64_t)c * (K * K) + 4 * q);
       wcmv[4 * q] = t4.x; wcmv[4 * q + 1] = t4.y; wcmv[4 * q + 2] = t4.z; wcmv[4 * q + 3] = t4.w;
     }
   }
-  float4 acc[TW];
+  V acc[TW];
 #pragma unroll
-  for (int i = 0; i < TW; ++i) acc[i] = f4zero();
+  for (int i = 0; i < TW; ++i) acc[i] = cv_zero<T>();
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     const int hh = h + i - R;
     if (hh < 0 || hh >= H) continue;
     const T* xr = x + ((int64_t)b * H + hh) * W * ldx + c;
-    float4 row[TW + K - 1];
+    V row[TW + K - 1];
 #pragma unroll
     for (int j = 0; j < TW + K - 1; ++j) {
       const int ww = w0 + j - R;
-      row[j] = (ww >= 0 && ww < W) ? Io<T>::ld4(xr + (int64_t)ww * ldx) : f4zero();
+      row[j] = (ww >= 0 && ww < W) ? cv_ld(xr + (int64_t)ww * ldx) : cv_zero<T>();
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       const int tap = (MODE == 2) ? ((K - 1 - i) * K + (K - 1 - j)) : (i * K + j);
-      // weights: tap-major (K*K, C): one float4 per tap; or, wcm, nn.Conv2d's own channel-major (C, K*K): the lane's 4 channels
-      // are 4*K*K consecutive floats, fetched once as K*K float4s (wcmv) and picked apart at compile-time indices
-      const float4 wv = WCM ? make_float4(wcmv[tap], wcmv[(WCM ? K * K : 0) + tap * WCM], wcmv[(WCM ? 2 * K * K : 0) + tap * WCM], wcmv[(WCM ? 3 * K * K : 0) + tap * WCM])
-                            : *reinterpret_cast<const float4*>(wgt + (int64_t)tap * C + c);
+      // weights: tap-major (K*K, C): N consecutive floats per tap; or, wcm, nn.Conv2d's own channel-major (C, K*K): the lane's N channels
+      // are N*K*K consecutive floats, fetched once (wcmv) and picked apart at compile-time indices
+      V wv;
+      if (WCM) {
 #pragma unroll
-      for (int p = 0; p < TW; ++p) fma4(acc[p], wv, row[p + j]);
+        for (int qq = 0; qq < Q; ++qq)
+          wv.q[qq] = make_float4(wcmv[(WCM ? (4 * qq) * K * K : 0) + tap * WCM], wcmv[(WCM ? (4 * qq + 1) * K * K : 0) + tap * WCM],
+                                 wcmv[(WCM ? (4 * qq + 2) * K * K : 0) + tap * WCM], wcmv[(WCM ? (4 * qq + 3) * K * K : 0) + tap * WCM]);
+      } else {
+        wv = cv_ldf<T>(wgt + (int64_t)tap * C + c);
+      }
+#pragma unroll
+      for (int p = 0; p < TW; ++p) cv_fma(acc[p], wv, row[p + j]);
     }
   }
-  float4 bv = f4zero();
-  if (MODE != 2 && bias) bv = *reinterpret_cast<const float4*>(bias + c);
+  V bv = cv_zero<T>();
+  if (MODE != 2 && bias) bv = cv_ldf<T>(bias + c);
 #pragma unroll
   for (int p = 0; p < TW; ++p) {
     const int ww = w0 + p;
     if (ww >= W) break;
     const int64_t pix = ((int64_t)b * H + h) * W + ww;
-    float4 v = acc[p];
+    V v = acc[p];
     if (MODE == 0) {
-      v = apply_act(make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w), act);
-      if (aux) {
-        const float4 a = Io<T>::ld4(aux + pix * ldaux + c);
-        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-      }
+      cv_add(v, bv);
+#pragma unroll
+      for (int qq = 0; qq < Q; ++qq) v.q[qq] = apply_act(v.q[qq], act);
+      if (aux) cv_add(v, cv_ld(aux + pix * ldaux + c));
     } else if (MODE == 1) {
-      const float4 g = apply_act_grad(make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w), act);
-      const float4 d = Io<T>::ld4(aux + pix * ldaux + c);
-      v = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+      cv_add(v, bv);
+      const V d = cv_ld(aux + pix * ldaux + c);
+#pragma unroll
+      for (int qq = 0; qq < Q; ++qq) {
+        const float4 g = apply_act_grad(v.q[qq], act);
+        v.q[qq] = make_float4(d.q[qq].x * g.x, d.q[qq].y * g.y, d.q[qq].z * g.z, d.q[qq].w * g.w);
+      }
     }
-    Io<T>::st4(y + pix * ldy + c, v);
+    cv_st(y + pix * ldy + c, v);
   }
 }
 
@@ -128,9 +205,10 @@ __device__ __forceinline__ void dwconv_wgrad_body(const T* __restrict__ dpre, in
                                                   float* __restrict__ part, int B, int H, int W, int C, int cgb, int wcm, const int bx,
                                                   const int by, const int nby) {
   constexpr int R = K / 2;
-  constexpr int NT = K * K;
-  const int C4 = C >> 2;
-  __shared__ __attribute__((aligned(16))) float red[K][K + 1][64][4];
+  constexpr int NT = K * K, N = CVec<T>::N;
+  using V = CVec<T>;
+  const int C4 = C / N;   // channel vectors per pixel
+  __shared__ __attribute__((aligned(16))) float red[K][K + 1][64][N];
   const int wv = threadIdx.x >> 6;
   const int i = wv % K;            // tap row of this wave
   const int sl = wv / K;           // tile slice of this wave
@@ -140,13 +218,13 @@ __device__ __forceinline__ void dwconv_wgrad_body(const T* __restrict__ dpre, in
   const int slots = 64 / cgb;
   const int cg = bx * cgb + cgl;
   const bool cv = cg < C4;
-  const int c = cv ? cg * 4 : 0;
+  const int c = cv ? cg * N : 0;
   const int WT = (W + TW - 1) / TW;
   const int64_t tiles = (int64_t)B * H * WT;
-  float4 aw[K];
-  float4 ab = f4zero();
+  V aw[K];
+  V ab = cv_zero<T>();
 #pragma unroll
-  for (int k = 0; k < K; ++k) aw[k] = f4zero();
+  for (int k = 0; k < K; ++k) aw[k] = cv_zero<T>();
   if (cv) {
     // Each block owns a CONTIGUOUS range of tiles (XCD-aware: the ranges of one XCD are adjacent, so the x / dpre rows
     // shared by its K tap-row waves and by vertically adjacent tiles are served by that XCD's L2), and keeps two tiles
@@ -157,7 +235,7 @@ __device__ __forceinline__ void dwconv_wgrad_body(const T* __restrict__ dpre, in
     const int64_t tbeg = bid * tpb, tend = (tbeg + tpb < tiles) ? tbeg + tpb : tiles;
     const int64_t stride = (int64_t)slots * kWgSlices;
     for (int64_t t0 = tbeg + sl * slots + slot; t0 < tend; t0 += 2 * stride) {
-      float4 g[2][TW], row[2][TW + K - 1];
+      V g[2][TW], row[2][TW + K - 1];
       bool live[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -171,39 +249,41 @@ __device__ __forceinline__ void dwconv_wgrad_body(const T* __restrict__ dpre, in
 #pragma unroll
         for (int p = 0; p < TW; ++p) {
           const int ww = w0 + p;
-          g[u][p] = (live[u] && ww < W) ? Io<T>::ld4(dpre + (((int64_t)b * H + h) * W + ww) * ldd + c) : f4zero();
+          g[u][p] = (live[u] && ww < W) ? cv_ld(dpre + (((int64_t)b * H + h) * W + ww) * ldd + c) : cv_zero<T>();
         }
         const T* xr = x + ((int64_t)b * H + (live[u] ? hh : 0)) * W * ldx + c;
 #pragma unroll
         for (int j = 0; j < TW + K - 1; ++j) {
           const int ww = w0 + j - R;
-          row[u][j] = (live[u] && ww >= 0 && ww < W) ? Io<T>::ld4(xr + (int64_t)ww * ldx) : f4zero();
+          row[u][j] = (live[u] && ww >= 0 && ww < W) ? cv_ld(xr + (int64_t)ww * ldx) : cv_zero<T>();
         }
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         if (i == R) {
 #pragma unroll
-          for (int p = 0; p < TW; ++p) { ab.x += g[u][p].x; ab.y += g[u][p].y; ab.z += g[u][p].z; ab.w += g[u][p].w; }
+          for (int p = 0; p < TW; ++p) cv_add(ab, g[u][p]);
         }
 #pragma unroll
         for (int j = 0; j < K; ++j)
 #pragma unroll
-          for (int p = 0; p < TW; ++p) fma4(aw[j], g[u][p], row[u][p + j]);
+          for (int p = 0; p < TW; ++p) cv_fma(aw[j], g[u][p], row[u][p + j]);
       }
     }
   }
   // fold the pixel slots of a wave, then the tile slices of the block (LDS), then write the block's partial row
 #pragma unroll
   for (int j = 0; j <= K; ++j) {
-    float4 v = j < K ? aw[j] : ab;
-    v.x = wave_sum_from(v.x, cgb); v.y = wave_sum_from(v.y, cgb);
-    v.z = wave_sum_from(v.z, cgb); v.w = wave_sum_from(v.w, cgb);
-    if (j < K) aw[j] = v; else ab = v;
+    V& v = j < K ? aw[j] : ab;
+#pragma unroll
+    for (int qq = 0; qq < V::Q; ++qq) {
+      v.q[qq].x = wave_sum_from(v.q[qq].x, cgb); v.q[qq].y = wave_sum_from(v.q[qq].y, cgb);
+      v.q[qq].z = wave_sum_from(v.q[qq].z, cgb); v.q[qq].w = wave_sum_from(v.q[qq].w, cgb);
+    }
   }
   if (sl == 1) {
 #pragma unroll
-    for (int j = 0; j <= K; ++j) *reinterpret_cast<float4*>(&red[i][j][lane][0]) = j < K ? aw[j] : ab;
+    for (int j = 0; j <= K; ++j) cv_stf<T>(&red[i][j][lane][0], j < K ? aw[j] : ab);
   }
   __syncthreads();
   if (sl == 0) {
@@ -211,15 +291,17 @@ __device__ __forceinline__ void dwconv_wgrad_body(const T* __restrict__ dpre, in
 #pragma unroll
     for (int j = 0; j <= K; ++j) {
       if (j == K && i != R) break;
-      float4 v = j < K ? aw[j] : ab;
-      const float4 o = *reinterpret_cast<const float4*>(&red[i][j][lane][0]);
-      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      V v = j < K ? aw[j] : ab;
+      cv_add(v, cv_ldf<T>(&red[i][j][lane][0]));
       if (lane < cgb && cv) {
         if (wcm && j < K) {   // channel-major partial row: column c*K*K + tap, so the fold emits nn.Conv2d's (C, K*K) layout
           float* q = dst + (int64_t)c * NT + i * K + j;
-          q[0] = v.x; q[NT] = v.y; q[2 * NT] = v.z; q[3 * NT] = v.w;
+#pragma unroll
+          for (int qq = 0; qq < V::Q; ++qq) {
+            q[(4 * qq) * NT] = v.q[qq].x; q[(4 * qq + 1) * NT] = v.q[qq].y; q[(4 * qq + 2) * NT] = v.q[qq].z; q[(4 * qq + 3) * NT] = v.q[qq].w;
+          }
         } else {
-          *reinterpret_cast<float4*>(dst + (int64_t)(j < K ? i * K + j : NT) * C + c) = v;
+          cv_stf<T>(dst + (int64_t)(j < K ? i * K + j : NT) * C + c, v);
         }
       }
     }
@@ -268,48 +350,49 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void dwconv_wgrad3_roll_kernel(const T* __restrict__ dpre, int64_t ldd, const T* __restrict__ x, int64_t ldx,
                                                                     float* __restrict__ part, int B, int H, int W, int C, int cgb, int SEG,
                                                                     int nseg, int wcm) {
-  constexpr int K = 3, NT = 9;
-  __shared__ __attribute__((aligned(16))) float red[kBlock / 64 - 1][NT + 1][64][4];
-  const int C4 = C >> 2;
+  constexpr int K = 3, NT = 9, N = CVec<T>::N;
+  using V = CVec<T>;
+  __shared__ __attribute__((aligned(16))) float red[kBlock / 64 - 1][NT + 1][64][N];
+  const int C4 = C / N;   // channel vectors per pixel
   const int WT = (W + TW - 1) / TW;
   const int cgl = threadIdx.x & (cgb - 1), sp = threadIdx.x / cgb, spb = kBlock / cgb;
   const int cg = blockIdx.x * cgb + cgl;
   const int64_t S = (int64_t)B * nseg * WT, sidx = (int64_t)blockIdx.y * spb + sp;
   const bool cv = cg < C4, live = cv && sidx < S;
-  const int c = cv ? cg * 4 : 0;
-  float4 aw[NT], ab = f4zero();
+  const int c = cv ? cg * N : 0;
+  V aw[NT], ab = cv_zero<T>();
 #pragma unroll
-  for (int k = 0; k < NT; ++k) aw[k] = f4zero();
+  for (int k = 0; k < NT; ++k) aw[k] = cv_zero<T>();
   if (live) {
     const int wt = (int)(sidx % WT), seg = (int)((sidx / WT) % nseg), b = (int)(sidx / ((int64_t)WT * nseg));
     const int h0 = seg * SEG, h1 = h0 + SEG < H ? h0 + SEG : H, w0 = wt * TW;
-    auto load_x = [&](int hh, float4 (&r)[TW + 2]) {
+    auto load_x = [&](int hh, V (&r)[TW + 2]) {
       const bool ok = hh >= 0 && hh < H;
       const T* xr = x + ((int64_t)b * H + (ok ? hh : 0)) * W * ldx + c;
 #pragma unroll
       for (int j = 0; j < TW + 2; ++j) {
         const int ww = w0 + j - 1;
-        r[j] = (ok && ww >= 0 && ww < W) ? Io<T>::ld4(xr + (int64_t)ww * ldx) : f4zero();
+        r[j] = (ok && ww >= 0 && ww < W) ? cv_ld(xr + (int64_t)ww * ldx) : cv_zero<T>();
       }
     };
-    auto step = [&](int h, const float4 (&r0)[TW + 2], const float4 (&r1)[TW + 2], const float4 (&r2)[TW + 2]) {
-      float4 g[TW];
+    auto step = [&](int h, const V (&r0)[TW + 2], const V (&r1)[TW + 2], const V (&r2)[TW + 2]) {
+      V g[TW];
 #pragma unroll
       for (int p = 0; p < TW; ++p) {
         const int ww = w0 + p;
-        g[p] = ww < W ? Io<T>::ld4(dpre + (((int64_t)b * H + h) * W + ww) * ldd + c) : f4zero();
-        ab.x += g[p].x; ab.y += g[p].y; ab.z += g[p].z; ab.w += g[p].w;
+        g[p] = ww < W ? cv_ld(dpre + (((int64_t)b * H + h) * W + ww) * ldd + c) : cv_zero<T>();
+        cv_add(ab, g[p]);
       }
 #pragma unroll
       for (int j = 0; j < K; ++j)
 #pragma unroll
         for (int p = 0; p < TW; ++p) {
-          fma4(aw[j], g[p], r0[p + j]);
-          fma4(aw[K + j], g[p], r1[p + j]);
-          fma4(aw[2 * K + j], g[p], r2[p + j]);
+          cv_fma(aw[j], g[p], r0[p + j]);
+          cv_fma(aw[K + j], g[p], r1[p + j]);
+          cv_fma(aw[2 * K + j], g[p], r2[p + j]);
         }
     };
-    float4 ra[TW + 2], rb[TW + 2], rc[TW + 2];
+    V ra[TW + 2], rb[TW + 2], rc[TW + 2];
     load_x(h0 - 1, ra);
     load_x(h0, rb);
     for (int h = h0; h < h1; h += 3) {   // three rows per trip so the window rotates by renaming, not by copying
@@ -328,35 +411,37 @@ __global__ __launch_bounds__(kBlock) void dwconv_wgrad3_roll_kernel(const T* __r
   // strips that share a wave (lanes differing in bits >= log2 cgb), then the waves through LDS
 #pragma unroll
   for (int k = 0; k <= NT; ++k) {
-    float4 v = k < NT ? aw[k] : ab;
-    v.x = wave_sum_from(v.x, cgb); v.y = wave_sum_from(v.y, cgb);
-    v.z = wave_sum_from(v.z, cgb); v.w = wave_sum_from(v.w, cgb);
-    if (k < NT) aw[k] = v; else ab = v;
+    V& v = k < NT ? aw[k] : ab;
+#pragma unroll
+    for (int qq = 0; qq < V::Q; ++qq) {
+      v.q[qq].x = wave_sum_from(v.q[qq].x, cgb); v.q[qq].y = wave_sum_from(v.q[qq].y, cgb);
+      v.q[qq].z = wave_sum_from(v.q[qq].z, cgb); v.q[qq].w = wave_sum_from(v.q[qq].w, cgb);
+    }
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wave > 0) {
 #pragma unroll
-    for (int k = 0; k <= NT; ++k) *reinterpret_cast<float4*>(&red[wave - 1][k][lane][0]) = k < NT ? aw[k] : ab;
+    for (int k = 0; k <= NT; ++k) cv_stf<T>(&red[wave - 1][k][lane][0], k < NT ? aw[k] : ab);
   }
   __syncthreads();
   if (wave == 0 && lane < cgb) {
-    // lanes 0..cgb-1 of wave 0 hold channel quads cgl = lane; lane l of every other wave holds the same quad iff (l & (cgb-1)) == lane,
-    // and after wave_sum_from all lanes of a quad hold the wave's total, so reading lane `lane` of each wave is enough
+    // lanes 0..cgb-1 of wave 0 hold channel vectors cgl = lane; lane l of every other wave holds the same vector iff (l & (cgb-1)) == lane,
+    // and after wave_sum_from all lanes of a vector hold the wave's total, so reading lane `lane` of each wave is enough
     float* dst = part + (int64_t)blockIdx.y * (NT + 1) * C;
 #pragma unroll
     for (int k = 0; k <= NT; ++k) {
-      float4 v = k < NT ? aw[k] : ab;
+      V v = k < NT ? aw[k] : ab;
 #pragma unroll
-      for (int wv = 0; wv < kBlock / 64 - 1; ++wv) {
-        const float4 o = *reinterpret_cast<const float4*>(&red[wv][k][lane][0]);
-        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-      }
+      for (int wv = 0; wv < kBlock / 64 - 1; ++wv) cv_add(v, cv_ldf<T>(&red[wv][k][lane][0]));
       if (cv) {
         if (wcm && k < NT) {
           float* q = dst + (int64_t)c * NT + k;
-          q[0] = v.x; q[NT] = v.y; q[2 * NT] = v.z; q[3 * NT] = v.w;
+#pragma unroll
+          for (int qq = 0; qq < V::Q; ++qq) {
+            q[(4 * qq) * NT] = v.q[qq].x; q[(4 * qq + 1) * NT] = v.q[qq].y; q[(4 * qq + 2) * NT] = v.q[qq].z; q[(4 * qq + 3) * NT] = v.q[qq].w;
+          }
         } else {
-          *reinterpret_cast<float4*>(dst + (int64_t)k * C + c) = v;
+          cv_stf<T>(dst + (int64_t)k * C + c, v);
         }
       }
     }
@@ -491,9 +576,9 @@ struct WGeo {
   int cgb, gx, npb, rows;
   int seg, nseg;   // 3x3 column walker: rows per strip, strips per image column (0 = tap-row kernel)
 };
-WGeo wgeo(int64_t B, int64_t H, int64_t W, int64_t C, int K) {
+WGeo wgeo(int64_t B, int64_t H, int64_t W, int64_t C, int K, int cn = 4) {   // cn: channels per lane (4 fp32 / 8 bf16)
   WGeo g;
-  const int64_t C4 = C / 4;
+  const int64_t C4 = C / cn;
   g.cgb = 1;
   while (g.cgb < 64 && g.cgb < C4) g.cgb <<= 1;
   g.gx = (int)adnm_cdiv(C4, g.cgb);
@@ -568,6 +653,7 @@ int check(const char* who, const void* x, int64_t B, int64_t H, int64_t W, int64
   ADNM_REQUIRE(KH == KW && (KH == 3 || KH == 5), "%s: kernel %dx%d not in {3x3, 5x5}", who, KH, KW);
   ADNM_REQUIRE(act >= ADNM_ACT_NONE && act <= ADNM_ACT_GELU, "%s: bad activation %d", who, act);
   ADNM_REQUIRE(dtype == ADNM_F32 || dtype == ADNM_BF16, "%s: bad dtype %d", who, dtype);
+  ADNM_REQUIRE(dtype == ADNM_F32 || C % 8 == 0, "%s: bf16 tokens move 8 channels (16 bytes) per lane: C=%lld must be a multiple of 8", who, (long long)C);
   ADNM_REQUIRE(B * H * W * C < (1ll << 40), "%s: tensor too large", who);
   return ADNM_OK;
 }
@@ -575,7 +661,7 @@ int check(const char* who, const void* x, int64_t B, int64_t H, int64_t W, int64
 template <typename T, int MODE>
 void launch_conv(const void* x, int64_t ldx, const float* wgt, const float* bias, const void* aux, int64_t ldaux, void* y, int64_t ldy,
                  int64_t B, int64_t H, int64_t W, int64_t C, int K, int act, int wcm, hipStream_t st) {
-  const int64_t total = B * H * adnm_cdiv(W, TW) * (C / 4);
+  const int64_t total = B * H * adnm_cdiv(W, TW) * (C / CVec<T>::N);
   const unsigned grid = (unsigned)adnm_cdiv(total, kBlock);
 #define ADNM_DWCONV(KK, WCMV)                                                                                                       \
   dwconv_kernel<T, KK, MODE, WCMV><<<grid, kBlock, 0, st>>>((const T*)x, ldx, wgt, bias, (const T*)aux, ldaux, (T*)y, ldy, (int)B, (int)H, \
@@ -609,7 +695,7 @@ void launch_wgrad(const void* dpre, int64_t ldd, const void* x, int64_t ldx, flo
     adnm_launch_fold("dwconv_wgrad_fold", part, g.rows, 26 * (int)C, {dwgt, 25 * (int)C}, {dbias, (int)C}, {nullptr, 0}, {nullptr, 0}, st);
     return;
   }
-  const WGeo g = wgeo(B, H, W, C, K);
+  const WGeo g = wgeo(B, H, W, C, K, CVec<T>::N);
   const dim3 grid(g.gx, g.npb);
   if (K == 3 && g.seg > 0)
     { ADNM_PROF("dwconv_wgrad_k3", st, (double)sizeof(T) * B * H * W * C * 2); dwconv_wgrad3_roll_kernel<T><<<grid, kBlock, 0, st>>>((const T*)dpre, ldd, (const T*)x, ldx, part, (int)B, (int)H, (int)W, (int)C, g.cgb, g.seg, g.nseg, wcm); }
@@ -642,8 +728,10 @@ extern "C" int adnm_dwconv_fwd(const void* x, int64_t ldx, const float* wgt, con
   if (int rc = check("dwconv_fwd", x, B, H, W, C, KH, KW, act, dtype)) return rc;
   ADNM_REQUIRE(wgt && y, "dwconv_fwd: null pointer");
   ADNM_REQUIRE(wlayout == 0 || wlayout == 1, "dwconv_fwd: weight layout %d not in {0 tap-major, 1 channel-major}", wlayout);
-  ADNM_REQUIRE(ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0 && (!addend || (ldadd >= C && ldadd % 4 == 0)),
-               "dwconv_fwd: pixel strides must be >= C and multiples of 4");
+  const int al = dtype == ADNM_BF16 ? 8 : 4;   // elements per 16-byte lane access
+  ADNM_REQUIRE(ldx >= C && ldy >= C && ldx % al == 0 && ldy % al == 0 && (!addend || (ldadd >= C && ldadd % al == 0)) &&
+                   ((uintptr_t)x | (uintptr_t)y | (uintptr_t)addend) % 16 == 0,
+               "dwconv_fwd: pixel strides must be >= C, rows and strides 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == ADNM_F32) launch_conv<float, 0>(x, ldx, wgt, bias, addend, ldadd, y, ldy, B, H, W, C, KH, act, wlayout, st);
   else launch_conv<uint16_t, 0>(x, ldx, wgt, bias, addend, ldadd, y, ldy, B, H, W, C, KH, act, wlayout, st);
@@ -654,6 +742,10 @@ extern "C" int adnm_dwconv_fwd(const void* x, int64_t ldx, const float* wgt, con
 extern "C" int64_t adnm_dwconv_bwd_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t C, int KH, int KW) {
   if (B <= 0 || H <= 0 || W <= 0 || C < 4) return 0;
   int64_t rows = wgeo(B, H, W, C, KH).rows;
+  if (C % 8 == 0) {   // (the query does not know the storage type: bf16 tokens move 8 channels per lane, another geometry)
+    const int64_t r8 = wgeo(B, H, W, C, KH, 8).rows;
+    rows = r8 > rows ? r8 : rows;
+  }
   if (KH == 5) {   // (the query does not know the storage type: fp32 tokens take the column walker's geometry)
     const int64_t r5 = wgeo_walk5(B, H, W, C).rows;
     rows = r5 > rows ? r5 : rows;
@@ -668,8 +760,10 @@ extern "C" int adnm_dwconv_bwd(const void* dy, int64_t lddy, const void* x, int6
   ADNM_REQUIRE(dy && wgt && dx, "dwconv_bwd: null pointer");
   ADNM_REQUIRE(wlayout == 0 || wlayout == 1, "dwconv_bwd: weight layout %d not in {0 tap-major, 1 channel-major}", wlayout);
   ADNM_REQUIRE(act == ADNM_ACT_NONE || dpre, "dwconv_bwd: dpre scratch required when an activation is fused");
-  ADNM_REQUIRE(ldx >= C && lddy >= C && lddx >= C && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0,
-               "dwconv_bwd: pixel strides must be >= C and multiples of 4");
+  const int al = dtype == ADNM_BF16 ? 8 : 4;   // elements per 16-byte lane access
+  ADNM_REQUIRE(ldx >= C && lddy >= C && lddx >= C && ldx % al == 0 && lddy % al == 0 && lddx % al == 0 &&
+                   ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dpre) % 16 == 0,
+               "dwconv_bwd: pixel strides must be >= C, rows and strides 16-byte aligned");
   if (!ws || ws_bytes < adnm_dwconv_bwd_ws_bytes(B, H, W, C, KH, KW)) {
     adnm_set_error("dwconv_bwd: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_dwconv_bwd_ws_bytes(B, H, W, C, KH, KW));
     return ADNM_EWORKSPACE;
@@ -703,7 +797,9 @@ extern "C" int adnm_dwconv_wgrad(const void* g, int64_t ldg, const void* x, int6
   if (int rc = check("dwconv_wgrad", x, B, H, W, C, KH, KW, ADNM_ACT_NONE, dtype)) return rc;
   ADNM_REQUIRE(g && dwgt, "dwconv_wgrad: null pointer");
   ADNM_REQUIRE(wlayout == 0 || wlayout == 1, "dwconv_wgrad: weight layout %d not in {0 tap-major, 1 channel-major}", wlayout);
-  ADNM_REQUIRE(ldx >= C && ldg >= C && ldx % 4 == 0 && ldg % 4 == 0, "dwconv_wgrad: pixel strides must be >= C and multiples of 4");
+  const int al = dtype == ADNM_BF16 ? 8 : 4;   // elements per 16-byte lane access
+  ADNM_REQUIRE(ldx >= C && ldg >= C && ldx % al == 0 && ldg % al == 0 && ((uintptr_t)x | (uintptr_t)g) % 16 == 0,
+               "dwconv_wgrad: pixel strides must be >= C, rows and strides 16-byte aligned");
   if (!ws || ws_bytes < adnm_dwconv_bwd_ws_bytes(B, H, W, C, KH, KW)) {
     adnm_set_error("dwconv_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)adnm_dwconv_bwd_ws_bytes(B, H, W, C, KH, KW));
     return ADNM_EWORKSPACE;

@@ -129,7 +129,13 @@ extern "C" int adnm_wt_level(const float* x, int64_t ldx, int64_t cx, const floa
   a.x = x, a.ldx = ldx, a.taps = taps, a.sub = sub, a.tag = tag;
   a.B = (int)B, a.H = (int)H, a.W = (int)W, a.C = (int)C, a.h2 = (int)((H + 1) / 2), a.w2 = (int)((W + 1) / 2);
   a.tiles_x = (a.w2 + kT - 1) / kT;
+  // input channels per workgroup: as many as divide C (<= 32: the LDS tile), but on the small maps fewer, so that the grid still has ~256
+  // workgroups — 8 x 8 sub-band tiles of a 32 x 32 map with 32-channel blocks are 64 workgroups walking five items each on a 256-CU part
   a.CB = C % 32 == 0 ? 32 : (C % 16 == 0 ? 16 : (C % 8 == 0 ? 8 : 4));
+  {
+    const int64_t tiles = (int64_t)a.tiles_x * ((a.h2 + kT - 1) / kT) * B;
+    while (a.CB > 4 && tiles * (C / a.CB) < 256) a.CB >>= 1;
+  }
   hipStream_t st = (hipStream_t)stream;
   ADNM_PROF("wt_level", st, 4.0 * B * (H * W * C + 2.0 * a.h2 * a.w2 * 4 * C));
   int rc;

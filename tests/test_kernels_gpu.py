@@ -1212,3 +1212,29 @@ def test_adamw_writes_the_shadows():
             assert float(tab[k, 3]) == float(p[o:end].abs().max()), f"max |p| of tensor {k}"
         else:
             assert float(tab[1, 3]) == 0.0 and float(tab[3, 3]) == 0.0
+
+
+@pytest.mark.parametrize("B,H,W,C,K,act,bias", [(2, 16, 16, 32, 3, lib.ACT_SILU, False), (1, 131, 130, 24, 3, lib.ACT_NONE, True), (2, 64, 64, 192, 3, lib.ACT_SILU, False),
+                                                (1, 9, 11, 16, 5, lib.ACT_GELU, True), (4, 128, 128, 128, 3, lib.ACT_NONE, True)])
+def test_dwconv_bf16_tokens(B, H, W, C, K, act, bias):
+    """bf16 token storage (the wide internals of the full-resolution level): a lane moves 8 channels = 16 bytes per pixel; arithmetic in
+    fp32 on the bf16 values, the results rounded once when stored; the tap / bias gradients stay fp32."""
+    x, w = T("dwb.x", (B, H * W, C)), T("dwb.w", (C, 1, K, K), 0.5)
+    b = T("dwb.b", (C,), 0.3) if bias else None
+    cot = T("dwb.c", (B, H * W, C))
+    xr, cr = _bf16_round(x), _bf16_round(cot)
+    xo, wo = leaf(xr.double()), leaf(w.double())
+    bo = leaf(b.double()) if bias else None
+    pre = F.conv2d(O.img(xo, H, W), wo, bo, padding=K // 2, groups=C)
+    yo = O.seq({lib.ACT_NONE: lambda t: t, lib.ACT_SILU: O.silu, lib.ACT_GELU: O.gelu}[act](pre))
+    (yo * cr.double()).sum().backward()
+    xg, wg = leaf(xr.to(torch.bfloat16), DEV), leaf(w, DEV)
+    bg = leaf(b, DEV) if bias else None
+    yg = ops.dwconv(xg, wg, bg, H, W, act)
+    assert yg.dtype == torch.bfloat16
+    (yg.float() * cr.to(DEV)).sum().backward()
+    assert_close(yg.float(), yo, 4e-3, "y (one rounding to bf16)")
+    assert_close(xg.grad.float(), xo.grad, 8e-3, "dx (bf16 pre-activation gradient, one more rounding)")
+    assert_close(wg.grad, wo.grad, 8e-3, "dw")
+    if bias:
+        assert_close(bg.grad, bo.grad, 8e-3, "db")
