@@ -165,6 +165,15 @@ class QuantTable:
                     ent["tab"].zero_()
                 ent["state"].copy_(torch.tensor([0.0, float(self.period)]))
 
+    def snapshot(self, device):
+        ent = self._ent(device)
+        return ent["tab"].clone(), ent["state"].clone()
+
+    def restore(self, device, snap):
+        ent = self._ent(device)
+        ent["tab"].copy_(snap[0])
+        ent["state"].copy_(snap[1])
+
     def pin(self, device):
         """a captured graph that may hold record pointers of this device's table now exists (see reset())"""
         with self._lock:
@@ -341,7 +350,7 @@ class GradRegistry:
                 if second:
                     self._multi[owner].add(ptr)
         if second:   # autograd is about to ADD this contribution to the first one: both must be complete when it does
-            FOLDS.flush(device)
+            FOLDS.flush(device, on_main=True)
             FOLDS.hold(device)   # ... so the producer of this one must not defer its fold either
         return torch.empty(tuple(shape), dtype=dtype, device=device)
 
@@ -415,18 +424,59 @@ class FoldRegistry:
             with self._lock:
                 ent["keep"].clear()
 
-    def flush(self, device):
+    def flush(self, device, on_main=False):
+        """Issue the queued leaf launches and folds.  With the side stream on (SideStreams) they go THERE — forked from the current stream's
+        present, joined only at the end of the backward pass — unless the caller reads the results on the current stream right away
+        (on_main: a second claim of a gradient slice); the parameter-prep backward nodes, the other readers, move to the side stream
+        themselves (late())."""
         ent = self._q.get(device.index)
         if ent is None:
             return
+        sent = None if on_main else SIDE.live(device)
         with torch.cuda.device(device):
+            if sent is not None:
+                SIDE._launch(sent)   # what was collected for the side stream first, in submission order
+                SIDE.fork(sent)      # everything the queued launches read exists on the current stream by now
+                with torch.cuda.stream(sent["stream"]):
+                    self._issue(ent)
+                with self._lock:     # the workspaces / operands of what now runs beside the main stream: alive until the join
+                    sent["keep"].extend(ent["keep"])
+                    ent["keep"].clear()
+                return
             SIDE.join(device)   # queued folds (and whoever asked for the flush) read what weight-gradient kernels wrote on the side stream
-            if ent["lh"] is not None and lib.query("adnm_leafq_pending", ent["lh"]) > 0:
-                lib.call("adnm_leafq_flush", ent["lh"], _stream())   # the grouped leaf launches first: the folds read their partials
-            if lib.query("adnm_foldq_pending", ent["h"]) > 0:
-                lib.call("adnm_foldq_flush", ent["h"], _stream())
+            self._issue(ent)
         with self._lock:
             ent["keep"].clear()
+
+    @staticmethod
+    def _issue(ent):
+        if ent["lh"] is not None and lib.query("adnm_leafq_pending", ent["lh"]) > 0:
+            lib.call("adnm_leafq_flush", ent["lh"], _stream())   # the grouped leaf launches first: the folds read their partials
+        if lib.query("adnm_foldq_pending", ent["h"]) > 0:
+            lib.call("adnm_foldq_flush", ent["h"], _stream())
+
+    def late(self, device):
+        """with FOLDS.late(dev): <launch a kernel that reads deferred fold results and writes only parameter gradients> — the flush and the
+        body run on the side stream when it is on (the parameter-prep backward nodes), else on the current stream."""
+        return _Late(self, device)
+
+
+class _Late:
+    def __init__(self, reg, device):
+        self.reg, self.device, self.ctx = reg, device, None
+
+    def __enter__(self):
+        self.reg.flush(self.device)
+        sent = SIDE.live(self.device)
+        if sent is not None:
+            self.ctx = torch.cuda.stream(sent["stream"])
+            self.ctx.__enter__()
+            sent["dirty"] = True
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 class _Active:
@@ -496,6 +546,29 @@ class SideStreams:
             if ent is None:
                 ent = self._s[device.index] = {"stream": torch.cuda.Stream(device=device), "on": False, "dirty": False, "keep": [], "pending": []}
         return ent
+
+    def live(self, device):
+        """the device's entry while the side stream is ON (inside a trainer's backward pass), else None"""
+        ent = self._s.get(device.index)
+        return ent if ent is not None and ent["on"] else None
+
+    def keep(self, device, *tensors):
+        """hold tensors a side-stream kernel reads until the join (no-op with the side stream off)"""
+        ent = self.live(device)
+        if ent is not None:
+            with self._lock:
+                for t in tensors:
+                    if isinstance(t, (list, tuple)):
+                        ent["keep"].extend(x for x in t if x is not None)
+                    elif t is not None:
+                        ent["keep"].append(t)
+
+    def fork(self, ent):
+        """the side stream waits for everything enqueued on the current stream so far"""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(ent["stream"].device))
+        ent["stream"].wait_event(ev)
+        ent["dirty"] = True
 
     def submit(self, device, keep, deferred, fn):
         """fn() makes the library call on torch's CURRENT stream (it must read _stream() itself) inside `deferred` (a FOLDS.defer(...)
@@ -1647,15 +1720,15 @@ class AdnPrepFn(torch.autograd.Function):
         params = ctx.saved_tensors
         dm, di, gn, P = ctx.dims
         cx = di + 2 * gn
-        FOLDS.flush(params[0].device)   # the incoming gradients are (deferred) fold results of the mixer's backward
-        g_w_in, g_taps, g_ln_w, g_ln_b, g_w_out = (g.contiguous() for g in (g_w_in, g_taps, g_ln_w, g_ln_b, g_w_out))
-        gouts = [g_w_in, g_taps[:, di:], g_taps[:, :di], g_ln_w, g_ln_b, g_w_out]
-        dparams = [grad_dst(p.data_ptr(), p.shape, p.device, p.dtype) for p in params]
-        nb = lib.query("adnm_adnprep_bwd_ws_bytes")
-        ws = _ws(nb, params[0].device)
-        with FOLDS.defer(params[0].device, ws, g_w_in, g_taps, g_ln_w, g_ln_b, g_w_out):
-            lib.call("adnm_adnprep_bwd", lib.ptr_table(params), lib.ptr_table(gouts), lib.ptr_table(dparams), dm, di, gn, P, di + cx,
-                     ws.data_ptr(), nb, _stream())
+        with FOLDS.late(params[0].device):   # the incoming gradients are (deferred) fold results of the mixer's backward
+            g_w_in, g_taps, g_ln_w, g_ln_b, g_w_out = (g.contiguous() for g in (g_w_in, g_taps, g_ln_w, g_ln_b, g_w_out))
+            gouts = [g_w_in, g_taps[:, di:], g_taps[:, :di], g_ln_w, g_ln_b, g_w_out]
+            dparams = [grad_dst(p.data_ptr(), p.shape, p.device, p.dtype) for p in params]
+            nb = lib.query("adnm_adnprep_bwd_ws_bytes")
+            ws = _ws(nb, params[0].device)
+            with FOLDS.defer(params[0].device, ws, g_w_in, g_taps, g_ln_w, g_ln_b, g_w_out):
+                lib.call("adnm_adnprep_bwd", lib.ptr_table(params), lib.ptr_table(gouts), lib.ptr_table(dparams), dm, di, gn, P, di + cx,
+                         ws.data_ptr(), nb, _stream())
         return (None, None, None, None, *dparams)
 
 
@@ -1687,15 +1760,16 @@ class WtPrepFn(torch.autograd.Function):
         n = 1 + levels
         saved = ctx.saved_tensors
         bias, w, s = saved[0], saved[1:1 + n], saved[1 + n:]
-        FOLDS.flush(w[0].device)   # the incoming tap gradients are (deferred) fold results of the depthwise weight-gradient kernels
-        gtaps = [g.contiguous() for g in gtaps]
-        dw = [torch.empty_like(t) for t in w]
-        ds = [torch.empty_like(t) for t in s]
-        dbias = torch.empty_like(bias) if bias is not None else None
-        if bias is not None:
-            gbias_t = gbias_t.contiguous() if gbias_t is not None else torch.zeros(Cp, dtype=torch.float32, device=bias.device)
-        lib.call("adnm_wtprep_bwd", lib.ptr_table(w), lib.ptr_table(s), _p(bias), lib.ptr_table(gtaps), _p(gbias_t) if bias is not None else None,
-                 lib.ptr_table(dw), lib.ptr_table(ds), _p(dbias), C, Cp, K, levels, _stream())
+        with FOLDS.late(w[0].device):   # the incoming tap gradients are (deferred) fold results of the depthwise weight-gradient kernels
+            gtaps = [g.contiguous() for g in gtaps]
+            dw = [torch.empty_like(t) for t in w]
+            ds = [torch.empty_like(t) for t in s]
+            dbias = torch.empty_like(bias) if bias is not None else None
+            if bias is not None:
+                gbias_t = gbias_t.contiguous() if gbias_t is not None else torch.zeros(Cp, dtype=torch.float32, device=bias.device)
+            lib.call("adnm_wtprep_bwd", lib.ptr_table(w), lib.ptr_table(s), _p(bias), lib.ptr_table(gtaps), _p(gbias_t) if bias is not None else None,
+                     lib.ptr_table(dw), lib.ptr_table(ds), _p(dbias), C, Cp, K, levels, _stream())
+            SIDE.keep(w[0].device, gtaps, gbias_t)
         return (None, None, None, None, dbias, *dw, *ds)
 
 
@@ -1771,22 +1845,22 @@ class AdnPrepMultiFn(torch.autograd.Function):
         dims = ctx.dims
         n = len(dims)
         dev = params[0].device
-        FOLDS.flush(dev)   # the incoming gradients are (deferred) fold results of the mixers' backward
-        gtab, dflat, keep = [], [], []
-        for i, (dm, di, gn, P) in enumerate(dims):
-            nh, cx = di // P, di + 2 * gn
-            shapes = [(2 * di + 2 * gn + nh, dm), (9, di + cx), (di,), (di,), (dm, 2 * di)]
-            gi = [t.contiguous() if t is not None else torch.zeros(shp, dtype=torch.float32, device=dev) for t, shp in zip(g[9 * i:9 * i + 5], shapes)]
-            keep += gi
-            g_w_in, g_taps, g_ln_w, g_ln_b, g_w_out = gi
-            gtab += [g_w_in, g_taps[:, di:], g_taps[:, :di], g_ln_w, g_ln_b, g_w_out]
-            dflat += [dm, di, gn, P, 2 * di + 2 * gn]
-        dparams = [grad_dst(p.data_ptr(), p.shape, dev, p.dtype) for p in params]
-        nb = lib.query("adnm_adnprep_bwd_multi_ws_bytes", n)
-        ws = _ws(nb, dev)
-        with FOLDS.defer(dev, ws, *keep):
-            lib.call("adnm_adnprep_bwd_multi", n, lib.ptr_table(params), lib.ptr_table(gtab), lib.ptr_table(dparams), lib.i64_table(dflat),
-                     ws.data_ptr(), nb, _stream())
+        with FOLDS.late(dev):   # the incoming gradients are (deferred) fold results of the mixers' backward
+            gtab, dflat, keep = [], [], []
+            for i, (dm, di, gn, P) in enumerate(dims):
+                nh, cx = di // P, di + 2 * gn
+                shapes = [(2 * di + 2 * gn + nh, dm), (9, di + cx), (di,), (di,), (dm, 2 * di)]
+                gi = [t.contiguous() if t is not None else torch.zeros(shp, dtype=torch.float32, device=dev) for t, shp in zip(g[9 * i:9 * i + 5], shapes)]
+                keep += gi
+                g_w_in, g_taps, g_ln_w, g_ln_b, g_w_out = gi
+                gtab += [g_w_in, g_taps[:, di:], g_taps[:, :di], g_ln_w, g_ln_b, g_w_out]
+                dflat += [dm, di, gn, P, 2 * di + 2 * gn]
+            dparams = [grad_dst(p.data_ptr(), p.shape, dev, p.dtype) for p in params]
+            nb = lib.query("adnm_adnprep_bwd_multi_ws_bytes", n)
+            ws = _ws(nb, dev)
+            with FOLDS.defer(dev, ws, *keep):
+                lib.call("adnm_adnprep_bwd_multi", n, lib.ptr_table(params), lib.ptr_table(gtab), lib.ptr_table(dparams), lib.i64_table(dflat),
+                         ws.data_ptr(), nb, _stream())
         return (None, *dparams)
 
 
@@ -1825,25 +1899,26 @@ class WtPrepMultiFn(torch.autograd.Function):
         dims = ctx.dims
         saved = ctx.saved_tensors
         dev = saved[0].device
-        FOLDS.flush(dev)   # the incoming tap gradients are (deferred) fold results of the depthwise weight-gradient kernels
-        w, s, bias, gtaps, gbias_t, dw, ds, dbias, dflat, grads = [], [], [], [], [], [], [], [], [], []
-        si, gi = iter(saved), iter(g)
-        for C, Cp, K, levels, has_bias in dims:
-            n1 = 1 + levels
-            b = next(si) if has_bias else None
-            ws_ = [next(si) for _ in range(n1)]
-            ss = [next(si) for _ in range(n1)]
-            gb = next(gi).contiguous() if has_bias else None
-            gt = [next(gi).contiguous() for _ in range(n1)]
-            dws, dss = [torch.empty_like(t) for t in ws_], [torch.empty_like(t) for t in ss]
-            db = torch.empty_like(b) if has_bias else None
-            pad = [None] * (5 - n1)
-            w += list(ws_) + pad; s += list(ss) + pad; gtaps += gt + pad; dw += dws + pad; ds += dss + pad
-            bias.append(b); gbias_t.append(gb); dbias.append(db)
-            dflat += [C, Cp, K, levels]
-            grads += ([db] if has_bias else []) + dws + dss
-        lib.call("adnm_wtprep_bwd_multi", len(dims), lib.ptr_table(w), lib.ptr_table(s), lib.ptr_table(bias), lib.ptr_table(gtaps), lib.ptr_table(gbias_t),
-                 lib.ptr_table(dw), lib.ptr_table(ds), lib.ptr_table(dbias), lib.i64_table(dflat), _stream())
+        with FOLDS.late(dev):   # the incoming tap gradients are (deferred) fold results of the depthwise weight-gradient kernels
+            w, s, bias, gtaps, gbias_t, dw, ds, dbias, dflat, grads = [], [], [], [], [], [], [], [], [], []
+            si, gi = iter(saved), iter(g)
+            for C, Cp, K, levels, has_bias in dims:
+                n1 = 1 + levels
+                b = next(si) if has_bias else None
+                ws_ = [next(si) for _ in range(n1)]
+                ss = [next(si) for _ in range(n1)]
+                gb = next(gi).contiguous() if has_bias else None
+                gt = [next(gi).contiguous() for _ in range(n1)]
+                dws, dss = [torch.empty_like(t) for t in ws_], [torch.empty_like(t) for t in ss]
+                db = torch.empty_like(b) if has_bias else None
+                pad = [None] * (5 - n1)
+                w += list(ws_) + pad; s += list(ss) + pad; gtaps += gt + pad; dw += dws + pad; ds += dss + pad
+                bias.append(b); gbias_t.append(gb); dbias.append(db)
+                dflat += [C, Cp, K, levels]
+                grads += ([db] if has_bias else []) + dws + dss
+            lib.call("adnm_wtprep_bwd_multi", len(dims), lib.ptr_table(w), lib.ptr_table(s), lib.ptr_table(bias), lib.ptr_table(gtaps), lib.ptr_table(gbias_t),
+                     lib.ptr_table(dw), lib.ptr_table(ds), lib.ptr_table(dbias), lib.i64_table(dflat), _stream())
+            SIDE.keep(dev, gtaps, gbias_t)
         return (None, *grads)
 
 

@@ -236,6 +236,7 @@ class FlatTrainer:
         were finalised by the cyclic GC in the middle of a NEW trainer's warm-up / stream capture: destroying a hipGraph (and
         freeing its private pool) while another capture is in flight on the device is not allowed by the runtime.  prepare()
         therefore also collects BEFORE it starts and keeps the collector off until both captures have ended."""
+        self.tail = None
         self.graphs = []
         self.graph2 = None
         self.graph = None
@@ -425,15 +426,58 @@ class FlatTrainer:
                     self.static_loss = self._fwd_bwd(self.sx, self.st)
                     self._gather()
             else:
+                # each stage graph ends with the wire cast of ITS bucket (bf16 wire): a step at N > 1 is then K graph replays + K collective
+                # calls + the tail graph below, nothing else is launched from the host
                 with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                     self.static_loss = self._stage_part0(self.sx, self.st)
+                    self._wire_cast(0)
                 self.graphs = []   # same memory pool: every part reads what the parts before saved for it
                 for j in range(1, len(self.stage_defs)):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, pool=self.graph.pool(), capture_error_mode="thread_local"):
                         self._stage_part(j)
+                        self._wire_cast(j)
                     self.graphs.append(g)
                 self.graph2 = self.graphs[0] if self.graphs else None
+            # the tail of a step: (bf16 wire: averages back to fp32) -> fp8 scale update -> clip + AdamW (+ shadow), with the learning rate and
+            # the clip threshold in device memory (self.hyper) so that the captured launches follow the host's schedules
+            self.tail = None
+            if self.fused and self.staged:
+                self.hyper = torch.tensor([self.lr, self.max_norm], dtype=torch.float32, device=x.device)
+                self._hyper_host = (float(self.lr), float(self.max_norm))
+                keep = (self.flat_p.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.state.clone(), self.flat_g.clone(),
+                        self.shadow.clone() if getattr(self, "shadow", None) is not None else None)
+                qsave = ops.QUANT.snapshot(x.device) if self.fp8 else None
+                side2 = torch.cuda.Stream()
+                side2.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side2):
+                    self._tail_body()   # warm-up outside capture
+                torch.cuda.current_stream().wait_stream(side2)
+                self.tail = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.tail, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                    self._tail_body()
+                # the warm-up advanced the optimiser once: put everything back
+                for dst, src in zip((self.flat_p, self.exp_avg, self.exp_avg_sq, self.state, self.flat_g, getattr(self, "shadow", None)), keep):
+                    if src is not None:
+                        dst.copy_(src)
+                if qsave is not None:
+                    ops.QUANT.restore(x.device, qsave)
+
+    def _wire_cast(self, j):
+        """fp32 -> bf16 copy of bucket j into the wire buffer (captured at the end of stage graph j)"""
+        if self.world > 1 and self.reduce_dtype == "bf16":
+            lo, hi = self.buckets[j]
+            if hi > lo:
+                self._cast(self.flat_g[lo:hi], self.comm[lo:hi])
+
+    def _tail_body(self):
+        if self.world > 1 and self.reduce_dtype == "bf16":
+            for lo, hi in self.buckets:
+                if hi > lo:
+                    self._cast(self.comm[lo:hi], self.flat_g[lo:hi], 1.0 / self.world)
+        if getattr(self, "fp8", False):
+            ops.QUANT.update(self.flat_g.device)
+        self._optimizer_step(hyper=True)
 
     def _run_eager(self, x, tgt, between=None):
         """between(j): called after part j (its bucket is complete) while parts remain — the N > 1 flow starts the bucket's all-reduce there"""
@@ -457,7 +501,7 @@ class FlatTrainer:
         else:
             dst.copy_(src.to(dst.dtype) if scale == 1.0 else (src.float() * scale).to(dst.dtype))
 
-    def _reduce_begin(self, lo, hi, pending):
+    def _reduce_begin(self, lo, hi, pending, cast_done=False):
         """Start averaging flat_g[lo:hi] over the ranks.  RCCL: asynchronously on its own stream (it first waits for what the
         compute stream has enqueued so far, i.e. the graph that produced the range), so the next graph runs beside the ring."""
         if self.world == 1 or hi <= lo:
@@ -465,7 +509,8 @@ class FlatTrainer:
         nccl = dist.get_backend(self.group) == "nccl"
         if self.reduce_dtype == "bf16":
             t = self.comm[lo:hi]
-            self._cast(self.flat_g[lo:hi], t)
+            if not cast_done:   # (the stage graphs end with their bucket's cast)
+                self._cast(self.flat_g[lo:hi], t)
             op = dist.ReduceOp.SUM
         else:
             t = self.flat_g[lo:hi]
@@ -473,9 +518,12 @@ class FlatTrainer:
         work = dist.all_reduce(t, op=op, group=self.group, async_op=True)
         pending.append((work, lo, hi, nccl))
 
-    def _reduce_end(self, pending):
+    def _reduce_end(self, pending, tail=False):
+        """tail: the casts back / the division are part of the captured tail graph"""
         for work, lo, hi, nccl in pending:
             work.wait()   # the compute stream waits for the ring; the host does not block (RCCL)
+            if tail and self.reduce_dtype == "bf16":
+                continue
             if self.reduce_dtype == "bf16":
                 self._cast(self.comm[lo:hi], self.flat_g[lo:hi], 1.0 / self.world)
             elif not nccl:
@@ -489,18 +537,20 @@ class FlatTrainer:
             self.prepare(x, tgt)
         pending = []
         nb = len(self.buckets)
+        graphed = False
         if self.graph is not None and not eager:
             if x.data_ptr() != self.sx.data_ptr():
                 self.sx.copy_(x, non_blocking=True)
                 self.st.copy_(tgt, non_blocking=True)
             self.graph.replay()
-            self._reduce_begin(*self.buckets[0], pending)
+            self._reduce_begin(*self.buckets[0], pending, cast_done=self.staged)
             if self.staged:
                 for j, g in enumerate(self.graphs, start=1):
                     g.replay()
                     if j < nb:
-                        self._reduce_begin(*self.buckets[j], pending)
+                        self._reduce_begin(*self.buckets[j], pending, cast_done=True)
             loss = self.static_loss
+            graphed = True
         else:
             for p in self.used:
                 p.grad = None
@@ -512,16 +562,23 @@ class FlatTrainer:
                 self._reduce_begin(*self.buckets[0], pending)
             for p in self.used:
                 p.grad = None
-        self._reduce_end(pending)
-        if getattr(self, "fp8", False):
-            # one launch: amax -> scales on calibration steps, the next step's record flags.  BEFORE the optimiser pass: that pass writes the
-            # e4m3 shadow of the updated weights with the scales the next step's GEMMs will read
-            ops.QUANT.update(self.flat_g.device)
-        self._optimizer_step()
+        tail = graphed and getattr(self, "tail", None) is not None and (self.world == 1 or self.reduce_dtype == "bf16" or dist.get_backend(self.group) == "nccl")
+        self._reduce_end(pending, tail=tail)
+        if tail:
+            if (float(self.lr), float(self.max_norm)) != self._hyper_host:   # a schedule moved them: two floats to the device
+                self._hyper_host = (float(self.lr), float(self.max_norm))
+                self.hyper.copy_(torch.tensor(self._hyper_host, dtype=torch.float32), non_blocking=True)
+            self.tail.replay()
+        else:
+            if getattr(self, "fp8", False):
+                # one launch: amax -> scales on calibration steps, the next step's record flags.  BEFORE the optimiser pass: that pass writes
+                # the e4m3 shadow of the updated weights with the scales the next step's GEMMs will read
+                ops.QUANT.update(self.flat_g.device)
+            self._optimizer_step()
         self._steps += 1
         return loss
 
-    def _optimizer_step(self):
+    def _optimizer_step(self, hyper=False):
         if self.fused:
             mode = getattr(self, "shadow_mode", 0)
             sh = (self.shadow.data_ptr(), mode, self.seg_end.data_ptr(), self.seg_rec.data_ptr(), self.seg_end.numel(),
@@ -529,7 +586,7 @@ class FlatTrainer:
             lib.call("adnm_adamw_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                      self.exp_avg_sq.data_ptr(), self.n, self.state.data_ptr(), float(self.lr), float(self.betas[0]), float(self.betas[1]),
                      float(self.eps), float(self.wd), float(self.max_norm), self.ws.data_ptr(), self.ws.numel(), *sh,
-                     torch.cuda.current_stream().cuda_stream)
+                     self.hyper.data_ptr() if hyper else None, torch.cuda.current_stream().cuda_stream)
         else:
             self._torch_adamw_for_tests()
 

@@ -17,7 +17,7 @@ void adnm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* adnm_last_error(void) { return g_err; }
-extern "C" int adnm_abi_version(void) { return 9; }   // 9: the split-K workspace is the caller's (ws_uncached of adnm_skgemm, adnm_uncached_alloc / _free; the per-device rings are gone); 8: adnm_mixnorm_*, adnm_bridge_pool_* (adnm_tokmean_* gone), up1 / up2 of adnm_haar_idwt; 7: precision ladder (`q` of the GEMM-shaped entry points, adnm_quant_update, fp8); 6: tap_ld of adnm_adnprep_*; 5: `prec` of adnm_tsgemm_nt; 4: workspace of adnm_colsum
+extern "C" int adnm_abi_version(void) { return 10; }   // 10: narrow weight shadows (b_dtype / b_scale of adnm_skgemm, shadow args + hyper of adnm_adamw_step, adnm_shadow_refresh, narrow of adnm_adnprep_fwd_multi), counters / slabs_uc of adnm_skgemm; 9: the split-K workspace is the caller's (adnm_uncached_alloc / _free; the per-device rings are gone); 8: adnm_mixnorm_*, adnm_bridge_pool_* (adnm_tokmean_* gone), up1 / up2 of adnm_haar_idwt; 7: precision ladder (`q` of the GEMM-shaped entry points, adnm_quant_update, fp8); 6: tap_ld of adnm_adnprep_*; 5: `prec` of adnm_tsgemm_nt; 4: workspace of adnm_colsum
 
 // ---- profiler: OFF by default (one relaxed atomic load per launch).  When bench.py enables it, every kernel
 // launch of the library is bracketed by hipEventRecord on the stream it is launched on; adnm_prof_collect()

@@ -55,7 +55,9 @@ __device__ __forceinline__ void adamw_elem(float& P, float g, float& M, float& V
 template <bool NT, int U, bool SH16>
 __global__ __launch_bounds__(kBlock) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, int64_t n, const float* __restrict__ state, float lr,
-                                                       float beta1, float beta2, float eps, float wd, float max_norm, uint16_t* __restrict__ sh16) {
+                                                       float beta1, float beta2, float eps, float wd, float max_norm, uint16_t* __restrict__ sh16,
+                                                       const float* __restrict__ hyper) {
+  if (hyper) lr = hyper[0], max_norm = hyper[1];   // device-resident learning rate / clip threshold: a captured launch follows the host's schedule
   float coef = 1.0f;
   if (max_norm > 0.f) {  // torch.nn.utils.clip_grad_norm_: coef = clamp(max_norm / (norm + 1e-6), max=1)
     coef = max_norm / (sqrtf(state[1]) + 1e-6f);
@@ -115,7 +117,8 @@ __global__ __launch_bounds__(kBlock) void adamw_seg_kernel(float* __restrict__ p
                                                            float* __restrict__ v, int64_t n4, int64_t per_block, const float* __restrict__ state,
                                                            float lr, float beta1, float beta2, float eps, float wd, float max_norm,
                                                            void* __restrict__ shadow, const int* __restrict__ seg_end, const int* __restrict__ seg_rec,
-                                                           int nseg, AdnmQuant* __restrict__ tab, int collect) {
+                                                           int nseg, AdnmQuant* __restrict__ tab, int collect, const float* __restrict__ hyper) {
+  if (UPD && hyper) lr = hyper[0], max_norm = hyper[1];
   float coef = 1.0f, bc1 = 1.f, bc2s = 1.f;
   if (UPD) {
     if (max_norm > 0.f) {
@@ -253,7 +256,7 @@ extern "C" int64_t adnm_adamw_ws_bytes(void) { return kNormBlocks * (int64_t)siz
 namespace {
 int seg_launch(bool upd, float* p, const float* g, float* m, float* v, int64_t n, float* state, float lr, float beta1, float beta2, float eps,
                float wd, float max_norm, void* shadow, int shadow_dtype, const int* seg_end, const int* seg_rec, int64_t nseg, float* tab,
-               int collect, hipStream_t st) {
+               int collect, const float* hyper, hipStream_t st) {
   ADNM_REQUIRE(seg_end && seg_rec && nseg >= 1 && nseg < (1 << 24) && tab, "adamw / shadow pass: the fp8 shadow needs the segment tables and the record table");
   ADNM_REQUIRE(n / 4 < (1ll << 31), "adamw / shadow pass: more than 2^31 quads");
   const int64_t n4 = n / 4;
@@ -263,7 +266,7 @@ int seg_launch(bool upd, float* p, const float* g, float* m, float* v, int64_t n
   const int64_t per_block = adnm_cdiv(adnm_cdiv(n4, blocks), kBlock) * kBlock;
   AdnmQuant* t = reinterpret_cast<AdnmQuant*>(tab);
 #define SEG(UPDV, SHV) adamw_seg_kernel<UPDV, SHV><<<(unsigned)blocks, kBlock, 0, st>>>(p, g, m, v, n4, per_block, state, lr, beta1, beta2, eps, wd, \
-                                                                                       max_norm, shadow, seg_end, seg_rec, (int)nseg, t, collect)
+                                                                                       max_norm, shadow, seg_end, seg_rec, (int)nseg, t, collect, hyper)
   if (upd) {
     if (shadow_dtype == ADNM_B_BF16) SEG(true, 1); else SEG(true, 2);
   } else {
@@ -276,7 +279,7 @@ int seg_launch(bool upd, float* p, const float* g, float* m, float* v, int64_t n
 
 extern "C" int adnm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float* state, float lr, float beta1, float beta2,
                                float eps, float weight_decay, float max_norm, void* ws, int64_t ws_bytes, void* shadow, int shadow_dtype,
-                               const int* seg_end, const int* seg_rec, int64_t nseg, float* wtab, adnm_stream_t stream) {
+                               const int* seg_end, const int* seg_rec, int64_t nseg, float* wtab, const float* hyper, adnm_stream_t stream) {
   ADNM_REQUIRE(p && g && m && v && state, "adamw_step: null pointer");
   ADNM_REQUIRE(n > 0 && n % 4 == 0, "adamw_step: n=%lld must be a positive multiple of 4 (pad the flat buffers)", (long long)n);
   ADNM_REQUIRE(!shadow || shadow_dtype == ADNM_B_BF16 || shadow_dtype == ADNM_B_FP8, "adamw_step: the shadow is bf16 (1) or scaled e4m3 (2)");
@@ -294,11 +297,11 @@ extern "C" int adnm_adamw_step(float* p, const float* g, float* m, float* v, int
   {   // measured in one session (two runs each): plain accesses 0.446 ms, non-temporal g / m / v 0.414, + two float4 per lane 0.400 / 0.47 without
     ADNM_PROF("adamw_update", st, 4.0 * n * 7 + (shadow ? (shadow_dtype == ADNM_B_BF16 ? 2.0 : 1.0) * n : 0.0));
     if (shadow && shadow_dtype == ADNM_B_FP8) {
-      if (int rc = seg_launch(true, p, g, m, v, n, state, lr, beta1, beta2, eps, weight_decay, max_norm, shadow, shadow_dtype, seg_end, seg_rec, nseg, wtab, 1, st)) return rc;
+      if (int rc = seg_launch(true, p, g, m, v, n, state, lr, beta1, beta2, eps, weight_decay, max_norm, shadow, shadow_dtype, seg_end, seg_rec, nseg, wtab, 1, hyper, st)) return rc;
     } else if (shadow) {
-      adamw_kernel<true, 1, true><<<(unsigned)blocks, kBlock, 0, st>>>(p, g, m, v, n, state, lr, beta1, beta2, eps, weight_decay, max_norm, (uint16_t*)shadow);
+      adamw_kernel<true, 1, true><<<(unsigned)blocks, kBlock, 0, st>>>(p, g, m, v, n, state, lr, beta1, beta2, eps, weight_decay, max_norm, (uint16_t*)shadow, hyper);
     } else {
-      adamw_kernel<true, 1, false><<<(unsigned)blocks, kBlock, 0, st>>>(p, g, m, v, n, state, lr, beta1, beta2, eps, weight_decay, max_norm, nullptr);
+      adamw_kernel<true, 1, false><<<(unsigned)blocks, kBlock, 0, st>>>(p, g, m, v, n, state, lr, beta1, beta2, eps, weight_decay, max_norm, nullptr, hyper);
     }
   }
   ADNM_CHECK_LAUNCH("adamw_step");
@@ -318,7 +321,7 @@ extern "C" int adnm_shadow_refresh(const float* p, int64_t n, void* shadow, int 
     return adnm_cast_f32_bf16(p, shadow, n, 1.0f, stream);
   }
   if (int rc = seg_launch(false, const_cast<float*>(p), nullptr, nullptr, nullptr, n, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, shadow, shadow_dtype, seg_end,
-                          seg_rec, nseg, wtab, collect, st))
+                          seg_rec, nseg, wtab, collect, nullptr, st))
     return rc;
   ADNM_CHECK_LAUNCH("shadow_refresh");
   return ADNM_OK;

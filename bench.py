@@ -84,6 +84,9 @@ def parse():
     ap.add_argument("--dump-json", default=os.path.join(ROOT, "bench_tables.json"),
                     help="side file for the full record (the stdout line + the complete per-family / per-kernel tables)")
     ap.add_argument("--dump-prof", default="", help="write the per-(kernel, shape) HIP-event table of the instrumented steps to this file")
+    ap.add_argument("--side-stream", type=int, default=-1,
+                    help="weight-gradient leaves (grouped weight-gradient GEMMs / stencils, their folds, the parameter-prep backward nodes) on a second "
+                         "stream beside the input-gradient chain = parallel branches of the captured graph: 1 on, 0 off, -1 the trainer's default")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): replay fwd+bwd as captured hipGraphs; 0: eager launches")
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16", "fp8"],
                     help="matrix-core precision of the GEMM-shaped kernels.  bf16 (default) = BASELINE config 2's precision: bf16 MFMA operands, "
@@ -395,7 +398,8 @@ def main():
     overlap = (world > 1) if args.overlap < 0 else bool(args.overlap)
     # AdamW recipe of train_untils.py:35-42; clip threshold = norm_max of the warm-up epochs (train.py:87,122-124)
     trainer = FlatTrainer(model, criterion, lr=1e-3, betas=(0.9, 0.999), eps=1e-9, weight_decay=1e-2, max_norm=0.025,
-                          use_graph=bool(args.graph), overlap=overlap, reduce_dtype=args.reduce_dtype, nstages=args.stages or None)
+                          use_graph=bool(args.graph), overlap=overlap, reduce_dtype=args.reduce_dtype, nstages=args.stages or None,
+                          **({} if args.side_stream < 0 else {"side_stream": bool(args.side_stream)}))
     frames = recipe.radar_batch(args.batch, args.in_frames + args.out_frames, args.size, salt=rank, name="bench").to(dev)
     x, tgt = frames[:, :args.in_frames].contiguous(), frames[:, args.in_frames:].contiguous()
     trainer.prepare(x, tgt)

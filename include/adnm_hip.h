@@ -464,12 +464,15 @@ int adnm_mixnorm_bwd(const float* dyn, int64_t lddyn, const float* dres, int64_t
  *     or < 0 for a tensor no GEMM reads (its shadow bytes are unspecified).  While a record's `record` flag is set the pass collects
  *     max |p| of the UPDATED values into amax_b; adnm_quant_update (run over wtab BEFORE this pass in a step) turns it into the next
  *     scale_b, with which this pass writes the shadow and the next step's GEMMs read it: shadow and scale never disagree.
+ * hyper (optional, NULL = use the arguments): two device floats {lr, max_norm} read by the kernels INSTEAD of the by-value arguments, so that
+ *   a launch captured in a hipGraph (the tail graph of a multi-GPU step) follows the host's learning-rate schedule and adaptive clip
+ *   threshold (train.py:122-130) — the host rewrites the two floats when they change.
  * adnm_shadow_refresh: the shadow alone from the parameters as they are (after they moved into the flat buffer, after a checkpoint load);
  *   shadow = NULL (fp8) with collect != 0: only collect max |p| (the first calibration). */
 int64_t adnm_adamw_ws_bytes(void);
 int adnm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float* state, float lr, float beta1,
                     float beta2, float eps, float weight_decay, float max_norm, void* ws, int64_t ws_bytes, void* shadow, int shadow_dtype,
-                    const int* seg_end, const int* seg_rec, int64_t nseg, float* wtab, adnm_stream_t stream);
+                    const int* seg_end, const int* seg_rec, int64_t nseg, float* wtab, const float* hyper, adnm_stream_t stream);
 int adnm_shadow_refresh(const float* p, int64_t n, void* shadow, int shadow_dtype, const int* seg_end, const int* seg_rec, int64_t nseg,
                         float* wtab, int collect, adnm_stream_t stream);
 

@@ -15,7 +15,7 @@ def test_header_parses_and_library_exports_every_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for name in protos:
         assert hasattr(so, name), f"{name} declared in include/adnm_hip.h but not exported"
-    assert lib.load().adnm_abi_version() == 9
+    assert lib.load().adnm_abi_version() == 10
 
 
 def test_ws_queries_are_pure_host_functions():

@@ -1193,7 +1193,7 @@ def test_adamw_writes_the_shadows():
         for _ in range(2):
             lib.call("adnm_adamw_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), total, state.data_ptr(), 1e-3, 0.9, 0.999, 1e-9, 1e-2, 0.05,
                      ws.data_ptr(), ws.numel(), None if sh is None else sh.data_ptr(), mode, seg_end.data_ptr(), seg_rec.data_ptr(), 5,
-                     tab.data_ptr() if mode == 2 else None, torch.cuda.current_stream().cuda_stream)
+                     tab.data_ptr() if mode == 2 else None, None, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         return p, m, v, sh, tab
     base = run(0)

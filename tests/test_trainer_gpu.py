@@ -224,3 +224,28 @@ def test_bf16_shadow_weights_are_bitwise_neutral(monkeypatch):
         ops.set_mfma_precision("f32")
     assert torch.equal(flats[0][1], flats[1][1]), "gradients differ with the shadow weights"
     assert torch.equal(flats[0][0], flats[1][0]), "parameters differ with the shadow weights"
+
+
+def test_tail_graph_follows_host_schedules():
+    """The staged trainer (the multi-GPU form) replays its optimiser as a captured TAIL graph whose learning rate and clip threshold live in
+    device memory: changing tr.lr / tr.max_norm between steps (train.py's warm-up + cosine schedule, its adaptive clip threshold) must give
+    bit for bit what the eagerly launched optimiser gives."""
+    from models.ADNMUNet import create_ADNMUNet
+    from models.loss import enRainfallLoss
+    frames = recipe.radar_batch(2, 25, 64, name="tail").to(DEV)
+    x, tgt = frames[:, :5].contiguous(), frames[:, 5:].contiguous()
+    flats = []
+    for use_graph in (False, True):
+        model = create_ADNMUNet(5, 20, 6, img_size=64)
+        recipe.fill_parameters(model)
+        model = model.to(DEV).train()
+        tr = FlatTrainer(model, enRainfallLoss(0.57, 0.25, gamma=0.0), lr=1e-3, max_norm=0.025, use_graph=use_graph, overlap=True)
+        for k in range(5):
+            tr.lr, tr.max_norm = 1e-3 * (1.0 - 0.15 * k), 0.025 * (1.0 + 0.5 * k)
+            tr.step(x, tgt)
+        torch.cuda.synchronize()
+        assert tr.staged and (getattr(tr, "tail", None) is not None) == use_graph
+        flats.append((tr.flat_p.clone(), tr.exp_avg.clone()))
+        tr.close()
+        del tr
+    assert torch.equal(flats[0][1], flats[1][1]) and torch.equal(flats[0][0], flats[1][0])
