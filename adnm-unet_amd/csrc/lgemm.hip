@@ -27,16 +27,18 @@ namespace {
 using f32x4 = adnm_f32x4;
 constexpr int kThreads = 256, kTile = 64, kStep = 32;
 
-// BF16: the LDS images hold bf16 pairs (rounded once, when a tile is staged).  fp32 AND fp8 keep fp32 images: the fp8 operands are
-// scaled / saturated / converted when a lane forms its fragment (the same code as the register-streaming kernel; an fp8 image would
-// quarter the LDS traffic of a kernel that is bound by the L2 -> CU fill, not by LDS).
-template <bool BF16>
+// LDS images by matrix-core precision: bf16 pairs (rounded once, when a tile is staged); fp8 BYTES (scaled / saturated / converted once, when
+// a tile is staged — or copied as they are from the weight's e4m3 shadow), both operands row-major [row][k] with 40-byte rows, the OC
+// operand transposed by byte stores on the way in: a fragment is one ds_read_b64 and the tile a quarter of the fp32 image's LDS bytes;
+// fp32 keeps fp32 images.
+template <int PREC>
 struct Geo {
-  static constexpr int rc_stride = BF16 ? 24 : 40;   // words per RC row (32 reduction steps + pad)
+  static constexpr bool BF16 = PREC == ADNM_MFMA_BF16, FP8 = PREC == ADNM_MFMA_FP8;
+  static constexpr int rc_stride = FP8 ? 10 : (BF16 ? 24 : 40);   // words per RC row (32 reduction steps + pad)
   static constexpr int rc_words = kTile * rc_stride;
   static constexpr int oc_stride = 68;               // words per OC row (64 columns + pad)
   static constexpr int oc_rows = BF16 ? kStep / 2 : kStep;
-  static constexpr int oc_words = oc_rows * oc_stride;
+  static constexpr int oc_words = FP8 ? rc_words : oc_rows * oc_stride;   // (fp8: the OC operand is staged transposed, as an RC image)
 };
 
 struct LgArgs {
@@ -69,8 +71,8 @@ template <bool B_OC, int PREC, bool A_BF8, int D, int BT>
 __global__ __launch_bounds__(kThreads) void lgemm_kernel(LgArgs p) {
   static_assert(BT == ADNM_B_F32 || (BT == ADNM_B_BF16 && PREC == ADNM_MFMA_BF16) || (BT == ADNM_B_FP8 && PREC == ADNM_MFMA_FP8),
                 "a narrow weight shadow feeds the matrix-core precision it was made for");
-  constexpr bool BF16 = PREC == ADNM_MFMA_BF16;
-  using G = Geo<BF16>;
+  constexpr bool BF16 = PREC == ADNM_MFMA_BF16, FP8 = PREC == ADNM_MFMA_FP8;
+  using G = Geo<PREC>;
   constexpr int kAW = G::rc_words, kBW = B_OC ? G::oc_words : G::rc_words;
   __shared__ __attribute__((aligned(16))) uint32_t lds[2 * (kAW + kBW)];
   uint32_t* const ldsA = lds;
@@ -126,7 +128,10 @@ __global__ __launch_bounds__(kThreads) void lgemm_kernel(LgArgs p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       av[u] = *reinterpret_cast<const float4*>(a_row[u] + (oka ? r0 : a_dead[u]));
-      bv[u] = adnm_ldb4<BT>(p.B, b_ok(kt, u) ? b_off[u] + (B_OC ? r0 * (int)p.ldb : r0) : 0);
+      const int64_t bo = b_ok(kt, u) ? b_off[u] + (B_OC ? r0 * (int)p.ldb : r0) : 0;
+      if constexpr (BT == ADNM_B_FP8)   // the shadow's bytes go into the fp8 image as they are: carried as the bit pattern of .x
+        bv[u] = make_float4(__int_as_float(*reinterpret_cast<const int*>(reinterpret_cast<const uint8_t*>(p.B) + bo)), 0.f, 0.f, 0.f);
+      else bv[u] = adnm_ldb4<BT>(p.B, bo);
     }
   };
   // fp8: per-tensor scales from the call site's quantisation record (the accumulators are un-scaled in the epilogue); rec_a / rec_b
@@ -157,6 +162,36 @@ __global__ __launch_bounds__(kThreads) void lgemm_kernel(LgArgs p) {
         const float4 v = keep_if(b_ok(kt, u), bv[u]);
         amax_b = adnm_amax4(amax_b, v.x, v.y, v.z, v.w);
       }
+    }
+    if constexpr (FP8) {
+      // bytes: 4 reduction steps of a row = one word.  A: scaled, saturated, e4m3 (e5m2 when it is a gradient); B: the same from fp32
+      // values, or the shadow's own bytes
+      auto q4 = [](float4 v, float sc, bool bf8) {
+        const float c0 = __builtin_amdgcn_fmed3f(v.x * sc, bf8 ? 57344.f : 448.f, bf8 ? -57344.f : -448.f);
+        const float c1 = __builtin_amdgcn_fmed3f(v.y * sc, bf8 ? 57344.f : 448.f, bf8 ? -57344.f : -448.f);
+        const float c2 = __builtin_amdgcn_fmed3f(v.z * sc, bf8 ? 57344.f : 448.f, bf8 ? -57344.f : -448.f);
+        const float c3 = __builtin_amdgcn_fmed3f(v.w * sc, bf8 ? 57344.f : 448.f, bf8 ? -57344.f : -448.f);
+        int w = 0;
+        if (bf8) w = __builtin_amdgcn_cvt_pk_bf8_f32(c0, c1, w, false), w = __builtin_amdgcn_cvt_pk_bf8_f32(c2, c3, w, true);
+        else w = __builtin_amdgcn_cvt_pk_fp8_f32(c0, c1, w, false), w = __builtin_amdgcn_cvt_pk_fp8_f32(c2, c3, w, true);
+        return (uint32_t)w;
+      };
+#pragma unroll
+      for (int u = 0; u < 2; ++u) sa[(lrow + 32 * u) * G::rc_stride + q] = q4(keep_if(oka, av[u]), q_sa, A_BF8);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float4 v = keep_if(b_ok(kt, u), bv[u]);
+        const uint32_t w = BT == ADNM_B_FP8 ? (uint32_t)__float_as_int(v.x) : q4(v, q_sb, false);
+        if (!B_OC) {
+          sb[(lrow + 32 * u) * G::rc_stride + q] = w;
+        } else {   // 4 columns of reduction row lr + 16 u -> byte (column, k) of the transposed image
+          uint8_t* const sb8 = reinterpret_cast<uint8_t*>(sb);
+          const int k = lr + 16 * u;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) sb8[(4 * cq + c) * (4 * G::rc_stride) + k] = (uint8_t)(w >> (8 * c));
+        }
+      }
+      return;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -193,7 +228,17 @@ __global__ __launch_bounds__(kThreads) void lgemm_kernel(LgArgs p) {
   auto compute = [&](int buf) {
     const uint32_t* const sa = ldsA + buf * kAW;
     const uint32_t* const sb = ldsB + buf * kBW;
-    if constexpr (BF16) {
+    if constexpr (FP8) {
+      AdnmFrag<ADNM_MFMA_FP8> fa[2], fb[2];   // 8 bytes = reduction steps 8 kq .. 8 kq + 7 of the tile: one ds_read_b64, one fp8 MFMA per block pair
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a].v = *reinterpret_cast<const long*>(sa + (32 * wi + 16 * a + l15) * G::rc_stride + 2 * kq);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fb[b].v = *reinterpret_cast<const long*>(sb + (32 * wj + 16 * b + l15) * G::rc_stride + 2 * kq);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = adnm_mma<ADNM_MFMA_FP8, false, A_BF8>(fb[b], fa[a], acc[a][b]);
+    } else if constexpr (BF16) {
       uint4 fa[2], fb[2];   // 8 bf16 = reduction steps 8 kq .. 8 kq + 7 of the tile: ONE v_mfma_f32_16x16x32_bf16 per block pair
 #pragma unroll
       for (int a = 0; a < 2; ++a) fa[a] = *reinterpret_cast<const uint4*>(sa + (32 * wi + 16 * a + l15) * G::rc_stride + 4 * kq);
