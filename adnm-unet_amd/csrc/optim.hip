@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void adamw_seg_kernel(float* __restrict__ p
   for (int64_t i = lo + threadIdx.x; i < lo + per_block; i += kBlock) {   // (uniform trip count: the wave votes below need every lane)
     const bool in = i < hi;
     while (in && seg + 1 < nseg && i >= (int64_t)seg_end[seg]) ++seg;
-    const int r = in ? seg_rec[seg] : -3;
+    const int r = in ? (SH == 2 ? seg_rec[seg] : -1) : -3;   // (the bf16 shadow has no records: the table may be NULL)
     f4 pp = {0.f, 0.f, 0.f, 0.f};
     if (in) {
       pp = reinterpret_cast<const f4*>(p)[i];
