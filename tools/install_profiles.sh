@@ -2,10 +2,10 @@
 # tools/install_profiles.sh <tag> : copy what tools/make_profiles.sh <tag> left under gpurun_out/<tag>/ (merged back from the GPU box) into
 # profiles/ under the judged names (gpurun_out/ is scratch, profiles/ is tracked).
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 src=gpurun_out/$tag
 for f in bench_bf16.json bench_f32.json bench_fp8.json fp8_error.txt kernel_shapes_bf16.tsv kernel_shapes_f32.tsv kernel_shapes_fp8.tsv kernel_stats_bf16.csv steady_state_bf16.txt small_grids_bf16.txt \
-         tsgemm.txt gemm_bench.txt pmc_traffic.txt; do
+         tsgemm.txt gemm_bench.txt pmc_traffic.txt dwconv_storage.txt two_streams.txt ab_switches.txt; do
   cp $src/$f profiles/${tag}_$f
 done
 cp $src/pmc_traffic.json profiles/pmc_traffic.json

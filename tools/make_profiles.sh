@@ -9,7 +9,7 @@
 #   profiles/<tag>_bf16_parity.txt              tools/bf16_error.py: measured error of the bf16 mode on the whole model
 # The PMC passes run BEFORE the judged bench line so that the line can carry `traffic` from the same kernel sources.
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/$tag
 mkdir -p $out
 root=$(pwd)
@@ -26,6 +26,12 @@ python3 tools/fp8_error.py 2>&1 | grep -v amdgpu.ids > $out/fp8_error.txt
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace -o t -- python3 $root/bench.py --steps 20 --warmup 10 --prof-steps 0 --no-cpu-baseline > $root/$out/trace.log 2>&1 ) || { echo "trace pass failed"; tail -n 5 $out/trace.log; exit 1; }
 python3 tools/bf16_error.py > $out/bf16_parity.txt 2>&1
 python3 tools/kbench_ts.py 2>&1 | grep -v amdgpu.ids > $out/tsgemm.txt
+python3 tools/kbench_dw.py 2>&1 | grep -v amdgpu.ids > $out/dwconv_storage.txt
+python3 tools/kbench_twostream.py 2>&1 | grep -v amdgpu.ids > $out/two_streams.txt
+( for s in 0 1; do python3 bench.py --no-cpu-baseline --prof-steps 0 --side-stream $s 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('side_stream=$s', d['ms_per_step'], d['windows_ms_per_step'])"; done
+  for o in 0 1; do python3 bench.py --no-cpu-baseline --prof-steps 0 --overlap $o 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('staged(5 graphs + tail graph)=$o', d['ms_per_step'], d['windows_ms_per_step'])"; done
+  for s in 0 1; do ADNM_BF16_STORAGE=$s python3 bench.py --no-cpu-baseline --prof-steps 0 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('ADNM_BF16_STORAGE=$s', d['ms_per_step'], d['windows_ms_per_step'])"; done
+  for s in 0 1; do ADNM_NARROW_WEIGHTS=$s python3 bench.py --no-cpu-baseline --prof-steps 0 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('ADNM_NARROW_WEIGHTS=$s', d['ms_per_step'], d['windows_ms_per_step'])"; done ) > $out/ab_switches.txt 2>&1
 python3 tools/kbench_gemm.py 2>&1 | grep -v amdgpu.ids > $out/gemm_bench.txt
 python3 tools/kstats.py $out/trace 80 3 80 > $out/steady_state_bf16.txt 2>&1
 python3 tools/kclass.py $out/trace 64 > $out/small_grids_bf16.txt 2>&1
