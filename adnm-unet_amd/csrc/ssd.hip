@@ -64,7 +64,12 @@ inline Geo make_geo(int64_t B, int64_t L, int64_t H, int64_t P, bool reduction) 
     g.nchunk = 1;
     return g;
   }
-  int64_t tpw = (B * g.nhb * tiles) / 2048;
+  // target wave count (ADNM_SSD_WAVES / ADNM_SSD_WAVES_RED: measurement aids).  Streaming passes (apply, backward): 4096 = one 16-token
+  // tile per wave at the refiner shape, every tile's loads in flight at once; the reduction pass keeps 2048 (its partials and fold grow
+  // with the workgroup count)
+  static const int64_t waves_s = [] { const char* e = getenv("ADNM_SSD_WAVES"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 4096); }();
+  static const int64_t waves_r = [] { const char* e = getenv("ADNM_SSD_WAVES_RED"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 2048); }();
+  int64_t tpw = (B * g.nhb * tiles) / (reduction ? waves_r : waves_s);
   tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
   g.tok = (int)(kWaves * tpw * kTile);
   g.nchunk = (int)adnm_cdiv(L, g.tok);

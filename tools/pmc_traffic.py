@@ -47,7 +47,7 @@ SCOPES = [
     (r"^ssd_bwd_kernel", "ssd_bwd"), (r"^ssd_fold_kernel", "ssd_fold"), (r"^ssd_bc_fold_kernel", "ssd_bc_fold"),
     (r"^fold_rows_kernel", FOLDS),
     (r"^conv3_kernel", "conv3_fwd|conv3_dgrad"), (r"^conv3_wgrad_kernel", "conv3_wgrad"), (r"^conv3_join_kernel", "conv3_join"),
-    (r"^adamw_kernel", "adamw_update"), (r"^sumsq_partial_kernel", "grad_sumsq"),
+    (r"^adamw_(seg_)?kernel", "adamw_update"), (r"^sumsq_partial_kernel", "grad_sumsq"),
     (r"^haar_dwt_kernel", "haar_dwt"), (r"^haar_idwt_kernel", "haar_idwt"),
     (r"^(\w+?)_kernel", None),   # default: the symbol's stem is the scope (rownorm_fwd, lincomb_bwd, gate_fwd, instnorm_apply, ...)
 ]
@@ -82,7 +82,7 @@ def load(d, counter):
 
 def per_step(rows, scale):
     """cut whole steps at the adamw launches, drop the first step; -> (steps, {symbol: [bytes per step, launches per step]})"""
-    cuts = [i for i, (_, s, _) in enumerate(rows) if s.startswith("adamw_kernel")]
+    cuts = [i for i, (_, s, _) in enumerate(rows) if s.startswith(("adamw_kernel", "adamw_seg_kernel"))]
     if len(cuts) < 3:
         raise SystemExit("need at least 3 training steps in the PMC pass")
     lo, hi = cuts[0] + 1, cuts[-1] + 1
