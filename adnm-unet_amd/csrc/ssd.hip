@@ -55,7 +55,7 @@ struct Geo {
   int nchunk;   // workgroups along L
 };
 // tiles per wave: enough waves to fill the chip (>= 2048), at most 8 tiles per wave; small maps: one workgroup per (b, head block)
-inline Geo make_geo(int64_t B, int64_t L, int64_t H, int64_t P, bool reduction) {
+inline Geo make_geo(int64_t B, int64_t L, int64_t H, int64_t P, bool reduction, bool apply = false) {
   Geo g;
   g.nhb = (int)adnm_cdiv(H * P, kCols);
   const int64_t tiles = adnm_cdiv(L, kTile);
@@ -64,12 +64,14 @@ inline Geo make_geo(int64_t B, int64_t L, int64_t H, int64_t P, bool reduction) 
     g.nchunk = 1;
     return g;
   }
-  // target wave count (ADNM_SSD_WAVES / ADNM_SSD_WAVES_RED: measurement aids).  Streaming passes (apply, backward): 4096 = one 16-token
-  // tile per wave at the refiner shape, every tile's loads in flight at once; the reduction pass keeps 2048 (its partials and fold grow
-  // with the workgroup count)
-  static const int64_t waves_s = [] { const char* e = getenv("ADNM_SSD_WAVES"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 4096); }();
+  // target wave count (ADNM_SSD_WAVES_* : measurement aids).  Measured at the refiner shape (tools/kbench_ssd.py, forward pair / backward
+  // pair per call): the apply pass is fastest with 4096 waves = one 16-token tile per wave, every tile's loads in flight at once
+  // (30.1 -> 28.5 us); the backward pass (236 VGPRs, 2 waves per SIMD) and the reduction pass (partials + fold grow with the
+  // workgroup count) with 2048 (41.8 vs 46.3 us; 30.1 vs 33.1 us)
+  static const int64_t waves_a = [] { const char* e = getenv("ADNM_SSD_WAVES_APPLY"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 4096); }();
+  static const int64_t waves_b = [] { const char* e = getenv("ADNM_SSD_WAVES_BWD"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 2048); }();
   static const int64_t waves_r = [] { const char* e = getenv("ADNM_SSD_WAVES_RED"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 2048); }();
-  int64_t tpw = (B * g.nhb * tiles) / (reduction ? waves_r : waves_s);
+  int64_t tpw = (B * g.nhb * tiles) / (reduction ? waves_r : (apply ? waves_a : waves_b));
   tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
   g.tok = (int)(kWaves * tpw * kTile);
   g.nchunk = (int)adnm_cdiv(L, g.tok);
@@ -100,6 +102,28 @@ __device__ __forceinline__ void stage_k_tile(const T* __restrict__ K, int64_t ld
     if (f < TOT) lds_st4(sK + t * SK + 4 * qq, v[r]);
   }
 }
+
+// the same in two halves: issue the loads of a tile (registers), write them to the wave's slab later — the next tile's loads fly under
+// the current tile's MFMAs
+template <typename T, int KW>
+struct KTile {
+  static constexpr int SK = KW + 4, Q = KW / 4, TOT = kTile * Q, IT = (TOT + 63) / 64;
+  float4 v[IT];
+  __device__ __forceinline__ void load(const T* __restrict__ K, int64_t ldk, int64_t row0, int nvalid, int lane) {
+#pragma unroll
+    for (int r = 0; r < IT; ++r) {
+      const int f = lane + 64 * r, t = f / Q, qq = f % Q;
+      v[r] = ld_row4<T>(K, row0 + t, ldk, 4 * qq, f < TOT && t < nvalid);
+    }
+  }
+  __device__ __forceinline__ void store(float* sK, int lane) const {
+#pragma unroll
+    for (int r = 0; r < IT; ++r) {
+      const int f = lane + 64 * r, t = f / Q, qq = f % Q;
+      if (f < TOT) lds_st4(sK + t * SK + 4 * qq, v[r]);
+    }
+  }
+};
 
 // ================================================================================================ pass 1
 // out[b, chunk, h, n, p] = sum_{l in chunk} K[b,l,g,n] * V[b,l,h,p] * (WEIGHTED ? w[b,l,h] : 1)
@@ -134,25 +158,39 @@ __global__ __launch_bounds__(kBlock) void ssd_kv_kernel(const T* __restrict__ V,
 #pragma unroll
   for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ntiles = (int)((l_end - l_begin + kTile - 1) / kTile);
-  for (int tile = wave; tile < ntiles; tile += kWaves) {
-    const int64_t t0 = l_begin + (int64_t)tile * kTile;
-    const int nvalid = (int)(l_end - t0 < kTile ? l_end - t0 : kTile);
-    const int64_t row0 = (int64_t)b * L + t0;
+  // two tiles in flight per wave: the loads of tile t + 1 are issued before tile t is staged and multiplied (a wave used to pay one
+  // full memory round trip per tile: 2 tiles per wave at the refiner shape)
+  struct Tile {
     float4 xv[4];
+    float z[4];
+    KTile<T, KW> k;
+    int nvalid;
+  };
+  auto load_tile = [&](int tile, Tile& tr) {
+    const int64_t t0 = l_begin + (int64_t)tile * kTile;
+    tr.nvalid = (int)(l_end - t0 < kTile ? l_end - t0 : kTile);
+    const int64_t row0 = (int64_t)b * L + t0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int t = kk + 4 * r;
-      const bool ok = hv && t < nvalid;
-      xv[r] = ld_row4<T>(V, row0 + t, ldv, col0 + 4 * q, ok);
+      const bool ok = hv && t < tr.nvalid;
+      tr.xv[r] = ld_row4<T>(V, row0 + t, ldv, col0 + 4 * q, ok);
+      tr.z[r] = (WEIGHTED && ok) ? Io<T>::ld(dt_raw + (row0 + t) * lddt + (int64_t)h * dt_hs) : 0.f;
+    }
+    tr.k.load(K, ldk, row0, tr.nvalid, lane);
+  };
+  auto process = [&](Tile& tr) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
       if (WEIGHTED) {
-        const float z = ok ? Io<T>::ld(dt_raw + (row0 + t) * lddt + (int64_t)h * dt_hs) + bias : 0.f;
-        const float w = ok ? softplusf_(z) * a : 0.f;
-        xv[r].x *= w; xv[r].y *= w; xv[r].z *= w; xv[r].w *= w;
+        const bool ok = hv && kk + 4 * r < tr.nvalid;
+        const float w = ok ? softplusf_(tr.z[r] + bias) * a : 0.f;
+        tr.xv[r].x *= w; tr.xv[r].y *= w; tr.xv[r].z *= w; tr.xv[r].w *= w;
       }
     }
-    stage_k_tile<T, KW>(K, ldk, row0, nvalid, sK, lane);
+    tr.k.store(sK, lane);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) lds_st4(sX + (kk + 4 * r) * kSX + 4 * q, xv[r]);
+    for (int r = 0; r < 4; ++r) lds_st4(sX + (kk + 4 * r) * kSX + 4 * q, tr.xv[r]);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -164,6 +202,20 @@ __global__ __launch_bounds__(kBlock) void ssd_kv_kernel(const T* __restrict__ V,
       for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c / CPG], sX[tok * kSX + mc[c]], acc[c], 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
+  };
+  {
+    Tile ta, tb;
+    int tile = wave;
+    if (tile < ntiles) load_tile(tile, ta);
+    for (; tile < ntiles; tile += 2 * kWaves) {
+      const bool second = tile + kWaves < ntiles;
+      if (second) load_tile(tile + kWaves, tb);
+      process(ta);
+      if (second) {
+        if (tile + 2 * kWaves < ntiles) load_tile(tile + 2 * kWaves, ta);
+        process(tb);
+      }
+    }
   }
   // sum the 4 waves through LDS (fixed order), then one store of the head block's N x 64 state.  MFMA D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
   __syncthreads();
@@ -601,7 +653,7 @@ template <typename T, int P, int N, int G>
 int run_apply(const void* x, int64_t ldx, const void* Cm, int64_t ldc, const float* D, int64_t p_hs, const float* kv, void* y, int64_t ldy,
               const float* ln_w, const float* ln_b, void* yn, int64_t ldyn, float* mu, float* rstd, float eps, int64_t B, int64_t L, int64_t H,
               hipStream_t st) {
-  const Geo g = make_geo(B, L, H, P, false);
+  const Geo g = make_geo(B, L, H, P, false, true);
   constexpr int KW = G * N, kSlab = kTile * kSX + kTile * (KW + 4);
   const size_t smem = sizeof(float) * (size_t)kWaves * kSlab;
   const dim3 grid(g.nchunk, g.nhb, (unsigned)B);

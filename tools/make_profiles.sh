@@ -27,6 +27,7 @@ python3 tools/fp8_error.py 2>&1 | grep -v amdgpu.ids > $out/fp8_error.txt
 python3 tools/bf16_error.py > $out/bf16_parity.txt 2>&1
 python3 tools/kbench_ts.py 2>&1 | grep -v amdgpu.ids > $out/tsgemm.txt
 python3 tools/kbench_dw.py 2>&1 | grep -v amdgpu.ids > $out/dwconv_storage.txt
+bash tools/k1_counters.sh $out/k1_counters.txt > /dev/null 2>&1
 python3 tools/kbench_twostream.py 2>&1 | grep -v amdgpu.ids > $out/two_streams.txt
 ( for s in 0 1; do python3 bench.py --no-cpu-baseline --prof-steps 0 --side-stream $s 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('side_stream=$s', d['ms_per_step'], d['windows_ms_per_step'])"; done
   for o in 0 1; do python3 bench.py --no-cpu-baseline --prof-steps 0 --overlap $o 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('staged(5 graphs + tail graph)=$o', d['ms_per_step'], d['windows_ms_per_step'])"; done
