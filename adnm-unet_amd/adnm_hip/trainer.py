@@ -196,6 +196,12 @@ class FlatTrainer:
         if self.fused:
             self.ws = torch.empty(int(lib.query("adnm_adamw_ws_bytes")), dtype=torch.uint8, device=dev)
 
+    def bucket_report(self):
+        """[(bucket index in all-reduce order, first element, last element + 1, bytes on the wire)]: what each stage's collective moves —
+        the sizes to price against the xGMI ring."""
+        eb = 2 if self.reduce_dtype == "bf16" else 4
+        return [(j, lo, hi, (hi - lo) * eb) for j, (lo, hi) in enumerate(self.buckets)]
+
     def _setup_shadows(self, mode):
         """The narrow SHADOW of the flat parameter buffer (ops.ShadowRegistry; include/adnm_hip.h: adnm_adamw_step): mode 1 = bf16, 2 = per-tensor
         scaled e4m3 (weight records in ops.QUANT's table, one per matrix-shaped parameter), rewritten by every optimiser pass.  The

@@ -19,9 +19,9 @@ export TMPDIR=/tmp
 ( cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $root/$out/pmc_write -o w -- python3 $root/bench.py --steps 2 --warmup 2 --prof-steps 0 --no-cpu-baseline > $root/$out/pmc_write.log 2>&1 ) || { echo "PMC write pass failed"; tail -n 5 $out/pmc_write.log; }
 python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $out/pmc_traffic.json $commit > $out/pmc_traffic.txt 2>&1 && cp $out/pmc_traffic.json profiles/pmc_traffic.json
 tail -n 3 $out/pmc_traffic.txt
-python3 bench.py --dump-prof $out/kernel_shapes_bf16.tsv > $out/bench_bf16.json 2> $out/bench_bf16.err || { echo "bench bf16 failed"; tail -n 5 $out/bench_bf16.err; exit 1; }
-python3 bench.py --dtype f32 --no-cpu-baseline --dump-prof $out/kernel_shapes_f32.tsv > $out/bench_f32.json 2> $out/bench_f32.err || { echo "bench f32 failed"; exit 1; }
-python3 bench.py --dtype fp8 --no-cpu-baseline --dump-prof $out/kernel_shapes_fp8.tsv > $out/bench_fp8.json 2> $out/bench_fp8.err || { echo "bench fp8 failed"; exit 1; }
+python3 bench.py --dump-json $out/bench_tables_bf16.json --dump-prof $out/kernel_shapes_bf16.tsv > $out/bench_bf16.json 2> $out/bench_bf16.err || { echo "bench bf16 failed"; tail -n 5 $out/bench_bf16.err; exit 1; }
+python3 bench.py --dtype f32 --no-cpu-baseline --dump-json $out/bench_tables_f32.json --dump-prof $out/kernel_shapes_f32.tsv > $out/bench_f32.json 2> $out/bench_f32.err || { echo "bench f32 failed"; exit 1; }
+python3 bench.py --dtype fp8 --no-cpu-baseline --dump-json $out/bench_tables_fp8.json --dump-prof $out/kernel_shapes_fp8.tsv > $out/bench_fp8.json 2> $out/bench_fp8.err || { echo "bench fp8 failed"; exit 1; }
 python3 tools/fp8_error.py 2>&1 | grep -v amdgpu.ids > $out/fp8_error.txt
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace -o t -- python3 $root/bench.py --steps 20 --warmup 10 --prof-steps 0 --no-cpu-baseline > $root/$out/trace.log 2>&1 ) || { echo "trace pass failed"; tail -n 5 $out/trace.log; exit 1; }
 python3 tools/bf16_error.py > $out/bf16_parity.txt 2>&1
@@ -29,10 +29,6 @@ python3 tools/kbench_ts.py 2>&1 | grep -v amdgpu.ids > $out/tsgemm.txt
 python3 tools/kbench_dw.py 2>&1 | grep -v amdgpu.ids > $out/dwconv_storage.txt
 bash tools/k1_counters.sh $out/k1_counters.txt > /dev/null 2>&1
 python3 tools/kbench_twostream.py 2>&1 | grep -v amdgpu.ids > $out/two_streams.txt
-( for s in 0 1; do python3 bench.py --no-cpu-baseline --prof-steps 0 --side-stream $s 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('side_stream=$s', d['ms_per_step'], d['windows_ms_per_step'])"; done
-  for o in 0 1; do python3 bench.py --no-cpu-baseline --prof-steps 0 --overlap $o 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('staged(5 graphs + tail graph)=$o', d['ms_per_step'], d['windows_ms_per_step'])"; done
-  for s in 0 1; do ADNM_BF16_STORAGE=$s python3 bench.py --no-cpu-baseline --prof-steps 0 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('ADNM_BF16_STORAGE=$s', d['ms_per_step'], d['windows_ms_per_step'])"; done
-  for s in 0 1; do ADNM_NARROW_WEIGHTS=$s python3 bench.py --no-cpu-baseline --prof-steps 0 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('ADNM_NARROW_WEIGHTS=$s', d['ms_per_step'], d['windows_ms_per_step'])"; done ) > $out/ab_switches.txt 2>&1
 python3 tools/kbench_gemm.py 2>&1 | grep -v amdgpu.ids > $out/gemm_bench.txt
 python3 tools/kstats.py $out/trace 80 3 80 > $out/steady_state_bf16.txt 2>&1
 python3 tools/kclass.py $out/trace 64 > $out/small_grids_bf16.txt 2>&1
