@@ -99,6 +99,45 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ in, int64_t
 }
 
 // ================================================================================================ forward / dgrad
+// epilogue shared by the two gather-GEMM kernels: bias, activation, pre-activation copy, or the split run's partial tile.
+// (Measured, round 4: parking the tile in LDS to write whole pixel rows — NB*64 contiguous bytes instead of 64 — gained 4 us on the
+// full-resolution GELU convs and lost 1-2 us on every other one to its two barriers: not kept.  tools/kbench_conv.py)
+template <int NB, int ACT_OUT>
+__device__ __forceinline__ void conv3_epilogue(const ConvArgs& a, const f32x4 (&acc)[NB][MB], int wave, int kk, int dyj, int dxj, int x0, int v0,
+                                               int n0) {
+  // D layout: row = channel (kk*4 + reg) of the block, column = pixel j
+  const int64_t M = (int64_t)a.B * a.H * a.W;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int64_t p = pixel_of(v0 + (wave * MB + mb) * a.RB + dyj, x0 + dxj, a.B, a.H, a.W, a.VR);
+    if (p < 0) continue;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = n0 + nb * 16 + 4 * kk;
+      if (n >= a.N) continue;
+      float v[4] = {acc[nb][mb][0], acc[nb][mb][1], acc[nb][mb][2], acc[nb][mb][3]};
+      if (a.nsplit > 1) {   // N % 4 == 0 is required for split runs (host-checked)
+        *reinterpret_cast<float4*>(a.part + ((int64_t)blockIdx.z * M + p) * a.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (a.bias && n + r < a.N) v[r] += a.bias[n + r];
+      if (a.vec_out && n + 3 < a.N) {
+        if (a.pre) *reinterpret_cast<float4*>(a.pre + p * a.ldpre + n) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(a.out + p * a.ldo + n) = make_float4(act_fwd<ACT_OUT>(v[0]), act_fwd<ACT_OUT>(v[1]), act_fwd<ACT_OUT>(v[2]), act_fwd<ACT_OUT>(v[3]));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < a.N) {
+            if (a.pre) a.pre[p * a.ldpre + n + r] = v[r];
+            a.out[p * a.ldo + n + r] = act_fwd<ACT_OUT>(v[r]);
+          }
+      }
+    }
+  }
+}
+
 // LDS: [input tile (TH+2)(TW+2) x CKP] [weights of the chunk: 9 taps x NB*16 channels x CKP]
 // PREC = ADNM_MFMA_*; A_BF8: in the fp8 mode the pixel rows are a gradient (e5m2) — the dgrad use.
 template <int NB, int ACT_IN, int ACT_OUT, int PREC, bool A_BF8>
@@ -255,37 +294,137 @@ __global__ __launch_bounds__(kBlock) void conv3_kernel(ConvArgs a) {
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = acc[nb][mb] * inv;
   }
-  // epilogue.  D layout: row = channel (kk*4 + reg) of the block, column = pixel j
-  const int64_t M = (int64_t)a.B * a.H * a.W;
+  conv3_epilogue<NB, ACT_OUT>(a, acc, wave, kk, dyj, dxj, x0, v0, n0);
+}
+
+// ---- the bf16 configuration: bf16 IMAGES in LDS (round 4).  conv3_kernel keeps fp32 images and rounds where a lane forms its fragment —
+// every staged value is read by 9 taps (x the NB / MB blocks that share it), so it was converted nine times over, and a fragment cost two
+// 16-byte LDS reads.  Here a value is rounded ONCE when its tile is staged; the same 80-byte pixel pitch now holds 32 channels, a lane's
+// fragment of a 32-step MFMA is ONE ds_read_b128 (8 channels of one tap; conflict-free as before: 5 is coprime with 16), a chunk is 32
+// channels of all nine taps (no half-empty step for the ninth tap), and there are half as many chunk rounds (two barriers each).
+// Same results as rounding per use up to the fp32 summation order inside the accumulator.
+template <int NB, int ACT_IN, int ACT_OUT>
+__global__ __launch_bounds__(kBlock) void conv3_bf16_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CN = 2 * CK;   // channels per chunk
+  float amax_a = 0.f, amax_b = 0.f;
+  bool rec_a = false, rec_b = false;
+  if (a.q) {   // a calibrating pass of the fp8 configuration runs bf16 operands and collects the amax of what it staged
+    const bool rec = a.q->record != 0.f;
+    rec_a = rec && blockIdx.y == 0, rec_b = rec && blockIdx.x == 0;
+  }
+  const int TWp = a.TW + 2;
+  float* sIn = smem;
+  float* sW = smem + (a.TH + 2) * TWp * CKP;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, kk = lane >> 4;
+  const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+  const int x0 = tx * a.TW, v0 = ty * a.TH, n0 = blockIdx.y * NB * 16;
+  const int dyj = j / a.TW, dxj = j - dyj * a.TW;
+  int base[MB];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    const int64_t p = pixel_of(v0 + (wave * MB + mb) * a.RB + dyj, x0 + dxj, a.B, a.H, a.W, a.VR);
-    if (p < 0) continue;
+  for (int mb = 0; mb < MB; ++mb) base[mb] = (((wave * MB + mb) * a.RB + dyj) * TWp + dxj) * CKP + 4 * kk;
+  f32x4 acc[NB][MB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int n = n0 + nb * 16 + 4 * kk;
-      if (n >= a.N) continue;
-      float v[4] = {acc[nb][mb][0], acc[nb][mb][1], acc[nb][mb][2], acc[nb][mb][3]};
-      if (a.nsplit > 1) {   // N % 4 == 0 is required for split runs (host-checked)
-        *reinterpret_cast<float4*>(a.part + ((int64_t)blockIdx.z * M + p) * a.N + n) = make_float4(v[0], v[1], v[2], v[3]);
-        continue;
-      }
+  for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (a.bias && n + r < a.N) v[r] += a.bias[n + r];
-      if (a.vec_out && n + 3 < a.N) {
-        if (a.pre) *reinterpret_cast<float4*>(a.pre + p * a.ldpre + n) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(a.out + p * a.ldo + n) = make_float4(act_fwd<ACT_OUT>(v[0]), act_fwd<ACT_OUT>(v[1]), act_fwd<ACT_OUT>(v[2]), act_fwd<ACT_OUT>(v[3]));
-      } else {
+    for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this split's channel range (chunks_per_split counts 16-channel units and is even for split runs: plan_split)
+  const int kbeg = blockIdx.z * a.chunks_per_split * CK;
+  const int kend = kbeg + a.chunks_per_split * CK < a.K ? kbeg + a.chunks_per_split * CK : a.K;
+  constexpr int kItIn = 4;                                    // (TH+2)(TW+2) pixels x 4 channel octets / 256 <= 3.2
+  constexpr int kItW = (9 * NB * 64 + kBlock - 1) / kBlock;   // 9 taps x NB*16 output channels x 4 octets
+  const int PT = (a.TH + 2) * TWp;
+  float rin[kItIn][8], rw[kItW][8];
+  auto load_chunk = [&](int c0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < a.N) {
-            if (a.pre) a.pre[p * a.ldpre + n + r] = v[r];
-            a.out[p * a.ldo + n + r] = act_fwd<ACT_OUT>(v[r]);
+    for (int u = 0; u < kItIn; ++u) {
+      const int it = threadIdx.x + u * kBlock;
+      const int pix = it >> 2, q = it & 3, r = pix / TWp, cc = pix - r * TWp, ch = c0 + 8 * q;
+      const int64_t p = it < PT * 4 ? pixel_of(v0 - 1 + r, x0 - 1 + cc, a.B, a.H, a.W, a.VR) : -1;
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (p >= 0 && ch < kend) {
+        if (a.vec_in && ch + 7 < kend) {
+          const float4 t0 = *reinterpret_cast<const float4*>(a.in + p * a.ldin + ch), t1 = *reinterpret_cast<const float4*>(a.in + p * a.ldin + ch + 4);
+          v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+          if (ACT_IN != ADNM_ACT_NONE) {   // (applied here, not when the chunk goes to LDS: between the barriers it was 35 % slower)
+            const float4 g0 = *reinterpret_cast<const float4*>(a.in2 + p * a.ldin2 + ch), g1 = *reinterpret_cast<const float4*>(a.in2 + p * a.ldin2 + ch + 4);
+            v[0] *= act_grad<ACT_IN>(g0.x); v[1] *= act_grad<ACT_IN>(g0.y); v[2] *= act_grad<ACT_IN>(g0.z); v[3] *= act_grad<ACT_IN>(g0.w);
+            v[4] *= act_grad<ACT_IN>(g1.x); v[5] *= act_grad<ACT_IN>(g1.y); v[6] *= act_grad<ACT_IN>(g1.z); v[7] *= act_grad<ACT_IN>(g1.w);
           }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (ch + e < kend) {
+              v[e] = a.in[p * a.ldin + ch + e];
+              if (ACT_IN != ADNM_ACT_NONE) v[e] *= act_grad<ACT_IN>(a.in2[p * a.ldin2 + ch + e]);
+            }
+        }
       }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rin[u][e] = v[e];
+    }
+    // weights of this chunk: the octet at sW[(tap*NB*16 + nl)*CKP + 4 kq] = W(n0 + nl, tap, c0 + 8 kq ..)
+#pragma unroll
+    for (int u = 0; u < kItW; ++u) {
+      const int it = threadIdx.x + u * kBlock;
+      const int kq = it & 3, nl = (it >> 2) % (NB * 16), tap = it / (NB * 64);
+      const int n = n0 + nl, k0 = c0 + 8 * kq;
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (it < 9 * NB * 64 && n < a.N && k0 < kend) {
+        const float* wp = a.w + (int64_t)n * a.sn + (int64_t)(a.flip ? 8 - tap : tap) * a.st + (int64_t)k0 * a.sk;
+        if (a.vec_w && k0 + 7 < kend) {
+          const float4 t0 = *reinterpret_cast<const float4*>(wp), t1 = *reinterpret_cast<const float4*>(wp + 4);
+          v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (k0 + e < kend) v[e] = wp[(int64_t)e * a.sk];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rw[u][e] = v[e];
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int u = 0; u < kItIn; ++u) {
+      const int it = threadIdx.x + u * kBlock;
+      if (it >= PT * 4) break;
+      if (rec_a) amax_a = adnm_amax4(adnm_amax4(amax_a, rin[u][0], rin[u][1], rin[u][2], rin[u][3]), rin[u][4], rin[u][5], rin[u][6], rin[u][7]);
+      *reinterpret_cast<adnm_bf16x8*>(sIn + (it >> 2) * CKP + 4 * (it & 3)) = adnm_pack_bf16x8(rin[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kItW; ++u) {
+      const int it = threadIdx.x + u * kBlock;
+      if (it >= 9 * NB * 64) break;
+      const int kq = it & 3, nl = (it >> 2) % (NB * 16), tap = it / (NB * 64);
+      if (rec_b) amax_b = adnm_amax4(adnm_amax4(amax_b, rw[u][0], rw[u][1], rw[u][2], rw[u][3]), rw[u][4], rw[u][5], rw[u][6], rw[u][7]);
+      *reinterpret_cast<adnm_bf16x8*>(sW + (tap * NB * 16 + nl) * CKP + 4 * kq) = adnm_pack_bf16x8(rw[u]);
+    }
+  };
+  if (kbeg < kend) load_chunk(kbeg);
+  for (int c0 = kbeg; c0 < kend; c0 += CN) {
+    __syncthreads();   // every wave has finished reading the previous chunk's LDS images
+    store_chunk();
+    __syncthreads();
+    if (c0 + CN < kend) load_chunk(c0 + CN);   // in flight under this chunk's MFMAs
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = ((tap / 3) * TWp + (tap % 3)) * CKP;
+      adnm_bf16x8 fw[NB], fx[MB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) fw[nb] = *reinterpret_cast<const adnm_bf16x8*>(sW + (tap * NB * 16 + nb * 16 + j) * CKP + 4 * kk);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) fx[mb] = *reinterpret_cast<const adnm_bf16x8*>(sIn + base[mb] + toff);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nb], fx[mb], acc[nb][mb], 0, 0, 0);
     }
   }
+  if (rec_a) adnm_amax_commit(&a.q->amax_a, amax_a);
+  if (rec_b) adnm_amax_commit(&a.q->amax_b, amax_b);
+  conv3_epilogue<NB, ACT_OUT>(a, acc, wave, kk, dyj, dxj, x0, v0, n0);
 }
 
 // split runs: out = act(sum_z part[z] + bias) (+ pre), one float4 per thread
@@ -495,6 +634,7 @@ inline Split plan_split(const Geo& g, int64_t K, int64_t N) {
     if (want < 1) want = 1;
   }
   s.cps = (int)adnm_cdiv(nchunks, want);
+  if (want > 1 && (s.cps & 1)) ++s.cps;   // whole 32-channel chunks per split: the bf16 kernel's chunk is two of these units
   s.nsplit = (int)adnm_cdiv(nchunks, s.cps);
   return s;
 }
@@ -510,8 +650,13 @@ int launch_conv(const ConvArgs& a, const Geo& g, const Split& s, int prec, hipSt
     else if (s.nb == 2) conv3_kernel<2, ACT_IN, ACT_OUT, PRECV, BF8V><<<grid, kBlock, smem, st>>>(a);    \
     else conv3_kernel<1, ACT_IN, ACT_OUT, PRECV, BF8V><<<grid, kBlock, smem, st>>>(a);                   \
   } while (0)
-  if (prec == ADNM_MFMA_BF16) CV(ADNM_MFMA_BF16, false);
-  else if (prec == ADNM_MFMA_FP8) CV(ADNM_MFMA_FP8, false);
+  static const bool fp32_images = getenv("ADNM_CONV3_FP32_IMAGES") && atoi(getenv("ADNM_CONV3_FP32_IMAGES")) != 0;   // measurement aid: the round-3 kernel
+  if (prec == ADNM_MFMA_BF16 && fp32_images) CV(ADNM_MFMA_BF16, false);
+  else if (prec == ADNM_MFMA_BF16) {
+    if (s.nb == 4) conv3_bf16_kernel<4, ACT_IN, ACT_OUT><<<grid, kBlock, smem, st>>>(a);
+    else if (s.nb == 2) conv3_bf16_kernel<2, ACT_IN, ACT_OUT><<<grid, kBlock, smem, st>>>(a);
+    else conv3_bf16_kernel<1, ACT_IN, ACT_OUT><<<grid, kBlock, smem, st>>>(a);
+  } else if (prec == ADNM_MFMA_FP8) CV(ADNM_MFMA_FP8, false);
   else if (prec == ADNM_MFMA_FP8_GRAD) CV(ADNM_MFMA_FP8, true);
   else CV(ADNM_MFMA_F32, false);
 #undef CV

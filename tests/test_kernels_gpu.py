@@ -967,20 +967,38 @@ def test_tsgemm_bf16_mfma(M, K, N, bf16_mfma):
     assert_close(bg.grad, cot.double().sum(0), 1e-5, "db")
 
 
-def test_conv3_bf16_mfma(bf16_mfma):
-    B, H, W, K, N = 2, 16, 16, 32, 64
-    x, w, b, cot = T("bfc.x", (B, H * W, K)), T("bfc.w", (N, K, 3, 3), 0.2), T("bfc.b", (N,)), T("bfc.c", (B, H * W, N))
+@pytest.mark.parametrize("B,H,W,K,N,act", [(2, 16, 16, 32, 64, "none"), (1, 32, 32, 5, 32, "gelu"), (2, 8, 8, 20, 20, "none"), (1, 16, 16, 128, 32, "gelu"),
+                                           (4, 4, 4, 256, 64, "none"), (1, 8, 8, 144, 48, "gelu"), (2, 4, 4, 512, 128, "gelu"), (1, 24, 40, 72, 16, "none")])
+def test_conv3_bf16_mfma(B, H, W, K, N, act, bf16_mfma):
+    """bf16 configuration: forward and input gradient run on bf16 LDS images (csrc/conv3.hip: conv3_bf16_kernel — 32-channel chunks, one
+    rounding per staged value): EXACTLY (fp32 summation order) the conv of the bf16-rounded operands.  Shapes: one / several chunks, a
+    ragged last chunk (K = 5, 20, 72, 144), split reductions with the join kernel (4 x 4 maps), GELU in the epilogue / on the way in."""
+    a = lib.ACT_GELU if act == "gelu" else lib.ACT_NONE
+    x, w, b, cot = T(f"bfc.x{K}", (B, H * W, K)), T(f"bfc.w{K}{N}", (N, K, 3, 3), 0.2), T(f"bfc.b{N}", (N,)), T(f"bfc.c{N}{H}", (B, H * W, N))
     xg, wg, bg = leaf(x, DEV), leaf(w, DEV), leaf(b, DEV)
-    yg = ops.conv3(xg, wg, bg, H, W, lib.ACT_NONE)
+    yg = ops.conv3(xg, wg, bg, H, W, a)
     (yg * cot.to(DEV)).sum().backward()
-    xr, wr, cr = _bf16_round(x).double(), _bf16_round(w).double(), _bf16_round(cot).double()
+    xr, wr = _bf16_round(x).double(), _bf16_round(w).double()
     xo, wo = leaf(xr), leaf(wr)
-    yo = F.conv2d(xo.view(B, H, W, K).permute(0, 3, 1, 2), wo, b.double(), padding=1).permute(0, 2, 3, 1).reshape(B, H * W, N)
-    (yo * cr).sum().backward()
-    assert_close(yg, yo, 2e-6, "y vs the conv of bf16-rounded operands")
-    assert_close(xg.grad, xo.grad, 2e-6, "dx")
-    assert_close(wg.grad, wo.grad, 2e-6, "dw")
-    assert_close(bg.grad, cot.double().sum((0, 1)), 1e-5, "db (fp32 sums of the unrounded gradient)")
+    pre = F.conv2d(xo.view(B, H, W, K).permute(0, 3, 1, 2), wo, b.double(), padding=1).permute(0, 2, 3, 1).reshape(B, H * W, N)
+    assert_close(yg, F.gelu(pre) if act == "gelu" else pre, 2e-6, "y vs the conv of bf16-rounded operands")
+    # backward: the kernels round dpre = cot * act'(pre) (pre = the fp32 value the forward saved) on the way in
+    pre32 = pre.detach().float()
+    if act == "gelu":
+        pl = pre32.clone().requires_grad_(True)
+        F.gelu(pl).backward(cot)
+        dpre = pl.grad
+    else:
+        dpre = cot
+    dr = _bf16_round(dpre).double()
+    dxo = F.conv_transpose2d(dr.view(B, H, W, N).permute(0, 3, 1, 2), wr, padding=1).permute(0, 2, 3, 1).reshape(B, H * W, K)
+    # (GELU: the reference's dpre comes from ITS pre-activation, the kernel's from the fp32 value it saved — the last-bit differences flip a
+    # bf16 rounding of dpre once in ~4e4 elements, each flip 2^-9 of its element: rel-L2 up to ~5e-5; a wrong lane map would be >= 1e-2)
+    gt = 2e-4 if act == "gelu" else 2e-6
+    assert_close(xg.grad, dxo, gt, "dx")
+    dwo = torch.nn.grad.conv2d_weight(xr.view(B, H, W, K).permute(0, 3, 1, 2), (N, K, 3, 3), dr.view(B, H, W, N).permute(0, 3, 1, 2), padding=1)
+    assert_close(wg.grad, dwo, gt, "dw")
+    assert_close(bg.grad, dpre.double().sum((0, 1)), 1e-5, "db (fp32 sums of the unrounded gradient)")
 
 
 # ------------------------------------------------------------------------------------------- fp8 MFMA precision (BASELINE config 5)
