@@ -4,7 +4,7 @@ import csv, re, sys, glob
 d = sys.argv[1]
 f = (glob.glob(d + '/*/*_kernel_trace.csv') + glob.glob(d + '/*_kernel_trace.csv'))[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "adamw_kernel" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "adamw_kernel" in r["Kernel_Name"] or "adamw_seg_kernel" in r["Kernel_Name"]]
 lo, hi = marks[-2] + 1, marks[-1] + 1
 for r in rows[lo:hi]:
     wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
