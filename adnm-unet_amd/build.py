@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "adnm_hip", "libadnm_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", os.environ.get("ADNM_HIPCC_OPT", "-O3"), "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc():
