@@ -127,20 +127,85 @@ int fold_lc(int rows, int n) {
   if (rows <= 32) return 7;
   return 6;
 }
+constexpr int kFoldVec = 16;   // FoldDesc::acc bit 4: the set is folded four columns per lane (16-byte loads)
 __global__ __launch_bounds__(kFoldThreads) void fold_rows_kernel(MultiFold mf_by_value) {
-  __shared__ float sm[kFoldThreads + kFoldThreads / 4];
+  __shared__ __attribute__((aligned(16))) float sm[4 * (kFoldThreads + kFoldThreads / 4)];
   // The descriptor table is indexed with a run-time (workgroup-uniform) k: read it through the kernarg segment pointer (constant
   // memory / scalar loads).  The explicit arguments of a HIP kernel start at offset 0 of that segment.
   (void)mf_by_value;
   const __attribute__((address_space(4))) MultiFold& mf = *(const __attribute__((address_space(4))) MultiFold*)__builtin_amdgcn_kernarg_segment_ptr();
+  // which descriptor: count the prefix entries at or below blockIdx with CONSTANT indices — three s_load_dwordx16 and 48 scalar compares; a
+  // `while (blockIdx >= blk_end[k]) ++k` walk is a chain of up to 48 dependent scalar loads in front of every workgroup of the late sets
+  // (unused entries repeat the total: launch_folds)
   int k = 0;
-  while (k + 1 < mf.count && (int)blockIdx.x >= mf.blk_end[k]) ++k;
+#pragma unroll
+  for (int i = 0; i < kMaxFolds - 1; ++i) k += (int)blockIdx.x >= mf.blk_end[i] ? 1 : 0;
   const __attribute__((address_space(4))) FoldDesc& fd = mf.d[k];
   const float* __restrict__ part = fd.part;
   const int rows = fd.rows, n = fd.n, lc = fd.lc;
   const int cols = 1 << lc, slices = kFoldThreads >> lc;
   const int cl = threadIdx.x & (cols - 1), sl = threadIdx.x >> lc;
-  const int c = (((int)blockIdx.x - (k ? mf.blk_end[k - 1] : 0)) << lc) + cl;
+  const int blk = (int)blockIdx.x - (k ? mf.blk_end[k - 1] : 0);
+  if (fd.acc & kFoldVec) {
+    // large sets (a weight gradient's split-K slabs: a few rows x 10^5 .. 10^6 columns): four adjacent columns per lane.  Row slices, unroll
+    // and tree are those of the scalar path, so every column is summed in the same order — bit for bit the scalar result, a quarter of the
+    // load instructions (the scalar walk ran at 1.2 TB/s on the 50 MB sets)
+    const int c = ((blk << lc) + cl) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < n) {
+      float4 acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+      int r = sl;
+      for (; r + 7 * slices < rows; r += 8 * slices) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(part + (int64_t)(r + u * slices) * n + c);
+        acc.x += (v[0].x + v[1].x) + (v[2].x + v[3].x), acc.y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
+        acc.z += (v[0].z + v[1].z) + (v[2].z + v[3].z), acc.w += (v[0].w + v[1].w) + (v[2].w + v[3].w);
+        acc2.x += (v[4].x + v[5].x) + (v[6].x + v[7].x), acc2.y += (v[4].y + v[5].y) + (v[6].y + v[7].y);
+        acc2.z += (v[4].z + v[5].z) + (v[6].z + v[7].z), acc2.w += (v[4].w + v[5].w) + (v[6].w + v[7].w);
+      }
+      for (; r < rows; r += slices) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)r * n + c);
+        acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+      }
+      acc.x += acc2.x, acc.y += acc2.y, acc.z += acc2.z, acc.w += acc2.w;
+    }
+    float4* const mine = reinterpret_cast<float4*>(sm) + sl * (cols + 1) + cl;
+    *mine = acc;
+    __syncthreads();
+    for (int h = slices >> 1; h >= 1; h >>= 1) {   // fixed tree over the row slices
+      if (sl < h) {
+        const float4 o = mine[h * (cols + 1)];
+        float4 m = *mine;
+        m.x += o.x, m.y += o.y, m.z += o.z, m.w += o.w;
+        *mine = m;
+      }
+      __syncthreads();
+    }
+    if (sl == 0 && c < n) {
+      const float4 t = *mine;
+      int begin = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (c < fd.segs.end[q]) {   // (segment boundaries are multiples of 4 in this mode: the four columns share a segment)
+          if (fd.segs.ptr[q]) {
+            float4* dst = reinterpret_cast<float4*>(fd.segs.ptr[q] + (c - begin));
+            if (fd.acc & (1 << q)) {
+              float4 d = *dst;
+              d.x += t.x, d.y += t.y, d.z += t.z, d.w += t.w;
+              *dst = d;
+            } else {
+              *dst = t;
+            }
+          }
+          break;
+        }
+        begin = fd.segs.end[q];
+      }
+    }
+    return;
+  }
+  const int c = (blk << lc) + cl;
   float acc = 0.f;
   if (c < n) {
     // independent loads: 8 in flight per lane, two accumulators (fixed order -> still deterministic)
@@ -180,6 +245,8 @@ __global__ __launch_bounds__(kFoldThreads) void fold_rows_kernel(MultiFold mf_by
   }
 }
 
+inline int fold_blocks(const FoldDesc& d) { return (int)adnm_cdiv(d.n, (int64_t)(1 << d.lc) * ((d.acc & kFoldVec) ? 4 : 1)); }
+
 struct FoldQueue {
   std::vector<FoldDesc> pending;
   std::vector<const char*> names;
@@ -215,7 +282,7 @@ void launch_folds(const FoldDesc* d, const char* const* names, int count, hipStr
     double bytes = 0;
     for (int k = 0; k < m; ++k) {
       mf.d[k] = d[i0 + k];
-      blocks += (int)adnm_cdiv(d[i0 + k].n, 1 << d[i0 + k].lc);
+      blocks += fold_blocks(d[i0 + k]);
       mf.blk_end[k] = blocks;
       bytes += 4.0 * ((double)d[i0 + k].rows + 1) * d[i0 + k].n;
     }
@@ -239,11 +306,14 @@ void adnm_launch_fold(const char* prof_name, const float* part, int rows, int n,
   tls_fold_acc_next = 0;
   const AdnmFoldSeg in[4] = {s0, s1, s2, s3};
   int end = 0;
+  bool vec = n >= 2048 && n % 4 == 0 && ((uintptr_t)part & 15) == 0;   // four columns per lane: every segment starts and ends on a 16-byte boundary
   for (int k = 0; k < 4; ++k) {
     end += in[k].len;
     fd.segs.ptr[k] = in[k].ptr;
     fd.segs.end[k] = end;
+    vec = vec && in[k].len % 4 == 0 && ((uintptr_t)in[k].ptr & 15) == 0;
   }
+  if (vec) fd.acc |= kFoldVec;
   if (tls_foldq) {   // deferred: the caller keeps `part` and the destinations alive until adnm_foldq_flush
     tls_foldq->pending.push_back(fd);
     tls_foldq->names.push_back(prof_name);
@@ -282,7 +352,7 @@ extern "C" int adnm_foldq_flush(void* q, adnm_stream_t stream) {
   std::vector<FoldDesc> plain, accs;
   std::vector<const char*> pn, an;
   for (size_t i = 0; i < fq->pending.size(); ++i) {
-    if (fq->pending[i].acc) accs.push_back(fq->pending[i]), an.push_back(fq->names[i]);
+    if (fq->pending[i].acc & 15) accs.push_back(fq->pending[i]), an.push_back(fq->names[i]);
     else plain.push_back(fq->pending[i]), pn.push_back(fq->names[i]);
   }
   if (!plain.empty()) launch_folds(plain.data(), pn.data(), (int)plain.size(), (hipStream_t)stream);

@@ -916,6 +916,21 @@ def test_lincomb_scalar_mix_any_channel_count():
 
 
 # ------------------------------------------------------------------------------------------- bf16 MFMA precision (BASELINE's bf16 configs)
+@pytest.mark.parametrize("rows,n", [(2, 16384), (5, 65536 + 4), (16, 262144), (40, 32768), (300, 20480)])
+def test_fold_four_columns_per_lane_is_bitwise_the_scalar_fold(rows, n):
+    """The shared second-stage fold takes large, 16-byte aligned partial sets four columns per lane (csrc/core.hip: kFoldVec); row slices,
+    unroll and tree are those of the one-column walk, so every column is summed in the same order: the same bits.  The scalar walk is
+    reached here through a partial set that starts 4 bytes off a 16-byte boundary."""
+    buf = torch.randn(rows * n + 8, device=DEV)
+    a = buf[:rows * n].view(rows, n)
+    b = torch.empty(rows * n + 8, device=DEV)[1:1 + rows * n].view(rows, n)
+    b.copy_(a)
+    assert a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 4
+    va, vb = ops.colsum(a), ops.colsum(b)
+    assert torch.equal(va, vb), "vector and scalar folds must agree bit for bit"
+    assert_close(va, a.double().sum(0), 2e-6, "fold")
+
+
 @pytest.mark.parametrize("rows,n", [(65536, 32), (5000, 257), (2048, 4), (1500, 4), (1024, 131), (300, 3000), (7, 5), (3, 5000), (12, 3001), (20, 4000), (2, 263168)])
 def test_colsum(rows, n):
     """bias-gradient column sums: two-stage above 2048 rows, the shared fold (every workgroup geometry, 4 .. 1024 columns) below"""
