@@ -38,7 +38,7 @@ def timed(fn):
 for name in (sys.argv[1:] or ["f32", "bf16"]):
     prec = PREC[name]
     print(f"--- {name}: us per launch (graph of {REPS} launches on {REPS} operand copies)", flush=True)
-    tot = [0.0, 0.0]
+    tot = [0.0, 0.0, 0.0]
     for H, W, K, N in SHAPES:
         M = B * H * W
         xs = [torch.randn(M, K, device=dev) for _ in range(REPS)]
@@ -60,9 +60,19 @@ for name in (sys.argv[1:] or ["f32", "bf16"]):
                 lib.call("adnm_conv3_dgrad", dy.data_ptr(), N, pre.data_ptr() if act else None, N, act, w.data_ptr(), 9 * K, K, 1, dx.data_ptr(), K,
                          wsd.data_ptr(), nbd, B, H, W, K, N, prec, None, st)
 
-        t_f, t_d = timed(fwd), timed(dgrad)
+        nbw = lib.query("adnm_conv3_wgrad_ws_bytes", B, H, W, K, N)
+        wsw = torch.empty(max(nbw, 16), dtype=torch.uint8, device=dev)
+        dw, db = torch.empty(N, 3, 3, K, device=dev), torch.empty(N, device=dev)
+
+        def wgrad(st):   # (kernel + its fold: launched directly here; a queued leaf + a batched fold under a trainer)
+            for x, dy in zip(xs, dys):
+                lib.call("adnm_conv3_wgrad", dy.data_ptr(), N, pre.data_ptr() if act else None, N, act, x.data_ptr(), K, dw.data_ptr(), db.data_ptr(),
+                         wsw.data_ptr(), nbw, B, H, W, K, N, prec, st)
+
+        t_f, t_d, t_w = timed(fwd), timed(dgrad), timed(wgrad)
         mb = 4.0 * M * (K + N) / 1e6
-        print(f"{H:4d}x{W:<4d} {K:4d} -> {N:<4d} {mb:6.1f} MB   fwd {t_f:6.1f}   dgrad {t_d:6.1f}", flush=True)
+        print(f"{H:4d}x{W:<4d} {K:4d} -> {N:<4d} {mb:6.1f} MB   fwd {t_f:6.1f}   dgrad {t_d:6.1f}   wgrad + fold {t_w:6.1f}", flush=True)
         tot[0] += t_f
         tot[1] += t_d
-    print(f"sum: fwd {tot[0]:.1f} us, dgrad {tot[1]:.1f} us")
+        tot[2] += t_w
+    print(f"sum: fwd {tot[0]:.1f} us, dgrad {tot[1]:.1f} us, wgrad + fold {tot[2]:.1f} us")
