@@ -2309,6 +2309,9 @@ def _conv3_wstrides(w):
     return sn, skw, sk
 
 
+_CONV3_DPRE_ONCE = [os.environ.get("ADNM_CONV3_DPRE_ONCE", "1") != "0"]   # (measurement aid: 0 = the gradient kernels apply act' themselves)
+
+
 class Conv3Fn(torch.autograd.Function):
     """nn.Conv2d(k=3, s=1, p=1) [+ bias] [+ GELU] on (B, H*W, Cin) tokens (csrc/conv3.hip): implicit GEMM on MFMA, bias and
     activation in the epilogue; the pre-activation is saved for backward exactly as autograd saves it for a separate GELU."""
@@ -2345,6 +2348,13 @@ class Conv3Fn(torch.autograd.Function):
         dev = x2.device
         dy2 = dy.reshape(B * H * W, N)
         dy2 = dy2 if dy2.stride(-1) == 1 else dy2.contiguous()
+        if act != lib.ACT_NONE and _CONV3_DPRE_ONCE[0] and dy2.is_contiguous() and (B * H * W * N) % 4 == 0:
+            # dpre = dy * act'(pre) ONCE, as one elementwise pass: both gradient kernels stage this product tile by tile — the input gradient
+            # once per output-channel group, the weight gradient once per 16-channel input chunk (4 x for a 64 -> 64 conv) — and their
+            # loads (two arrays + the erf) are ~half of their time (profiles/r04_conv3_phases.txt).  Same fp32 product, same rounding after.
+            dpre = torch.empty_like(pre)
+            lib.call("adnm_act_bwd", dy2.data_ptr(), pre.data_ptr(), dpre.data_ptr(), pre.numel(), act, _stream())
+            dy2, pre, act = dpre, None, lib.ACT_NONE
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((B * H * W, K), dtype=torch.float32, device=dev)
